@@ -1,0 +1,114 @@
+/*
+ * vohip.h -- C ABI of libvohip.so, the MI355X (gfx950) implementation of the per-frame
+ * continuous-operation hot path of the MATLAB visual-odometry pipeline.
+ *
+ * The reference has no FFI; its boundary is the set of MATLAB function signatures.
+ * Every entry point below names the reference function (file:line) it stands in for.
+ * A MEX gateway (or ctypes, as the bundled Python host layer does) binds these
+ * symbols one to one.
+ *
+ * Conventions
+ *  - All matrices are column-major, exactly as MATLAB stores them: "3xN" means N
+ *    consecutive groups of 3 values.
+ *  - Every function returns a vohip_status; 0 is success.  vohip_last_error(ctx)
+ *    returns a human-readable message for the last non-zero status of that context.
+ *  - The caller owns every buffer it passes.  The library never keeps a host pointer
+ *    after a call returns.  Device scratch memory belongs to the context.
+ *  - A context is bound to one GPU and one HIP stream and must be used from one host
+ *    thread at a time; different contexts are independent.
+ *  - Functions whose name ends in _dev take DEVICE pointers for the arrays documented
+ *    as such, enqueue their kernels on the context's stream and return without
+ *    synchronising.  All other functions take host pointers and return with the
+ *    results in place.
+ *  - Index arguments are 0-based (a MATLAB caller subtracts 1).
+ */
+#ifndef VOHIP_H
+#define VOHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vohip_ctx vohip_ctx;
+
+typedef enum vohip_status {
+    VOHIP_OK = 0,
+    VOHIP_ERR_INVALID_ARGUMENT = 1,
+    VOHIP_ERR_HIP = 2,              /* a HIP runtime call failed; see vohip_last_error */
+    VOHIP_NO_MODEL = 3,             /* RANSAC: no hypothesis reached the minimum inlier count
+                                       (the reference returns R = t = [], ransacLocalization.m:138-140) */
+    VOHIP_SAMPLES_EXHAUSTED = 4,    /* RANSAC: the adaptive stop was not reached within the supplied
+                                       sample triples; outputs hold the best model so far */
+    VOHIP_TOO_FEW_POINTS = 5,
+    VOHIP_ERR_NO_DEVICE = 6
+} vohip_status;
+
+/* ---- context ------------------------------------------------------------------------------ */
+
+/* Creates a context on GPU `device_id`.  `hip_stream` is a hipStream_t to enqueue on, or NULL to
+ * let the context create (and own) a stream.  No reference counterpart: the reference keeps all
+ * state in MATLAB workspace variables. */
+int vohip_create(vohip_ctx **out, int device_id, void *hip_stream);
+int vohip_destroy(vohip_ctx *ctx);
+const char *vohip_last_error(const vohip_ctx *ctx);
+/* The hipStream_t all kernels of this context are enqueued on. */
+void *vohip_stream(vohip_ctx *ctx);
+int vohip_synchronize(vohip_ctx *ctx);
+/* Library version, "major.minor". */
+const char *vohip_version(void);
+
+/* ---- P3P RANSAC localisation ---------------------------------------------------------------
+ * Replaces utils/exe7_Ransac/ransacLocalization.m:1-157 together with p3p.m:41-217,
+ * solveQuartic.m:26-66 and the projectPoints.m:1-16 calls inside it (use_p3p = true,
+ * tweaked_for_more = true, adaptive = true, the only configuration the reference runs).
+ *
+ * The reference draws each 3-point sample with datasample from MATLAB's global RNG
+ * (ransacLocalization.m:46-47).  Here the caller draws the index triples (with the same toolbox
+ * call, so the hypothesis set is identical) and passes them in: samples is 3 x hcap, 0-based.
+ */
+
+/* Full adaptive RANSAC on host buffers.
+ *   kp_rc   2xN keypoints in (row, col) order, as the reference passes them (main_demo.m:387-388)
+ *   X       3xN landmarks
+ *   K       3x3 camera matrix
+ *   R_C_W (3x3), t_C_W (3): pose of the best hypothesis; untouched when VOHIP_NO_MODEL
+ *   mask    N bytes, 1 = inlier of the best hypothesis (all 0 when VOHIP_NO_MODEL)
+ *   max_num_inliers_history, num_iteration_history: hcap doubles each, first *n_iter filled
+ *   n_iter  iterations the reference loop would have executed (i-1 at ransacLocalization.m:155)
+ * Hypotheses are evaluated in chunks on the GPU; the adaptive-stop recurrence of
+ * ransacLocalization.m:118-135 is then replayed in sample order, so hypotheses past the stop
+ * index never influence the result. */
+int vohip_ransac_p3p(vohip_ctx *ctx, const double *kp_rc, const double *X, int n, const double K[9],
+                     const int32_t *samples, int hcap,
+                     double R_C_W[9], double t_C_W[3], uint8_t *mask,
+                     double *max_num_inliers_history, double *num_iteration_history, int *n_iter);
+
+/* Hypothesis generation + inlier scoring only (ransacLocalization.m:46-101 for h hypotheses at
+ * once), everything resident on the GPU: d_kp_rc (2xN), d_X (3xN), d_samples (3xh int32) and
+ * d_counts (4xh int32, out: inlier count of each of the 4 P3P solutions) are device pointers.
+ * Asynchronous on the context's stream. */
+int vohip_ransac_p3p_score_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
+                               const double K[9], const int32_t *d_samples, int h,
+                               int32_t *d_counts);
+
+/* Poses behind the counts of the last vohip_ransac_p3p_score_dev call: copies, for hypotheses
+ * [first, first+count), the 4 candidate poses as 12 doubles each ([R_C_W col-major | t_C_W]) to
+ * the host array Rt (count x 4 x 12).  Synchronises the stream. */
+int vohip_ransac_p3p_poses(vohip_ctx *ctx, int first, int count, double *Rt);
+
+/* Inlier mask of one pose over device-resident points, with exactly the arithmetic the scoring
+ * kernel counts with.  Rt = [R_C_W col-major | t_C_W].  d_mask: n bytes, device.  Asynchronous. */
+int vohip_ransac_inlier_mask_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
+                                 const double K[9], const double Rt[12], uint8_t *d_mask);
+
+/* p3p.m:41-217 for `count` independent problems (host buffers): world and bearings are
+ * count x (3x3), poses count x (3x16) as the reference lays them out
+ * ([C1 R1 C2 R2 C3 R3 C4 R4], real part). */
+int vohip_p3p(vohip_ctx *ctx, const double *world, const double *bearings, int count, double *poses);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

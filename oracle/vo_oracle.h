@@ -1,0 +1,67 @@
+/*
+ * vo_oracle.h -- CPU restatement (plain C, fp64) of the reference MATLAB hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped library links, loads or calls
+ * this code; it is the checker the HIP path is compared against (tests/, the smoke
+ * check and the cpu_baseline leg of bench.py).
+ *
+ * PARITY UNPINNED versus MATLAB itself: the reference ships no tests, golden vectors
+ * or fixtures and MATLAB/Octave are not available, so every function here is pinned
+ * only by (a) analytic known-answer tests and (b) independent numpy/scipy
+ * implementations (tests/test_oracle_*.py).  Each function cites the reference
+ * file:line it restates.  Arrays are column-major, exactly as MATLAB stores them.
+ */
+#ifndef VO_ORACLE_H
+#define VO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* utils/exe7_Ransac/solveQuartic.m:26-66.  factors[5] = A..E, roots as (re, im) pairs. */
+void vo_solve_quartic(const double factors[5], double roots_re[4], double roots_im[4]);
+
+/* utils/exe7_Ransac/p3p.m:41-217.  world 3x3 (columns = points), bearings 3x3 (unit
+ * columns).  poses 3x16 column-major = 4 x [C | R_W_C]; only the real part is kept
+ * (ransacLocalization.m:64-65 discards the imaginary part).  All zeros when the world
+ * points are collinear (p3p.m:56-58). */
+void vo_p3p(const double world[9], const double bearings[9], double poses[48]);
+
+/* utils/exe1/projectPoints.m:1-16 + distortPoints.m:1-18 with D = 0 (as every call
+ * site on the hot path uses it).  p 3xN -> out 2xN. */
+void vo_project_points(const double *p, int n, const double K[9], double *out);
+
+/* Per-hypothesis part of ransacLocalization.m:46-101: sample -> bearings -> p3p ->
+ * decode 4 poses -> score all N points for each -> pick the solution as :95 does.
+ * kp_uv is 2xN in (u,v) order (i.e. after the flipud at :34).  idx3 is 0-based.
+ * Outputs: counts[4] inlier count per solution, *best_sol the index kept by the
+ * strict '>' rule of :95, Rt[12] = [R_C_W (col-major 9) | t_C_W (3)] of that solution,
+ * mask[N] (may be NULL) inlier mask of that solution. */
+void vo_ransac_hypothesis(const double *kp_uv, const double *X, int n, const double K[9],
+                          const int32_t idx3[3], int counts[4], int *best_sol,
+                          double Rt[12], uint8_t *mask);
+
+/* utils/exe7_Ransac/ransacLocalization.m:1-157 with use_p3p = tweaked_for_more =
+ * adaptive = true.  kp_rc 2xN (row; col), X 3xN, K 3x3 column-major.  The reference
+ * draws its index triples from MATLAB's global RNG (datasample, :46-47); here the
+ * caller supplies them: samples 3 x hcap, 0-based.  Returns the number of iterations
+ * executed (i-1 at :155); -1 if the supplied triples ran out before the adaptive
+ * stop.  found = 0 reproduces the empty R/t of :138-140.  hist arrays need hcap
+ * entries.  per_hyp_counts (may be NULL) receives the winning-solution inlier count
+ * of every executed iteration. */
+int vo_ransac_localization(const double *kp_rc, const double *X, int n, const double K[9],
+                           const int32_t *samples, int hcap,
+                           double R_C_W[9], double t_C_W[3], uint8_t *best_mask, int *found,
+                           double *max_num_inliers_history, double *num_iteration_history,
+                           int32_t *per_hyp_counts);
+
+/* The adaptive iteration bound of ransacLocalization.m:118-129 for a given running
+ * maximum inlier count and point count. */
+double vo_ransac_num_iterations(int max_num_inliers, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,59 @@
+"""Regenerates the golden fixtures in this directory from the CPU oracle (oracle/) on seeded
+synthetic inputs.  The reference ships no fixtures and cannot be run (MATLAB), so these vectors
+pin the ORACLE's outputs; the GPU tests compare the HIP path against them.
+
+Usage: python tests/golden/make_golden.py [ransac|...]
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import vo_oracle as orc  # noqa: E402
+import importlib  # noqa: E402
+
+vo_synth = importlib.import_module("visual-odometry-pipeline_amd.synth")
+
+
+def make_ransac():
+    n, h = 2000, 256
+    kp_rc, X, R, t, is_in = vo_synth.pnp_problem(n, seed=7)
+    samples = vo_synth.sample_triples(n, h, seed=42)
+    kp_uv = kp_rc[::-1].T.copy()
+    counts = np.zeros((h, 4), np.int32)
+    best = np.zeros(h, np.int32)
+    poses = np.zeros((h, 12))
+    for i in range(h):
+        c, b, Rh, th, _ = orc.ransac_hypothesis(kp_uv, X.T, vo_synth.K_KITTI, samples[i])
+        counts[i] = c
+        best[i] = b
+        poses[i, :9] = Rh.T.reshape(9)
+        poses[i, 9:] = th
+    res = orc.ransac_localization(kp_rc.T, X.T, vo_synth.K_KITTI, samples)
+    np.savez_compressed(os.path.join(HERE, "ransac_n2000_h256.npz"),
+                        kp_rc=kp_rc, X=X, K=vo_synth.K_KITTI, samples=samples, counts=counts, best_sol=best,
+                        best_pose=poses, R_C_W=res["R_C_W"], t_C_W=res["t_C_W"],
+                        mask=res["mask"], n_iter=res["n_iter"],
+                        max_num_inliers_history=res["max_num_inliers_history"],
+                        num_iteration_history=res["num_iteration_history"])
+    # stand-alone P3P problems (including one collinear, one far-out-of-range root)
+    rng = np.random.default_rng(3)
+    world = rng.uniform(-10, 10, (64, 3, 3)) + np.array([0, 0, 30.0])
+    bear = rng.normal(0, 1, (64, 3, 3)) * np.array([0.3, 0.3, 0]) + np.array([0, 0, 1.0])
+    bear /= np.linalg.norm(bear, axis=2, keepdims=True)
+    world[5, 2] = 2 * world[5, 1] - world[5, 0]  # collinear
+    poses = np.stack([orc.p3p(world[i], bear[i]).reshape(48) for i in range(64)])
+    np.savez_compressed(os.path.join(HERE, "p3p_64.npz"), world=world, bearings=bear, poses=poses)
+
+
+MAKERS = {"ransac": make_ransac}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(MAKERS)
+    for w in which:
+        MAKERS[w]()
+        print("wrote", w)

@@ -1,0 +1,10 @@
+"""MI355X (gfx950) implementation of the per-frame hot path of the MATLAB visual-odometry
+pipeline, behind the reference's own function names.  All arithmetic runs in lib/libvohip.so
+(hand-written HIP); this package is the thin host layer above its C ABI (include/vohip.h).
+"""
+from . import _lib
+from ._lib import Context, VohipError, default_context
+from . import synth
+from .ransac import draw_triples, p3p, ransacLocalization
+
+__all__ = ["Context", "VohipError", "default_context", "ransacLocalization", "p3p", "draw_triples"]

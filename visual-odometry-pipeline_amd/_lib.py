@@ -1,0 +1,134 @@
+"""ctypes binding of libvohip.so -- the one place the C ABI of include/vohip.h is declared to
+Python.  There is no CPU fallback: if the library is missing or no GPU is visible, calls fail.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libvohip.so")
+
+VOHIP_OK = 0
+VOHIP_ERR_INVALID_ARGUMENT = 1
+VOHIP_ERR_HIP = 2
+VOHIP_NO_MODEL = 3
+VOHIP_SAMPLES_EXHAUSTED = 4
+VOHIP_TOO_FEW_POINTS = 5
+VOHIP_ERR_NO_DEVICE = 6
+
+STATUS_NAMES = {
+    0: "VOHIP_OK", 1: "VOHIP_ERR_INVALID_ARGUMENT", 2: "VOHIP_ERR_HIP", 3: "VOHIP_NO_MODEL",
+    4: "VOHIP_SAMPLES_EXHAUSTED", 5: "VOHIP_TOO_FEW_POINTS", 6: "VOHIP_ERR_NO_DEVICE",
+}
+
+c_double_p = C.POINTER(C.c_double)
+c_float_p = C.POINTER(C.c_float)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+c_int_p = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); mirrors include/vohip.h one to one
+SIGNATURES = {
+    "vohip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "vohip_destroy": (C.c_int, [C.c_void_p]),
+    "vohip_last_error": (C.c_char_p, [C.c_void_p]),
+    "vohip_stream": (C.c_void_p, [C.c_void_p]),
+    "vohip_synchronize": (C.c_int, [C.c_void_p]),
+    "vohip_version": (C.c_char_p, []),
+    "vohip_ransac_p3p": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, c_double_p, c_int32_p,
+                                    C.c_int, c_double_p, c_double_p, c_uint8_p, c_double_p, c_double_p,
+                                    c_int_p]),
+    "vohip_ransac_p3p_score_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
+                                              C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_ransac_p3p_poses": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
+    "vohip_ransac_inlier_mask_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
+                                                c_double_p, C.c_void_p]),
+    "vohip_p3p": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, c_double_p]),
+}
+
+_lib = None
+
+
+class VohipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
+        self.status = status
+
+
+def load():
+    """Loads libvohip.so and declares every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s not found: build it with `python %s`" % (LIB_PATH, os.path.join(HERE, "build.py")))
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def colmajor(mat):
+    """MATLAB (column-major) memory image of a 2-D array given in math layout."""
+    return np.ascontiguousarray(np.asarray(mat, dtype=np.float64).T)
+
+
+class Context:
+    """One GPU + one HIP stream.  `stream` is a raw hipStream_t (int) or None."""
+
+    def __init__(self, device=0, stream=None):
+        lib = load()
+        h = C.c_void_p()
+        st = lib.vohip_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None)
+        if st != VOHIP_OK:
+            raise VohipError(st, lib.vohip_last_error(None).decode())
+        self._h = h
+        self.device = device
+
+    @property
+    def handle(self):
+        if self._h is None:
+            raise RuntimeError("context destroyed")
+        return self._h
+
+    def check(self, status, allow=()):
+        if status != VOHIP_OK and status not in allow:
+            raise VohipError(status, load().vohip_last_error(self._h).decode())
+        return status
+
+    def synchronize(self):
+        self.check(load().vohip_synchronize(self.handle))
+
+    def close(self):
+        if self._h is not None:
+            load().vohip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on the GPU named by LOCAL_RANK (one process per GPU), else GPU 0."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

@@ -1,0 +1,661 @@
+// P3P RANSAC localisation for gfx950.
+//
+// Stands in for utils/exe7_Ransac/ransacLocalization.m:1-157 with p3p.m:41-217,
+// solveQuartic.m:26-66 and projectPoints.m:1-16 of the reference.
+//
+// Three kernels:
+//   p3p_solve_kernel   one THREAD per hypothesis: sample -> bearings -> Kneip P3P -> the four
+//                      candidate poses [R_C_W | t_C_W] and the fused projection K [R | t].
+//                      Written statement for statement in the reference's evaluation order and
+//                      compiled without FMA contraction, so poses agree with a CPU evaluation
+//                      of the same statements up to the last bits of pow/atan2/sincos.
+//   p3p_score_kernel   one WAVEFRONT per hypothesis: the 64 lanes stride over the N points,
+//                      each point is tested against the 4 candidate poses, counts come from
+//                      ballot + popcount.  Points are staged once per workgroup into LDS in
+//                      structure-of-arrays form and shared by the workgroup's hypotheses.
+//                      The inlier test is the division-free form of the reference test
+//                      |kp - proj|^2 < 100:  (x - u z)^2 + (y - v z)^2 < 100 z^2,
+//                      13 FMA + 2 MUL + 1 CMP per (pose, point).  It can differ from the
+//                      reference's divide-then-distort arithmetic only for points whose squared
+//                      error is within rounding of the threshold.
+//   inlier_mask_kernel the same test for one pose, writing the mask.
+//
+// The adaptive stop of ransacLocalization.m:118-135 is a sequential recurrence over the
+// per-hypothesis inlier counts; it is replayed on the host in sample order after each chunk
+// of hypotheses, so hypotheses past the stop index never influence the result.
+#include "vohip_internal.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Complex helpers with MATLAB's conventions (principal branches; a zero imaginary part is a
+// real number, so -0.0 imaginary never selects the lower sqrt branch).
+// ------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+
+struct cplx {
+    double re, im;
+};
+
+__device__ __forceinline__ cplx cmk(double re, double im)
+{
+    cplx z;
+    z.re = re;
+    z.im = (im == 0.0) ? 0.0 : im;
+    return z;
+}
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cmk(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return cmk(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ cplx cneg(cplx a) { return cmk(-a.re, -a.im); }
+__device__ __forceinline__ cplx cscale(double s, cplx a) { return cmk(s * a.re, s * a.im); }
+
+// Smith's algorithm.
+__device__ __forceinline__ cplx cdiv(cplx a, cplx b)
+{
+    if (b.im == 0.0) return cmk(a.re / b.re, a.im / b.re);
+    if (fabs(b.re) >= fabs(b.im)) {
+        double r = b.im / b.re;
+        double den = b.re + b.im * r;
+        return cmk((a.re + a.im * r) / den, (a.im - a.re * r) / den);
+    }
+    double r = b.re / b.im;
+    double den = b.re * r + b.im;
+    return cmk((a.re * r + a.im) / den, (a.im * r - a.re) / den);
+}
+
+__device__ __forceinline__ cplx csqrt_principal(cplx z)
+{
+    if (z.im == 0.0) {
+        if (z.re >= 0.0) return cmk(sqrt(z.re), 0.0);
+        if (z.re < 0.0) return cmk(0.0, sqrt(-z.re));
+        return cmk(z.re, z.re);
+    }
+    double m = sqrt(z.re * z.re + z.im * z.im);
+    if (z.re >= 0.0) {
+        double t = sqrt(0.5 * (m + z.re));
+        return cmk(t, z.im / (2.0 * t));
+    }
+    double t = sqrt(0.5 * (m - z.re));
+    if (z.im < 0.0) t = -t;
+    return cmk(z.im / (2.0 * t), t);
+}
+
+__device__ __forceinline__ cplx ccbrt_principal(cplx z)
+{
+    const double third = 1.0 / 3.0;
+    if (z.im == 0.0 && z.re >= 0.0) return cmk(pow(z.re, third), 0.0);
+    double m = sqrt(z.re * z.re + z.im * z.im);
+    double a = atan2(z.im, z.re) * third;
+    double r = pow(m, third);
+    double sa, ca;
+    sincos(a, &sa, &ca);
+    return cmk(r * ca, r * sa);
+}
+
+// solveQuartic.m:26-66; only the real parts of the roots are used by p3p.m:189-192.
+__device__ void solve_quartic_real(const double f[5], double xr[4])
+{
+    const double A = f[0], B = f[1], C = f[2], D = f[3], E = f[4];
+    const double A2 = A * A, B2 = B * B;
+    const double A3 = A2 * A, B3 = B2 * B;
+    const double A4 = A3 * A, B4 = B3 * B;
+
+    const double alpha = -3.0 * B2 / (8.0 * A2) + C / A;
+    const double beta = B3 / (8.0 * A3) - B * C / (2.0 * A2) + D / A;
+    const double gamma =
+        -3.0 * B4 / (256.0 * A4) + B2 * C / (16.0 * A3) - B * D / (4.0 * A2) + E / A;
+
+    const double alpha2 = alpha * alpha;
+    const double alpha3 = alpha2 * alpha;
+    const double P = -alpha2 / 12.0 - gamma;
+    const double Q = -alpha3 / 108.0 + alpha * gamma / 3.0 - (beta * beta) / 8.0;
+    const double disc = (Q * Q) / 4.0 + (P * P * P) / 27.0;
+    const cplx R = cadd(cmk(-Q / 2.0, 0.0), csqrt_principal(cmk(disc, 0.0)));
+    const cplx U = ccbrt_principal(R);
+
+    const cplx lead = cmk(-5.0 * alpha / 6.0, 0.0);
+    cplx y;
+    if (U.re == 0.0 && U.im == 0.0) {
+        y = csub(lead, ccbrt_principal(cmk(Q, 0.0)));
+    } else {
+        y = cadd(csub(lead, cdiv(cmk(P, 0.0), cscale(3.0, U))), U);
+    }
+    const cplx w = csqrt_principal(cadd(cmk(alpha, 0.0), cscale(2.0, y)));
+    const cplx base = cadd(cmk(3.0 * alpha, 0.0), cscale(2.0, y));
+    const cplx bw = cdiv(cmk(2.0 * beta, 0.0), w);
+    const cplx sp = csqrt_principal(cneg(cadd(base, bw)));
+    const cplx sm = csqrt_principal(cneg(csub(base, bw)));
+    const cplx shift = cmk(-B / (4.0 * A), 0.0);
+    xr[0] = cadd(shift, cscale(0.5, cadd(w, sp))).re;
+    xr[1] = cadd(shift, cscale(0.5, csub(w, sp))).re;
+    xr[2] = cadd(shift, cscale(0.5, cadd(cneg(w), sm))).re;
+    xr[3] = cadd(shift, cscale(0.5, csub(cneg(w), sm))).re;
+}
+
+struct v3 {
+    double x, y, z;
+};
+__device__ __forceinline__ v3 vsub(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ v3 vcross(v3 a, v3 b)
+{
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ double vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ v3 vdivs(v3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+
+// 3x3 with named rows; r0,r1,r2 are the rows.
+struct m3 {
+    v3 r0, r1, r2;
+};
+__device__ __forceinline__ v3 mrows_times(const m3 &M, v3 v)
+{
+    return {vdot(M.r0, v), vdot(M.r1, v), vdot(M.r2, v)};
+}
+
+// p3p.m:62-74 / :80-92
+__device__ __forceinline__ void camera_frame(v3 f1, v3 f2, v3 f3in, m3 &T, v3 &f3)
+{
+    v3 e3 = vcross(f1, f2);
+    e3 = vdivs(e3, sqrt(vdot(e3, e3)));
+    v3 e2 = vcross(e3, f1);
+    T.r0 = f1;
+    T.r1 = e2;
+    T.r2 = e3;
+    f3 = mrows_times(T, f3in);
+}
+
+// Kneip P3P, p3p.m:41-217.  out[s][0..2] = C (camera position), out[s][3..11] = R_W_C
+// column-major.  Returns false (and leaves `out` zeroed) for collinear world points.
+__device__ bool p3p_solve(v3 W1, v3 W2, v3 W3, v3 b1, v3 b2, v3 b3, double out[4][12])
+{
+    for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 12; ++j) out[s][j] = 0.0;
+
+    v3 cr = vcross(vsub(W2, W1), vsub(W3, W1));
+    if (sqrt(vdot(cr, cr)) == 0.0) return false;
+
+    v3 P1 = W1, P2 = W2, P3 = W3, f1 = b1, f2 = b2, f3;
+    m3 T;
+    camera_frame(f1, f2, b3, T, f3);
+    if (f3.z > 0.0) {
+        f1 = b2;
+        f2 = b1;
+        P1 = W2;
+        P2 = W1;
+        camera_frame(f1, f2, b3, T, f3);
+    }
+
+    // intermediate world frame, p3p.m:102-110
+    v3 d31 = vsub(P3, P1);
+    v3 n1 = vsub(P2, P1);
+    n1 = vdivs(n1, sqrt(vdot(n1, n1)));
+    v3 n3 = vcross(n1, d31);
+    n3 = vdivs(n3, sqrt(vdot(n3, n3)));
+    v3 n2 = vcross(n3, n1);
+    m3 N = {n1, n2, n3};
+
+    // p3p.m:114-129
+    v3 P3n = mrows_times(N, d31);
+    v3 d21 = vsub(P2, P1);
+    const double d_12 = sqrt(d21.x * d21.x + d21.y * d21.y + d21.z * d21.z);
+    const double f_1 = f3.x / f3.z;
+    const double f_2 = f3.y / f3.z;
+    const double p_1 = P3n.x;
+    const double p_2 = P3n.y;
+    const double cos_beta = vdot(f1, f2);
+    double b = 1.0 / (1.0 - cos_beta * cos_beta) - 1.0;
+    const double sb = (b < 0.0) ? 0.0 : sqrt(b);
+    b = (cos_beta < 0.0) ? -sb : sb;
+
+    const double f_1_pw2 = f_1 * f_1, f_2_pw2 = f_2 * f_2;
+    const double p_1_pw2 = p_1 * p_1, p_1_pw3 = p_1_pw2 * p_1, p_1_pw4 = p_1_pw3 * p_1;
+    const double p_2_pw2 = p_2 * p_2, p_2_pw3 = p_2_pw2 * p_2, p_2_pw4 = p_2_pw3 * p_2;
+    const double d_12_pw2 = d_12 * d_12, b_pw2 = b * b;
+
+    // p3p.m:146-179
+    double fac[5];
+    fac[0] = -f_2_pw2 * p_2_pw4 - p_2_pw4 * f_1_pw2 - p_2_pw4;
+    fac[1] = 2.0 * p_2_pw3 * d_12 * b + 2.0 * f_2_pw2 * p_2_pw3 * d_12 * b -
+             2.0 * f_2 * p_2_pw3 * f_1 * d_12;
+    fac[2] = -f_2_pw2 * p_2_pw2 * p_1_pw2 - f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2 -
+             f_2_pw2 * p_2_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw4 + p_2_pw4 * f_1_pw2 +
+             2.0 * p_1 * p_2_pw2 * d_12 + 2.0 * f_1 * f_2 * p_1 * p_2_pw2 * d_12 * b -
+             p_2_pw2 * p_1_pw2 * f_1_pw2 + 2.0 * p_1 * p_2_pw2 * f_2_pw2 * d_12 -
+             p_2_pw2 * d_12_pw2 * b_pw2 - 2.0 * p_1_pw2 * p_2_pw2;
+    fac[3] = 2.0 * p_1_pw2 * p_2 * d_12 * b + 2.0 * f_2 * p_2_pw3 * f_1 * d_12 -
+             2.0 * f_2_pw2 * p_2_pw3 * d_12 * b - 2.0 * p_1 * p_2 * d_12_pw2 * b;
+    fac[4] = -2.0 * f_2 * p_2_pw2 * f_1 * p_1 * d_12 * b + f_2_pw2 * p_2_pw2 * d_12_pw2 +
+             2.0 * p_1_pw3 * d_12 - p_1_pw2 * d_12_pw2 + f_2_pw2 * p_2_pw2 * p_1_pw2 - p_1_pw4 -
+             2.0 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
+             f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
+
+    double xr[4];
+    solve_quartic_real(fac, xr);
+
+    // p3p.m:187-215
+    for (int s = 0; s < 4; ++s) {
+        const double x = xr[s];
+        const double cot_alpha =
+            (-f_1 * p_1 / f_2 - x * p_2 + d_12 * b) / (-f_1 * x * p_2 / f_2 + p_1 - d_12);
+        const double cos_theta = x;
+        const double st2 = 1.0 - x * x;
+        const double sin_theta = (st2 < 0.0) ? 0.0 : sqrt(st2);  // real part of a pure-imaginary root
+        const double sin_alpha = sqrt(1.0 / (cot_alpha * cot_alpha + 1.0));
+        const double ca2 = 1.0 - sin_alpha * sin_alpha;
+        double cos_alpha = (ca2 < 0.0) ? 0.0 : sqrt(ca2);
+        if (cot_alpha < 0.0) cos_alpha = -cos_alpha;
+
+        const double k = sin_alpha * b + cos_alpha;
+        const v3 Cv = {d_12 * cos_alpha * k, cos_theta * d_12 * sin_alpha * k,
+                       sin_theta * d_12 * sin_alpha * k};
+        // C = P1 + N' * Cv
+        out[s][0] = P1.x + (N.r0.x * Cv.x + N.r1.x * Cv.y + N.r2.x * Cv.z);
+        out[s][1] = P1.y + (N.r0.y * Cv.x + N.r1.y * Cv.y + N.r2.y * Cv.z);
+        out[s][2] = P1.z + (N.r0.z * Cv.x + N.r1.z * Cv.y + N.r2.z * Cv.z);
+
+        const m3 Rm = {{-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta},
+                       {sin_alpha, -cos_alpha * cos_theta, -cos_alpha * sin_theta},
+                       {0.0, -sin_theta, cos_theta}};
+        // R = (N' * Rm') * T ;  (N' Rm')[r][c] = sum_k N[k][r] Rm[c][k]
+        const v3 Ncol[3] = {{N.r0.x, N.r1.x, N.r2.x}, {N.r0.y, N.r1.y, N.r2.y}, {N.r0.z, N.r1.z, N.r2.z}};
+        for (int r = 0; r < 3; ++r) {
+            const v3 nr = {vdot(Ncol[r], Rm.r0), vdot(Ncol[r], Rm.r1), vdot(Ncol[r], Rm.r2)};
+            const double c0 = nr.x * T.r0.x + nr.y * T.r1.x + nr.z * T.r2.x;
+            const double c1 = nr.x * T.r0.y + nr.y * T.r1.y + nr.z * T.r2.y;
+            const double c2 = nr.x * T.r0.z + nr.y * T.r1.z + nr.z * T.r2.z;
+            out[s][3 + r] = c0;      // column 0 of R_W_C
+            out[s][6 + r] = c1;      // column 1
+            out[s][9 + r] = c2;      // column 2
+        }
+    }
+    return true;
+}
+
+// K \ [u; v; 1] for an upper-triangular camera matrix, then unit length
+// (ransacLocalization.m:52-56).
+__device__ __forceinline__ v3 unit_bearing(const vohip_K &K, double u, double v)
+{
+    v3 n;
+    n.z = 1.0 / K.k[8];
+    n.y = (v - K.k[7] * n.z) / K.k[4];
+    n.x = (u - K.k[3] * n.y - K.k[6] * n.z) / K.k[0];
+    return vdivs(n, sqrt(n.x * n.x + n.y * n.y + n.z * n.z));
+}
+
+// Decode of ransacLocalization.m:61-68 and the fused projection matrix of one candidate.
+// pose = [C | R_W_C col-major];  Rt = [R_C_W col-major | t_C_W];  M = K [R_C_W | t_C_W] row-major.
+__device__ __forceinline__ void decode_pose(const vohip_K &K, const double pose[12], double Rt[12],
+                                            double M[12])
+{
+    // R_C_W = R_W_C'
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Rt[3 * c + r] = pose[3 + 3 * r + c];
+    for (int r = 0; r < 3; ++r)
+        Rt[9 + r] = (-Rt[r]) * pose[0] + (-Rt[3 + r]) * pose[1] + (-Rt[6 + r]) * pose[2];
+    for (int i = 0; i < 3; ++i)
+        for (int c = 0; c < 4; ++c)
+            M[4 * i + c] = K.k[i] * Rt[3 * c] + K.k[3 + i] * Rt[3 * c + 1] + K.k[6 + i] * Rt[3 * c + 2];
+}
+
+__global__ __launch_bounds__(64) void p3p_solve_kernel(const double *__restrict__ kp_rc,
+                                                       const double *__restrict__ X, int n, vohip_K K,
+                                                       const int32_t *__restrict__ samples, int h,
+                                                       double *__restrict__ Rt_out,
+                                                       double *__restrict__ M_out)
+{
+    const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (hyp >= h) return;
+    v3 W[3], bearing[3];
+    bool ok = true;
+    for (int c = 0; c < 3; ++c) {
+        int id = samples[3 * hyp + c];
+        if (id < 0 || id >= n) {
+            ok = false;
+            id = 0;
+        }
+        W[c] = {X[3 * id], X[3 * id + 1], X[3 * id + 2]};
+        bearing[c] = unit_bearing(K, kp_rc[2 * id + 1], kp_rc[2 * id]);
+    }
+    double poses[4][12];
+    p3p_solve(W[0], W[1], W[2], bearing[0], bearing[1], bearing[2], poses);
+    const double nan = __builtin_nan("");
+    for (int s = 0; s < 4; ++s) {
+        double Rt[12], M[12];
+        decode_pose(K, poses[s], Rt, M);
+        for (int j = 0; j < 12; ++j) {
+            Rt_out[(size_t)hyp * 48 + 12 * s + j] = ok ? Rt[j] : nan;
+            M_out[(size_t)hyp * 48 + 12 * s + j] = ok ? M[j] : nan;
+        }
+    }
+}
+
+// Stand-alone p3p.m for `count` problems, reference output layout (3x16 column-major).
+__global__ __launch_bounds__(64) void p3p_batch_kernel(const double *__restrict__ world,
+                                                       const double *__restrict__ bearings, int count,
+                                                       double *__restrict__ poses_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double *w = world + 9 * (size_t)i, *b = bearings + 9 * (size_t)i;
+    double poses[4][12];
+    p3p_solve({w[0], w[1], w[2]}, {w[3], w[4], w[5]}, {w[6], w[7], w[8]}, {b[0], b[1], b[2]},
+              {b[3], b[4], b[5]}, {b[6], b[7], b[8]}, poses);
+    for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 12; ++j) poses_out[(size_t)i * 48 + 12 * s + j] = poses[s][j];
+}
+
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------
+// Inlier test, shared by the scoring and the mask kernels so that popcount(mask) == count.
+// m = K [R | t] row-major 3x4.  13 FMA + 2 MUL + 1 CMP.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_inlier(const double m[12], double X, double Y, double Z, double u,
+                                          double v)
+{
+    const double x = __builtin_fma(m[0], X, __builtin_fma(m[1], Y, __builtin_fma(m[2], Z, m[3])));
+    const double y = __builtin_fma(m[4], X, __builtin_fma(m[5], Y, __builtin_fma(m[6], Z, m[7])));
+    const double z = __builtin_fma(m[8], X, __builtin_fma(m[9], Y, __builtin_fma(m[10], Z, m[11])));
+    const double dx = __builtin_fma(-u, z, x);
+    const double dy = __builtin_fma(-v, z, y);
+    const double e = __builtin_fma(dy, dy, dx * dx);
+    const double zz = z * z;
+    return __builtin_fma(-100.0, zz, e) < 0.0;  // pixel_tolerance^2 = 100, strict
+}
+
+constexpr int SCORE_WAVES = 8;     // hypotheses per workgroup
+constexpr int SCORE_TILE = 1024;   // points per LDS tile (5 doubles each = 40 KiB)
+
+__global__ __launch_bounds__(SCORE_WAVES * 64) void p3p_score_kernel(
+    const double *__restrict__ kp_rc, const double *__restrict__ X, int n,
+    const double *__restrict__ M, int h, int32_t *__restrict__ counts)
+{
+    __shared__ double lds[5 * SCORE_TILE];
+    double *sX = lds, *sY = lds + SCORE_TILE, *sZ = lds + 2 * SCORE_TILE;
+    double *sV = lds + 3 * SCORE_TILE, *sU = lds + 4 * SCORE_TILE;  // kp_rc rows: (row=v, col=u)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hyp = blockIdx.x * SCORE_WAVES + wave;
+    const bool active = hyp < h;
+
+    double m[4][12];
+    {
+        const double *mp = M + (size_t)(active ? hyp : 0) * 48;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 12; ++j) m[s][j] = mp[12 * s + j];
+    }
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+
+    for (int base = 0; base < n; base += SCORE_TILE) {
+        const int tn = min(SCORE_TILE, n - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * tn; i += SCORE_WAVES * 64) {
+            const double val = X[(size_t)3 * base + i];
+            const int p = i / 3, c = i - 3 * p;
+            lds[c * SCORE_TILE + p] = val;
+        }
+        for (int i = threadIdx.x; i < 2 * tn; i += SCORE_WAVES * 64) {
+            const double val = kp_rc[(size_t)2 * base + i];
+            lds[(3 + (i & 1)) * SCORE_TILE + (i >> 1)] = val;
+        }
+        __syncthreads();
+        if (active) {
+            for (int p = lane; p < tn; p += 64) {
+                const double px = sX[p], py = sY[p], pz = sZ[p], pu = sU[p], pv = sV[p];
+                c0 += __popcll(__ballot(is_inlier(m[0], px, py, pz, pu, pv)));
+                c1 += __popcll(__ballot(is_inlier(m[1], px, py, pz, pu, pv)));
+                c2 += __popcll(__ballot(is_inlier(m[2], px, py, pz, pu, pv)));
+                c3 += __popcll(__ballot(is_inlier(m[3], px, py, pz, pu, pv)));
+            }
+        }
+    }
+    if (active && lane == 0) {
+        int4 out = {c0, c1, c2, c3};
+        *reinterpret_cast<int4 *>(counts + 4 * (size_t)hyp) = out;
+    }
+}
+
+struct pose_m {
+    double m[12];
+};
+
+__global__ __launch_bounds__(256) void inlier_mask_kernel(const double *__restrict__ kp_rc,
+                                                          const double *__restrict__ X, int n, pose_m P,
+                                                          uint8_t *__restrict__ mask)
+{
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const bool in = is_inlier(P.m, X[3 * j], X[3 * j + 1], X[3 * j + 2], kp_rc[2 * j + 1], kp_rc[2 * j]);
+        mask[j] = in ? 1 : 0;
+    }
+}
+
+// K [R | t] on the host with the same statements as decode_pose (no contraction on the host
+// build either: the expression is a plain sum of products evaluated left to right).
+void host_fused_projection(const double K[9], const double Rt[12], double M[12])
+{
+    for (int i = 0; i < 3; ++i)
+        for (int c = 0; c < 4; ++c) {
+            volatile double a = K[i] * Rt[3 * c];
+            volatile double b = K[3 + i] * Rt[3 * c + 1];
+            volatile double d = K[6 + i] * Rt[3 * c + 2];
+            volatile double ab = a + b;
+            M[4 * i + c] = ab + d;
+        }
+}
+
+// ransacLocalization.m:118-129
+double adaptive_num_iterations(int max_num_inliers, int n)
+{
+    const double confidence = 0.9999, upper = 0.95;
+    double outlier_ratio = 1.0 - (double)max_num_inliers / (double)n;
+    if (upper < outlier_ratio) outlier_ratio = upper;
+    double it = std::log(1.0 - confidence) / std::log(1.0 - std::pow(1.0 - outlier_ratio, 3.0));
+    if (it > 15000.0) it = 15000.0;
+    if (it < 100.0) it = 100.0;
+    return it;
+}
+
+int launch_score(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const double K[9],
+                 const int32_t *d_samples, int h, int32_t *d_counts)
+{
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_RT], (size_t)h * 48 * sizeof(double)));
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_M], (size_t)h * 48 * sizeof(double)));
+    ctx->ransac_h = h;
+    double *d_Rt = (double *)ctx->bufs[B_RANSAC_RT].ptr;
+    double *d_M = (double *)ctx->bufs[B_RANSAC_M].ptr;
+    const vohip_K Kv = vohip_make_K(K);
+    hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n,
+                       Kv, d_samples, h, d_Rt, d_M);
+    hipLaunchKernelGGL(p3p_score_kernel, dim3((h + SCORE_WAVES - 1) / SCORE_WAVES),
+                       dim3(SCORE_WAVES * 64), 0, ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vohip_ransac_p3p_score_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
+                               const double K[9], const int32_t *d_samples, int h, int32_t *d_counts)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, d_kp_rc && d_X && K && d_samples && d_counts, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 3, "need at least 3 points");
+    VOHIP_REQUIRE(ctx, h >= 1, "need at least 1 hypothesis");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_score(ctx, d_kp_rc, d_X, n, K, d_samples, h, d_counts);
+}
+
+int vohip_ransac_p3p_poses(vohip_ctx *ctx, int first, int count, double *Rt)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, Rt, "NULL argument");
+    VOHIP_REQUIRE(ctx, first >= 0 && count >= 0 && first + count <= ctx->ransac_h,
+                  "pose range outside the last scored batch");
+    if (count == 0) return VOHIP_OK;
+    VOHIP_HIP(ctx, hipMemcpyAsync(Rt, (const double *)ctx->bufs[B_RANSAC_RT].ptr + (size_t)first * 48,
+                                  (size_t)count * 48 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VOHIP_OK;
+}
+
+int vohip_ransac_inlier_mask_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
+                                 const double K[9], const double Rt[12], uint8_t *d_mask)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, d_kp_rc && d_X && K && Rt && d_mask, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 1, "need at least 1 point");
+    pose_m P;
+    host_fused_projection(K, Rt, P.m);
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(inlier_mask_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, ctx->stream,
+                       d_kp_rc, d_X, n, P, d_mask);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+int vohip_ransac_p3p(vohip_ctx *ctx, const double *kp_rc, const double *X, int n, const double K[9],
+                     const int32_t *samples, int hcap, double R_C_W[9], double t_C_W[3], uint8_t *mask,
+                     double *max_hist, double *iter_hist, int *n_iter)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, kp_rc && X && K && samples && R_C_W && t_C_W && mask && max_hist && iter_hist && n_iter,
+                  "NULL argument");
+    *n_iter = 0;
+    if (n < 3) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "P3P needs at least 3 correspondences, got %d", n);
+    VOHIP_REQUIRE(ctx, hcap >= 1, "need at least 1 sample triple");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_KP], (size_t)2 * n * sizeof(double)));
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_X], (size_t)3 * n * sizeof(double)));
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_SAMPLES], (size_t)3 * hcap * sizeof(int32_t)));
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_COUNTS], (size_t)4 * hcap * sizeof(int32_t)));
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_MASK], (size_t)n));
+    VOHIP_TRY(vohip_reserve_pinned(ctx, ctx->bufs[H_RANSAC_COUNTS], (size_t)4 * hcap * sizeof(int32_t)));
+    // the pose buffers must hold every chunk at its own offset
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_RT], (size_t)hcap * 48 * sizeof(double)));
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_M], (size_t)hcap * 48 * sizeof(double)));
+
+    double *d_kp = (double *)ctx->bufs[B_RANSAC_KP].ptr;
+    double *d_X = (double *)ctx->bufs[B_RANSAC_X].ptr;
+    int32_t *d_samples = (int32_t *)ctx->bufs[B_RANSAC_SAMPLES].ptr;
+    int32_t *d_counts = (int32_t *)ctx->bufs[B_RANSAC_COUNTS].ptr;
+    uint8_t *d_mask = (uint8_t *)ctx->bufs[B_RANSAC_MASK].ptr;
+    int32_t *h_counts = (int32_t *)ctx->bufs[H_RANSAC_COUNTS].ptr;
+    double *d_Rt = (double *)ctx->bufs[B_RANSAC_RT].ptr;
+    double *d_M = (double *)ctx->bufs[B_RANSAC_M].ptr;
+    hipStream_t st = ctx->stream;
+
+    VOHIP_HIP(ctx, hipMemcpyAsync(d_kp, kp_rc, (size_t)2 * n * sizeof(double), hipMemcpyHostToDevice, st));
+    VOHIP_HIP(ctx, hipMemcpyAsync(d_X, X, (size_t)3 * n * sizeof(double), hipMemcpyHostToDevice, st));
+    VOHIP_HIP(ctx, hipMemcpyAsync(d_samples, samples, (size_t)3 * hcap * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const vohip_K Kv = vohip_make_K(K);
+
+    // Replay state of ransacLocalization.m:37,42-44.
+    int max_num_inliers = 0, best_h = -1, best_s = 0;
+    double num_iterations = INFINITY;
+    int i = 1;          // reference loop counter
+    int evaluated = 0;  // hypotheses scored so far
+    bool exhausted = false;
+    while (num_iterations > (double)i) {
+        if (i > evaluated) {
+            if (evaluated >= hcap) {
+                exhausted = true;
+                break;
+            }
+            // chunk: at least the 99 iterations the clamp at :129 guarantees, then up to the
+            // current bound, in multiples of the workgroup's 8 hypotheses.
+            int want = evaluated == 0 ? 104 : (int)std::ceil(num_iterations) - 1 - evaluated;
+            if (want < 64) want = 64;
+            want = (want + SCORE_WAVES - 1) / SCORE_WAVES * SCORE_WAVES;
+            if (want > hcap - evaluated) want = hcap - evaluated;
+            hipLaunchKernelGGL(p3p_solve_kernel, dim3((want + 63) / 64), dim3(64), 0, st, d_kp, d_X, n, Kv,
+                               d_samples + 3 * (size_t)evaluated, want, d_Rt + (size_t)evaluated * 48,
+                               d_M + (size_t)evaluated * 48);
+            hipLaunchKernelGGL(p3p_score_kernel, dim3((want + SCORE_WAVES - 1) / SCORE_WAVES),
+                               dim3(SCORE_WAVES * 64), 0, st, d_kp, d_X, n, d_M + (size_t)evaluated * 48, want,
+                               d_counts + 4 * (size_t)evaluated);
+            VOHIP_HIP(ctx, hipGetLastError());
+            VOHIP_HIP(ctx, hipMemcpyAsync(h_counts + 4 * (size_t)evaluated, d_counts + 4 * (size_t)evaluated,
+                                          (size_t)4 * want * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            VOHIP_HIP(ctx, hipStreamSynchronize(st));
+            evaluated += want;
+        }
+        // :77-101  pick the solution with the strict '>' rule, lowest index wins ties
+        const int32_t *c = h_counts + 4 * (size_t)(i - 1);
+        int s_best = 0;
+        for (int s = 1; s < 4; ++s)
+            if (c[s] > c[s_best]) s_best = s;
+        const int cnt = c[s_best];
+        if (cnt > max_num_inliers && cnt >= 30) {  // :104,109-110
+            max_num_inliers = cnt;
+            best_h = i - 1;
+            best_s = s_best;
+        }
+        num_iterations = adaptive_num_iterations(max_num_inliers, n);
+        iter_hist[i - 1] = num_iterations;
+        max_hist[i - 1] = (double)max_num_inliers;
+        ++i;
+    }
+    ctx->ransac_h = evaluated;
+    *n_iter = i - 1;
+
+    if (best_h < 0) {
+        std::memset(mask, 0, (size_t)n);
+        if (exhausted)
+            return vohip_fail(ctx, VOHIP_SAMPLES_EXHAUSTED, "sample triples ran out after %d iterations, no model", i - 1);
+        return vohip_fail(ctx, VOHIP_NO_MODEL, "no hypothesis reached 30 inliers in %d iterations", i - 1);
+    }
+    double Rt[12];
+    VOHIP_HIP(ctx, hipMemcpyAsync(Rt, d_Rt + (size_t)best_h * 48 + 12 * best_s, 12 * sizeof(double),
+                                  hipMemcpyDeviceToHost, st));
+    VOHIP_HIP(ctx, hipStreamSynchronize(st));
+    std::memcpy(R_C_W, Rt, 9 * sizeof(double));
+    std::memcpy(t_C_W, Rt + 9, 3 * sizeof(double));
+    // mask of the winner with the scoring kernel's own projection matrix
+    pose_m P;
+    VOHIP_HIP(ctx, hipMemcpyAsync(P.m, d_M + (size_t)best_h * 48 + 12 * best_s, 12 * sizeof(double),
+                                  hipMemcpyDeviceToHost, st));
+    VOHIP_HIP(ctx, hipStreamSynchronize(st));
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(inlier_mask_kernel, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, st, d_kp, d_X, n,
+                       P, d_mask);
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_HIP(ctx, hipMemcpyAsync(mask, d_mask, (size_t)n, hipMemcpyDeviceToHost, st));
+    VOHIP_HIP(ctx, hipStreamSynchronize(st));
+    if (exhausted)
+        return vohip_fail(ctx, VOHIP_SAMPLES_EXHAUSTED, "sample triples ran out after %d iterations", i - 1);
+    return VOHIP_OK;
+}
+
+int vohip_p3p(vohip_ctx *ctx, const double *world, const double *bearings, int count, double *poses)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, world && bearings && poses, "NULL argument");
+    VOHIP_REQUIRE(ctx, count >= 0, "negative count");
+    if (count == 0) return VOHIP_OK;
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_b = (size_t)count * 9 * sizeof(double), out_b = (size_t)count * 48 * sizeof(double);
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_STAGE0], in_b));
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_STAGE1], in_b));
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_STAGE2], out_b));
+    hipStream_t st = ctx->stream;
+    VOHIP_HIP(ctx, hipMemcpyAsync(ctx->bufs[B_STAGE0].ptr, world, in_b, hipMemcpyHostToDevice, st));
+    VOHIP_HIP(ctx, hipMemcpyAsync(ctx->bufs[B_STAGE1].ptr, bearings, in_b, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(p3p_batch_kernel, dim3((count + 63) / 64), dim3(64), 0, st,
+                       (const double *)ctx->bufs[B_STAGE0].ptr, (const double *)ctx->bufs[B_STAGE1].ptr, count,
+                       (double *)ctx->bufs[B_STAGE2].ptr);
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_HIP(ctx, hipMemcpyAsync(poses, ctx->bufs[B_STAGE2].ptr, out_b, hipMemcpyDeviceToHost, st));
+    VOHIP_HIP(ctx, hipStreamSynchronize(st));
+    return VOHIP_OK;
+}
+
+}  // extern "C"

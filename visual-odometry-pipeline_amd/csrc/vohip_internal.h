@@ -1,0 +1,78 @@
+// Internal definitions shared by the translation units of libvohip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "vohip.h"
+
+// A grow-only device (or pinned host) buffer owned by the context.
+struct vohip_buf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    bool pinned_host = false;
+};
+
+// Identifiers of the context-owned buffers (device unless the name starts with H_).
+enum vohip_buf_id {
+    B_RANSAC_RT = 0,   // h x 4 x 12 doubles: [R_C_W | t_C_W] of every candidate pose
+    B_RANSAC_M,        // h x 4 x 12 doubles: K [R | t], row-major 3x4
+    B_RANSAC_KP,
+    B_RANSAC_X,
+    B_RANSAC_SAMPLES,
+    B_RANSAC_COUNTS,
+    B_RANSAC_MASK,
+    H_RANSAC_COUNTS,
+    B_STAGE0, B_STAGE1, B_STAGE2, B_STAGE3, B_STAGE4, B_STAGE5, B_STAGE6, B_STAGE7,
+    H_STAGE0, H_STAGE1, H_STAGE2, H_STAGE3,
+    VOHIP_NBUF = 96
+};
+
+struct vohip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    char err[512] = {0};
+    vohip_buf bufs[VOHIP_NBUF];
+    int ransac_h = 0;  // hypotheses held by B_RANSAC_RT / B_RANSAC_M
+};
+
+int vohip_fail(vohip_ctx *ctx, int status, const char *fmt, ...);
+int vohip_reserve(vohip_ctx *ctx, vohip_buf &b, size_t bytes);
+int vohip_reserve_pinned(vohip_ctx *ctx, vohip_buf &b, size_t bytes);
+void vohip_release(vohip_buf &b);
+
+#define VOHIP_HIP(ctx, call)                                                                 \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return vohip_fail((ctx), VOHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call,          \
+                              hipGetErrorString(e__), __FILE__, __LINE__);                   \
+    } while (0)
+
+#define VOHIP_TRY(expr)                     \
+    do {                                    \
+        int s__ = (expr);                   \
+        if (s__ != VOHIP_OK) return s__;    \
+    } while (0)
+
+#define VOHIP_REQUIRE(ctx, cond, msg)                                                \
+    do {                                                                             \
+        if (!(cond)) return vohip_fail((ctx), VOHIP_ERR_INVALID_ARGUMENT, "%s", msg); \
+    } while (0)
+
+// Camera matrix passed to kernels by value (column-major, as MATLAB stores it).
+struct vohip_K {
+    double k[9];
+};
+static inline vohip_K vohip_make_K(const double K[9])
+{
+    vohip_K r;
+    for (int i = 0; i < 9; ++i) r.k[i] = K[i];
+    return r;
+}

@@ -1,0 +1,97 @@
+"""Host-side mirror of the reference's RANSAC localisation interface.
+
+Function names, argument meaning and return values follow
+utils/exe7_Ransac/ransacLocalization.m:1-2 and utils/exe7_Ransac/p3p.m:41 of the reference;
+the arithmetic runs in libvohip.so on the GPU (no CPU fallback).
+Arrays use MATLAB's math layout: keypoints 2xN, landmarks 3xN, K 3x3.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VOHIP_NO_MODEL, VOHIP_OK, VOHIP_SAMPLES_EXHAUSTED, as_f64, colmajor, dptr
+
+MAX_ITERATIONS = 15000  # cap of ransacLocalization.m:128
+
+
+def draw_triples(rng, n, count):
+    """`count` index triples, each 3 distinct indices in [0, n) -- the stand-in for
+    datasample(landmarks, 3, 2, 'Replace', false) at ransacLocalization.m:46-47.
+    One call consumes exactly 3*count draws of `rng` in triple order, so drawing m triples and
+    then k more equals drawing m+k at once."""
+    r = rng.random((count, 3))
+    a = np.minimum((r[:, 0] * n).astype(np.int64), n - 1)
+    b = np.minimum((r[:, 1] * (n - 1)).astype(np.int64), n - 2)
+    c = np.minimum((r[:, 2] * (n - 2)).astype(np.int64), n - 3)
+    b = b + (b >= a)
+    lo = np.minimum(a, b)
+    hi = np.maximum(a, b)
+    c = c + (c >= lo)
+    c = c + (c >= hi)
+    return np.stack([a, b, c], axis=1).astype(np.int32)
+
+
+def ransacLocalization(matched_query_keypoints, corresponding_landmarks, K, samples=None, rng=None,
+                       ctx=None):
+    """[R_C_W, t_C_W, best_inlier_mask, max_num_inliers_history, num_iteration_history] =
+    ransacLocalization(matched_query_keypoints, corresponding_landmarks, K)
+
+    matched_query_keypoints 2xN in (row, col) order, corresponding_landmarks 3xN, K 3x3.
+    `samples` (H x 3, 0-based) fixes the hypothesis set; otherwise triples are drawn from `rng`
+    (numpy Generator), whose state afterwards is as if exactly n_iter triples had been drawn --
+    the reference consumes one datasample call per executed iteration.
+    Returns R_C_W = t_C_W = empty arrays when no model reaches 30 inliers
+    (ransacLocalization.m:138-140) and best_inlier_mask as a 1xN row of 0/1.
+    """
+    ctx = ctx or _lib.default_context()
+    lib = _lib.load()
+    kp = colmajor(matched_query_keypoints)      # (N, 2) rows = (row, col)
+    X = colmajor(corresponding_landmarks)       # (N, 3)
+    Kc = colmajor(K)
+    n = kp.shape[0]
+    if X.shape[0] != n:
+        raise ValueError("keypoints and landmarks differ in count")
+    rng_state = None
+    if samples is None:
+        if rng is None:
+            rng = np.random.default_rng()
+        rng_state = rng.bit_generator.state
+        samples = draw_triples(rng, n, MAX_ITERATIONS - 1) if n >= 3 else np.zeros((1, 3), np.int32)
+    samples = np.ascontiguousarray(samples, dtype=np.int32)
+    h = samples.shape[0]
+    R = np.zeros(9)
+    t = np.zeros(3)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    max_hist = np.zeros(h)
+    iter_hist = np.zeros(h)
+    n_iter = C.c_int(0)
+    st = lib.vohip_ransac_p3p(ctx.handle, dptr(kp), dptr(X), n, dptr(Kc),
+                              samples.ctypes.data_as(_lib.c_int32_p), h, dptr(R), dptr(t),
+                              mask.ctypes.data_as(_lib.c_uint8_p), dptr(max_hist), dptr(iter_hist),
+                              C.byref(n_iter))
+    ctx.check(st, allow=(VOHIP_NO_MODEL, VOHIP_SAMPLES_EXHAUSTED))
+    if st == VOHIP_SAMPLES_EXHAUSTED and rng_state is None:
+        raise _lib.VohipError(st, lib.vohip_last_error(ctx.handle).decode())
+    k = n_iter.value
+    if rng_state is not None:
+        rng.bit_generator.state = rng_state
+        if k > 0:
+            draw_triples(rng, n, k)
+    if st == VOHIP_NO_MODEL:
+        return (np.zeros((0, 0)), np.zeros((0, 0)), np.zeros((1, n)), max_hist[:k].copy(),
+                iter_hist[:k].copy())
+    return (R.reshape(3, 3).T.copy(), t.reshape(3, 1).copy(), mask[:n].reshape(1, n).astype(np.float64),
+            max_hist[:k].copy(), iter_hist[:k].copy())
+
+
+def p3p(worldPoints, imageVectors, ctx=None):
+    """poses = p3p(worldPoints, imageVectors): 3x3 world points and 3x3 unit bearing vectors
+    (columns) -> 3x16 [C1 R1 C2 R2 C3 R3 C4 R4] with R_i rotating camera to world (p3p.m:35-39).
+    Real part only, as every caller of the reference takes it."""
+    ctx = ctx or _lib.default_context()
+    w = colmajor(worldPoints).reshape(1, 9)
+    b = colmajor(imageVectors).reshape(1, 9)
+    out = np.zeros(48)
+    ctx.check(_lib.load().vohip_p3p(ctx.handle, dptr(as_f64(w)), dptr(as_f64(b)), 1, dptr(out)))
+    return out.reshape(16, 3).T.copy()
