@@ -56,6 +56,10 @@ const char *vohip_last_error(const vohip_ctx *ctx);
 /* The hipStream_t all kernels of this context are enqueued on. */
 void *vohip_stream(vohip_ctx *ctx);
 int vohip_synchronize(vohip_ctx *ctx);
+/* Tuning knobs (no reference counterpart).  "ransac_score_variant" 0..5 (-1 = automatic, the default) selects the workgroup
+ * geometry (hypotheses per workgroup x points per LDS tile) of the RANSAC scoring kernel; results
+ * do not depend on it. */
+int vohip_set_option(vohip_ctx *ctx, const char *name, int value);
 /* Library version, "major.minor". */
 const char *vohip_version(void);
 
@@ -88,9 +92,19 @@ int vohip_ransac_p3p(vohip_ctx *ctx, const double *kp_rc, const double *X, int n
 /* Hypothesis generation + inlier scoring only (ransacLocalization.m:46-101 for h hypotheses at
  * once), everything resident on the GPU: d_kp_rc (2xN), d_X (3xN), d_samples (3xh int32) and
  * d_counts (4xh int32, out: inlier count of each of the 4 P3P solutions) are device pointers.
- * Asynchronous on the context's stream. */
+ * Asynchronous on the context's stream.  Equivalent to _solve_dev followed by _count_dev. */
 int vohip_ransac_p3p_score_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
                                const double K[9], const int32_t *d_samples, int h,
+                               int32_t *d_counts);
+
+/* First half of _score_dev: sample -> bearings -> p3p -> 4 candidate poses per hypothesis
+ * (ransacLocalization.m:46-68, p3p.m, solveQuartic.m), kept in the context. */
+int vohip_ransac_p3p_solve_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
+                               const double K[9], const int32_t *d_samples, int h);
+
+/* Second half of _score_dev: inlier counts of the poses of the last _solve_dev call against
+ * all n points (ransacLocalization.m:77-101), one hypothesis per wavefront. */
+int vohip_ransac_p3p_count_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, int h,
                                int32_t *d_counts);
 
 /* Poses behind the counts of the last vohip_ransac_p3p_score_dev call: copies, for hypotheses

@@ -36,11 +36,16 @@ SIGNATURES = {
     "vohip_stream": (C.c_void_p, [C.c_void_p]),
     "vohip_synchronize": (C.c_int, [C.c_void_p]),
     "vohip_version": (C.c_char_p, []),
+    "vohip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "vohip_ransac_p3p": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, c_double_p, c_int32_p,
                                     C.c_int, c_double_p, c_double_p, c_uint8_p, c_double_p, c_double_p,
                                     c_int_p]),
     "vohip_ransac_p3p_score_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
                                               C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_ransac_p3p_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
+                                              C.c_void_p, C.c_int]),
+    "vohip_ransac_p3p_count_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_void_p]),
     "vohip_ransac_p3p_poses": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p]),
     "vohip_ransac_inlier_mask_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
                                                 c_double_p, C.c_void_p]),
@@ -107,6 +112,9 @@ class Context:
         if status != VOHIP_OK and status not in allow:
             raise VohipError(status, load().vohip_last_error(self._h).decode())
         return status
+
+    def set_option(self, name, value):
+        self.check(load().vohip_set_option(self.handle, name.encode(), int(value)))
 
     def synchronize(self):
         self.check(load().vohip_synchronize(self.handle))

@@ -114,6 +114,18 @@ const char *vohip_last_error(const vohip_ctx *ctx) { return ctx ? ctx->err : g_c
 
 void *vohip_stream(vohip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+int vohip_set_option(vohip_ctx *ctx, const char *name, int value)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, name, "NULL option name");
+    if (std::strcmp(name, "ransac_score_variant") == 0) {
+        VOHIP_REQUIRE(ctx, value >= -1 && value <= 5, "ransac_score_variant must be -1 (auto) or 0..5");
+        ctx->opt_ransac_variant = value;
+        return VOHIP_OK;
+    }
+    return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "unknown option '%s'", name);
+}
+
 int vohip_synchronize(vohip_ctx *ctx)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;

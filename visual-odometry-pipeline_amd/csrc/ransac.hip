@@ -366,56 +366,117 @@ __device__ __forceinline__ bool is_inlier(const double m[12], double X, double Y
     return __builtin_fma(-100.0, zz, e) < 0.0;  // pixel_tolerance^2 = 100, strict
 }
 
-constexpr int SCORE_WAVES = 8;     // hypotheses per workgroup
-constexpr int SCORE_TILE = 1024;   // points per LDS tile (5 doubles each = 40 KiB)
+// Inlier test with the 9 rotation-part coefficients as wave-uniform scalars (SGPR operands of
+// v_fma_f64: one scalar operand per VALU instruction is free) and the 3 translation-part
+// coefficients as vector registers.  Same arithmetic, operation for operation, as is_inlier.
+struct pose_s {
+    double r[9];  // m[0..2], m[4..6], m[8..10]
+};
+__device__ __forceinline__ bool is_inlier_sv(const pose_s &ms, double t0, double t1, double t2, double X,
+                                             double Y, double Z, double u, double v)
+{
+    const double x = __builtin_fma(ms.r[0], X, __builtin_fma(ms.r[1], Y, __builtin_fma(ms.r[2], Z, t0)));
+    const double y = __builtin_fma(ms.r[3], X, __builtin_fma(ms.r[4], Y, __builtin_fma(ms.r[5], Z, t1)));
+    const double z = __builtin_fma(ms.r[6], X, __builtin_fma(ms.r[7], Y, __builtin_fma(ms.r[8], Z, t2)));
+    const double dx = __builtin_fma(-u, z, x);
+    const double dy = __builtin_fma(-v, z, y);
+    const double e = __builtin_fma(dy, dy, dx * dx);
+    const double zz = z * z;
+    return __builtin_fma(-100.0, zz, e) < 0.0;
+}
 
-__global__ __launch_bounds__(SCORE_WAVES * 64) void p3p_score_kernel(
+constexpr int SCORE_WAVES = 8;  // default hypotheses per workgroup (chunk granularity of the host loop)
+
+// One wavefront per hypothesis, WAVES hypotheses per workgroup.  The point arrays are staged
+// through LDS in tiles of TILE points, structure-of-arrays, double-buffered: the global loads of
+// tile t+1 are issued before the arithmetic on tile t and written to the other LDS buffer after it.
+template <int WAVES, int TILE>
+__global__ __launch_bounds__(WAVES * 64) void p3p_score_kernel(
     const double *__restrict__ kp_rc, const double *__restrict__ X, int n,
     const double *__restrict__ M, int h, int32_t *__restrict__ counts)
 {
-    __shared__ double lds[5 * SCORE_TILE];
-    double *sX = lds, *sY = lds + SCORE_TILE, *sZ = lds + 2 * SCORE_TILE;
-    double *sV = lds + 3 * SCORE_TILE, *sU = lds + 4 * SCORE_TILE;  // kp_rc rows: (row=v, col=u)
+    constexpr int NT = WAVES * 64;
+    constexpr int PER_X = (3 * TILE + NT - 1) / NT;
+    constexpr int PER_K = (2 * TILE + NT - 1) / NT;
+    __shared__ double lds[2][5 * TILE];
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hyp = blockIdx.x * SCORE_WAVES + wave;
-    const bool active = hyp < h;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hyp_raw = blockIdx.x * WAVES + wave;
+    const int hyp = hyp_raw < h ? hyp_raw : h - 1;  // surplus waves redo the last hypothesis, no store
 
-    double m[4][12];
+    pose_s ms[4];
+    double tv[4][3];
     {
-        const double *mp = M + (size_t)(active ? hyp : 0) * 48;
+        const double *mp = M + (size_t)hyp * 48;  // wave-uniform address: scalar loads
+        // translation column through a per-lane address so that it lives in vector registers
+        const int hv = min(blockIdx.x * WAVES + (tid >> 6), h - 1);
+        const double *mv = M + (size_t)hv * 48;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int j = 0; j < 12; ++j) m[s][j] = mp[12 * s + j];
-    }
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-
-    for (int base = 0; base < n; base += SCORE_TILE) {
-        const int tn = min(SCORE_TILE, n - base);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 3 * tn; i += SCORE_WAVES * 64) {
-            const double val = X[(size_t)3 * base + i];
-            const int p = i / 3, c = i - 3 * p;
-            lds[c * SCORE_TILE + p] = val;
-        }
-        for (int i = threadIdx.x; i < 2 * tn; i += SCORE_WAVES * 64) {
-            const double val = kp_rc[(size_t)2 * base + i];
-            lds[(3 + (i & 1)) * SCORE_TILE + (i >> 1)] = val;
-        }
-        __syncthreads();
-        if (active) {
-            for (int p = lane; p < tn; p += 64) {
-                const double px = sX[p], py = sY[p], pz = sZ[p], pu = sU[p], pv = sV[p];
-                c0 += __popcll(__ballot(is_inlier(m[0], px, py, pz, pu, pv)));
-                c1 += __popcll(__ballot(is_inlier(m[1], px, py, pz, pu, pv)));
-                c2 += __popcll(__ballot(is_inlier(m[2], px, py, pz, pu, pv)));
-                c3 += __popcll(__ballot(is_inlier(m[3], px, py, pz, pu, pv)));
+            for (int i = 0; i < 3; ++i) {
+                ms[s].r[3 * i] = mp[12 * s + 4 * i];
+                ms[s].r[3 * i + 1] = mp[12 * s + 4 * i + 1];
+                ms[s].r[3 * i + 2] = mp[12 * s + 4 * i + 2];
+                tv[s][i] = mv[12 * s + 4 * i + 3];
             }
         }
     }
-    if (active && lane == 0) {
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+
+    double rx[PER_X], rk[PER_K];
+    auto load_tile = [&](int base) {
+        const int tn = min(TILE, n - base);
+#pragma unroll
+        for (int i = 0; i < PER_X; ++i) {
+            const int idx = tid + i * NT;
+            rx[i] = idx < 3 * tn ? X[(size_t)3 * base + idx] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < PER_K; ++i) {
+            const int idx = tid + i * NT;
+            rk[i] = idx < 2 * tn ? kp_rc[(size_t)2 * base + idx] : 0.0;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        double *L = lds[buf];
+#pragma unroll
+        for (int i = 0; i < PER_X; ++i) {
+            const int idx = tid + i * NT;
+            const int p = idx / 3, c = idx - 3 * p;
+            if (idx < 3 * TILE) L[c * TILE + p] = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PER_K; ++i) {
+            const int idx = tid + i * NT;
+            // kp_rc pairs are (row = v, col = u): array 3 = v, array 4 = u
+            if (idx < 2 * TILE) L[(3 + (idx & 1)) * TILE + (idx >> 1)] = rk[i];
+        }
+    };
+
+    const int ntiles = (n + TILE - 1) / TILE;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int base = t * TILE;
+        const int tn = min(TILE, n - base);
+        if (t + 1 < ntiles) load_tile(base + TILE);
+        const double *L = lds[t & 1];
+        for (int p = lane; p < tn; p += 64) {
+            const double px = L[p], py = L[TILE + p], pz = L[2 * TILE + p];
+            const double pv = L[3 * TILE + p], pu = L[4 * TILE + p];
+            c0 += __popcll(__ballot(is_inlier_sv(ms[0], tv[0][0], tv[0][1], tv[0][2], px, py, pz, pu, pv)));
+            c1 += __popcll(__ballot(is_inlier_sv(ms[1], tv[1][0], tv[1][1], tv[1][2], px, py, pz, pu, pv)));
+            c2 += __popcll(__ballot(is_inlier_sv(ms[2], tv[2][0], tv[2][1], tv[2][2], px, py, pz, pu, pv)));
+            c3 += __popcll(__ballot(is_inlier_sv(ms[3], tv[3][0], tv[3][1], tv[3][2], px, py, pz, pu, pv)));
+        }
+        if (t + 1 < ntiles) store_tile((t + 1) & 1);
+        __syncthreads();
+    }
+    if (hyp_raw < h && lane == 0) {
         int4 out = {c0, c1, c2, c3};
         *reinterpret_cast<int4 *>(counts + 4 * (size_t)hyp) = out;
     }
@@ -461,36 +522,85 @@ double adaptive_num_iterations(int max_num_inliers, int n)
     return it;
 }
 
-int launch_score(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const double K[9],
-                 const int32_t *d_samples, int h, int32_t *d_counts)
+int launch_solve(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const double K[9],
+                 const int32_t *d_samples, int h)
 {
     VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_RT], (size_t)h * 48 * sizeof(double)));
     VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_M], (size_t)h * 48 * sizeof(double)));
     ctx->ransac_h = h;
-    double *d_Rt = (double *)ctx->bufs[B_RANSAC_RT].ptr;
-    double *d_M = (double *)ctx->bufs[B_RANSAC_M].ptr;
     const vohip_K Kv = vohip_make_K(K);
     hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n,
-                       Kv, d_samples, h, d_Rt, d_M);
-    hipLaunchKernelGGL(p3p_score_kernel, dim3((h + SCORE_WAVES - 1) / SCORE_WAVES),
-                       dim3(SCORE_WAVES * 64), 0, ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts);
+                       Kv, d_samples, h, (double *)ctx->bufs[B_RANSAC_RT].ptr,
+                       (double *)ctx->bufs[B_RANSAC_M].ptr);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
+}
+
+template <int WAVES, int TILE>
+void launch_score_t(hipStream_t st, const double *d_kp_rc, const double *d_X, int n, const double *d_M, int h,
+                    int32_t *d_counts)
+{
+    hipLaunchKernelGGL((p3p_score_kernel<WAVES, TILE>), dim3((h + WAVES - 1) / WAVES), dim3(WAVES * 64), 0, st,
+                       d_kp_rc, d_X, n, d_M, h, d_counts);
+}
+
+int launch_score_variant(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const double *d_M,
+                         int h, int32_t *d_counts)
+{
+    // Geometry: many hypotheses -> 16 per workgroup share each staged tile (fewest L2->LDS bytes);
+    // few hypotheses -> small workgroups so that more CUs take part.  Measured on MI355X:
+    // 4096 x 8192: variant 2 = 77 us, variant 0 = 83 us; 104 x 2000: variant 3 = 10.7 us, 2 = 21 us.
+    int variant = ctx->opt_ransac_variant;
+    if (variant < 0) variant = h >= 2048 ? 2 : (h < 512 ? 3 : 0);
+    switch (variant) {
+    case 1: launch_score_t<8, 512>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
+    case 2: launch_score_t<16, 1024>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
+    case 3: launch_score_t<4, 512>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
+    case 4: launch_score_t<16, 512>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
+    case 5: launch_score_t<4, 256>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
+    default: launch_score_t<8, 1024>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
+    }
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+int launch_count(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, int h, int32_t *d_counts)
+{
+    return launch_score_variant(ctx, d_kp_rc, d_X, n, (const double *)ctx->bufs[B_RANSAC_M].ptr, h, d_counts);
 }
 
 }  // namespace
 
 extern "C" {
 
+int vohip_ransac_p3p_solve_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
+                               const double K[9], const int32_t *d_samples, int h)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, d_kp_rc && d_X && K && d_samples, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 3, "need at least 3 points");
+    VOHIP_REQUIRE(ctx, h >= 1, "need at least 1 hypothesis");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    return launch_solve(ctx, d_kp_rc, d_X, n, K, d_samples, h);
+}
+
+int vohip_ransac_p3p_count_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, int h,
+                               int32_t *d_counts)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, d_kp_rc && d_X && d_counts, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 1, "need at least 1 point");
+    VOHIP_REQUIRE(ctx, h >= 1 && h <= ctx->ransac_h, "h exceeds the hypotheses solved by the last solve call");
+    return launch_count(ctx, d_kp_rc, d_X, n, h, d_counts);
+}
+
 int vohip_ransac_p3p_score_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
                                const double K[9], const int32_t *d_samples, int h, int32_t *d_counts)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
-    VOHIP_REQUIRE(ctx, d_kp_rc && d_X && K && d_samples && d_counts, "NULL argument");
-    VOHIP_REQUIRE(ctx, n >= 3, "need at least 3 points");
-    VOHIP_REQUIRE(ctx, h >= 1, "need at least 1 hypothesis");
-    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
-    return launch_score(ctx, d_kp_rc, d_X, n, K, d_samples, h, d_counts);
+    VOHIP_REQUIRE(ctx, d_counts, "NULL argument");
+    VOHIP_TRY(vohip_ransac_p3p_solve_dev(ctx, d_kp_rc, d_X, n, K, d_samples, h));
+    return launch_count(ctx, d_kp_rc, d_X, n, h, d_counts);
 }
 
 int vohip_ransac_p3p_poses(vohip_ctx *ctx, int first, int count, double *Rt)
@@ -579,10 +689,8 @@ int vohip_ransac_p3p(vohip_ctx *ctx, const double *kp_rc, const double *X, int n
             hipLaunchKernelGGL(p3p_solve_kernel, dim3((want + 63) / 64), dim3(64), 0, st, d_kp, d_X, n, Kv,
                                d_samples + 3 * (size_t)evaluated, want, d_Rt + (size_t)evaluated * 48,
                                d_M + (size_t)evaluated * 48);
-            hipLaunchKernelGGL(p3p_score_kernel, dim3((want + SCORE_WAVES - 1) / SCORE_WAVES),
-                               dim3(SCORE_WAVES * 64), 0, st, d_kp, d_X, n, d_M + (size_t)evaluated * 48, want,
-                               d_counts + 4 * (size_t)evaluated);
-            VOHIP_HIP(ctx, hipGetLastError());
+            VOHIP_TRY(launch_score_variant(ctx, d_kp, d_X, n, d_M + (size_t)evaluated * 48, want,
+                                           d_counts + 4 * (size_t)evaluated));
             VOHIP_HIP(ctx, hipMemcpyAsync(h_counts + 4 * (size_t)evaluated, d_counts + 4 * (size_t)evaluated,
                                           (size_t)4 * want * sizeof(int32_t), hipMemcpyDeviceToHost, st));
             VOHIP_HIP(ctx, hipStreamSynchronize(st));

@@ -40,6 +40,7 @@ struct vohip_ctx {
     char err[512] = {0};
     vohip_buf bufs[VOHIP_NBUF];
     int ransac_h = 0;  // hypotheses held by B_RANSAC_RT / B_RANSAC_M
+    int opt_ransac_variant = -1;  // scoring-kernel geometry, see vohip_set_option
 };
 
 int vohip_fail(vohip_ctx *ctx, int status, const char *fmt, ...);
