@@ -122,6 +122,59 @@ int vohip_ransac_inlier_mask_dev(vohip_ctx *ctx, const double *d_kp_rc, const do
  * ([C1 R1 C2 R2 C3 R3 C4 R4], real part). */
 int vohip_p3p(vohip_ctx *ctx, const double *world, const double *bearings, int count, double *poses);
 
+/* ---- SE(3) ---------------------------------------------------------------------------------- */
+
+/* utils/exe9_BA/twist2HomogMatrix.m:1-16 for n twists (6xn, [v; w]) -> n 4x4 matrices.  Closed
+ * form of the reference's expm call. */
+int vohip_twist2homog(vohip_ctx *ctx, const double *twists, int n, double *H);
+/* utils/exe9_BA/HomogMatrix2twist.m:1-25 for n 4x4 rigid transforms -> 6xn twists (rotation
+ * angle in [0, pi]).  Closed form of the reference's logm call. */
+int vohip_homog2twist(vohip_ctx *ctx, const double *H, int n, double *twists);
+
+/* ---- triangulation -------------------------------------------------------------------------- */
+
+/* utils/exe6_8point/linearTriangulation.m:1-41.  p1, p2 3xn homogeneous image points, M1, M2
+ * 3x4 projection matrices -- or one 3x4 per point (3x4xn) when the per_point flag is non-zero,
+ * which is how update_landmarks.m:57-61 calls it (n = 1, a different M_first each time).
+ * P 4xn, dehomogenised. */
+int vohip_triangulate(vohip_ctx *ctx, const double *p1, const double *p2, const double *M1,
+                      const double *M2, int per_point_M1, int per_point_M2, int n, double *P);
+int vohip_triangulate_dev(vohip_ctx *ctx, const double *d_p1, const double *d_p2, const double *d_M1,
+                          const double *d_M2, int per_point_M1, int per_point_M2, int n, double *d_P);
+
+/* utils/linearTriangulation_refinement.m:1-22.  P_init 4xn (rows 1-3 used), p1, p2 ldp x n with
+ * ldp >= 2 (rows 1-2 used), M1, M2 3x4.  P 4xn (row 4 copied).  The reference's lsqnonlin call is
+ * replaced by a per-point Levenberg-Marquardt with analytic Jacobians, at most 20 iterations. */
+int vohip_triangulate_refine(vohip_ctx *ctx, const double *P_init, const double *p1, const double *p2,
+                             int ldp, const double *M1, const double *M2, int n, double *P);
+
+/* ---- candidate bookkeeping ------------------------------------------------------------------ */
+
+/* Continuous_operation/update_candidate.m:12-27.  new_xy n_new x 2 single, (x, y) as
+ * cornerPoints.Location; C_rc 2xnC = S.C and P_rc 2xnP = S.P in (row, col).  keep[i] = 1 iff no
+ * S.C and no S.P point lies in the closed box of half-width r around detection i; all 1 when
+ * S.C is empty (update_candidate.m:25-27). */
+int vohip_candidate_filter(vohip_ctx *ctx, const float *new_xy, int n_new, const double *C_rc, int nC,
+                           const double *P_rc, int nP, double r, uint8_t *keep);
+int vohip_candidate_filter_dev(vohip_ctx *ctx, const float *d_new_xy, int n_new, const double *d_C_rc,
+                               int nC, const double *d_P_rc, int nP, double r, uint8_t *d_keep);
+
+/* Continuous_operation/update_landmarks.m:27-97 for the n candidates that survived tracking and
+ * the epipolar filter: bearing-angle test (:33-43), triangulation of those above the threshold
+ * (:56-61), depth filter and -- with is_BA -- the 100 px reprojection filter (:72-97).
+ *   cur_rc, first_rc 2xn (row, col); T_first 12xn = S.T; T_W_C 4x4 current pose; K 3x3.
+ *   status[i]: 0 = stays a candidate, 1 = becomes a landmark (X[:, i] valid), 2 = dropped.
+ *   X 3xn; angles n (degrees, may be NULL). */
+int vohip_candidate_triangulate(vohip_ctx *ctx, const double *cur_rc, const double *first_rc,
+                                const double *T_first, int n, const double T_W_C[16], const double K[9],
+                                double angle_threshold_deg, double min_depth, double max_depth, int is_BA,
+                                uint8_t *status, double *X, double *angles);
+int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, const double *d_first_rc,
+                                    const double *d_T_first, int n, const double T_W_C[16],
+                                    const double K[9], double angle_threshold_deg, double min_depth,
+                                    double max_depth, int is_BA, uint8_t *d_status, double *d_X,
+                                    double *d_angles);
+
 #ifdef __cplusplus
 }
 #endif

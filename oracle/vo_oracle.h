@@ -61,6 +61,34 @@ int vo_ransac_localization(const double *kp_rc, const double *X, int n, const do
  * maximum inlier count and point count. */
 double vo_ransac_num_iterations(int max_num_inliers, int n);
 
+/* ---- geometry_oracle.c ---------------------------------------------------------------- */
+
+/* utils/exe9_BA/twist2HomogMatrix.m:1-16 (expm of the se(3) matrix; twist = [v; w]). */
+void vo_twist2homog(const double twist[6], double H[16]);
+/* utils/exe9_BA/HomogMatrix2twist.m:1-25 (logm; rotation angle in [0, pi]). */
+void vo_homog2twist(const double H[16], double twist[6]);
+
+/* utils/exe6_8point/linearTriangulation.m:28-39 for one point. */
+void vo_triangulate_one(const double p1[3], const double p2[3], const double *M1, const double *M2,
+                        double P[4]);
+/* linearTriangulation.m:1-41; M 3x4 shared, or 3x4xn when the per_point flag is set (the way
+ * update_landmarks.m:57-61 calls it). */
+void vo_linear_triangulation(const double *p1, const double *p2, const double *M1, const double *M2,
+                             int per_point_M1, int per_point_M2, int n, double *P);
+/* utils/linearTriangulation_refinement.m:1-22. */
+void vo_triangulation_refine_one(const double P_init[3], const double *p1, const double *p2,
+                                 const double *M1, const double *M2, int max_iter, double P_out[3]);
+void vo_triangulation_refinement(const double *P_init, const double *p1, const double *p2, int ldp,
+                                 const double *M1, const double *M2, int n, double *P);
+/* Continuous_operation/update_candidate.m:12-27. */
+void vo_candidate_filter(const float *new_xy, int n_new, const double *C_rc, int nC, const double *P_rc,
+                         int nP, double r, uint8_t *keep);
+/* Continuous_operation/update_landmarks.m:27-97 (angle test, triangulation, depth filter). */
+void vo_candidate_triangulate(const double *cur_rc, const double *first_rc, const double *T_first, int n,
+                              const double T_W_C[16], const double K[9], double angle_threshold_deg,
+                              double min_depth, double max_depth, int is_BA, uint8_t *status,
+                              double *X_out, double *angles_deg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,3 +118,80 @@ def ransac_localization(kp_rc_cols, X_cols, K, samples):
 
 def ransac_num_iterations(max_inliers, n):
     return lib().vo_ransac_num_iterations(int(max_inliers), int(n))
+
+
+# ---- geometry ---------------------------------------------------------------------------
+
+def twist2homog(twist):
+    t = _f64(twist).reshape(6)
+    H = np.zeros(16)
+    lib().vo_twist2homog(_d(t), _d(H))
+    return H.reshape(4, 4).T.copy()
+
+
+def homog2twist(H):
+    Hc = _f64(np.asarray(H).T)
+    t = np.zeros(6)
+    lib().vo_homog2twist(_d(Hc), _d(t))
+    return t
+
+
+def _proj_cm(M):
+    """3x4 (or n x 3 x 4) projection matrices -> column-major memory image(s)."""
+    M = np.asarray(M, dtype=np.float64)
+    if M.ndim == 2:
+        return np.ascontiguousarray(M.T), 0
+    return np.ascontiguousarray(np.transpose(M, (0, 2, 1))), 1
+
+
+def linear_triangulation(p1, p2, M1, M2):
+    """p1, p2: 3xn (math layout).  M: 3x4 or n x 3 x 4.  Returns 4xn."""
+    a = _f64(np.asarray(p1).T)
+    b = _f64(np.asarray(p2).T)
+    n = a.shape[0]
+    m1, f1 = _proj_cm(M1)
+    m2, f2 = _proj_cm(M2)
+    P = np.zeros((n, 4))
+    lib().vo_linear_triangulation(_d(a), _d(b), _d(m1), _d(m2), C.c_int(f1), C.c_int(f2), C.c_int(n), _d(P))
+    return P.T.copy()
+
+
+def triangulation_refinement(P_init, p1, p2, M1, M2):
+    Pi = _f64(np.asarray(P_init).T)
+    a = _f64(np.asarray(p1).T)
+    b = _f64(np.asarray(p2).T)
+    n = Pi.shape[0]
+    m1, _ = _proj_cm(M1)
+    m2, _ = _proj_cm(M2)
+    P = np.zeros((n, 4))
+    lib().vo_triangulation_refinement(_d(Pi), _d(a), _d(b), C.c_int(a.shape[1]), _d(m1), _d(m2), C.c_int(n), _d(P))
+    return P.T.copy()
+
+
+def candidate_filter(new_xy, C_rc, P_rc, r):
+    """new_xy (n_new, 2) float32 (x, y); C_rc 2xM, P_rc 2xN (row; col).  Returns bool keep[n_new]."""
+    xy = np.ascontiguousarray(np.asarray(new_xy, dtype=np.float32).T)  # column-major n_new x 2
+    n_new = xy.shape[1]
+    Cc = _f64(np.asarray(C_rc).reshape(2, -1).T)
+    Pc = _f64(np.asarray(P_rc).reshape(2, -1).T)
+    keep = np.zeros(max(n_new, 1), dtype=np.uint8)
+    lib().vo_candidate_filter(xy.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(n_new), _d(Cc), C.c_int(Cc.shape[0]),
+                              _d(Pc), C.c_int(Pc.shape[0]), C.c_double(r), keep.ctypes.data_as(_bp))
+    return keep[:n_new].astype(bool)
+
+
+def candidate_triangulate(cur_rc, first_rc, T_first, T_W_C, K, angle_threshold, min_depth, max_depth, is_BA):
+    """cur_rc, first_rc 2xn; T_first 12xn; T_W_C 4x4.  Returns status (n,), X (3xn), angles (n,)."""
+    c = _f64(np.asarray(cur_rc).T)
+    f = _f64(np.asarray(first_rc).T)
+    Tf = _f64(np.asarray(T_first).T)
+    n = c.shape[0]
+    Tc = _f64(np.asarray(T_W_C).T)
+    Kc = _f64(np.asarray(K).T)
+    status = np.zeros(max(n, 1), dtype=np.uint8)
+    X = np.zeros((max(n, 1), 3))
+    ang = np.zeros(max(n, 1))
+    lib().vo_candidate_triangulate(_d(c), _d(f), _d(Tf), C.c_int(n), _d(Tc), _d(Kc), C.c_double(angle_threshold),
+                                   C.c_double(min_depth), C.c_double(max_depth), C.c_int(int(is_BA)),
+                                   status.ctypes.data_as(_bp), _d(X), _d(ang))
+    return status[:n], X[:n].T.copy(), ang[:n]

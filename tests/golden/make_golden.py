@@ -50,7 +50,31 @@ def make_ransac():
     np.savez_compressed(os.path.join(HERE, "p3p_64.npz"), world=world, bearings=bear, poses=poses)
 
 
-MAKERS = {"ransac": make_ransac}
+def make_geometry():
+    rng = np.random.default_rng(10)
+    twists = np.concatenate([rng.normal(0, 1, (40, 6)) * np.array([2, 2, 2, 0.3, 0.3, 0.3]),
+                             rng.normal(0, 1, (10, 6)) * np.array([2, 2, 2, 1e-6, 1e-6, 1e-6]),
+                             np.zeros((1, 6))])
+    H = np.stack([orc.twist2homog(t) for t in twists])
+    back = np.stack([orc.homog2twist(h) for h in H])
+    p1, p2, M1, M2, X = vo_synth.two_view_problem(1000, noise_px=0.5, seed=11)
+    P_lin = orc.linear_triangulation(p1, p2, M1, M2)
+    P_ref = orc.triangulation_refinement(P_lin, p1, p2, M1, M2)
+    C_rc = np.stack([rng.uniform(0, 376, 700), rng.uniform(0, 1241, 700)])
+    P_rc = np.stack([rng.uniform(0, 376, 900), rng.uniform(0, 1241, 900)])
+    new_xy = np.stack([rng.uniform(0, 1241, 1300), rng.uniform(0, 376, 1300)], axis=1).astype(np.float32)
+    keep = orc.candidate_filter(new_xy, C_rc, P_rc, 10.0)
+    cur, first, T_first, T_W_C, Xc = vo_synth.candidate_problem(1500, seed=12)
+    st, Xn, ang = orc.candidate_triangulate(cur, first, T_first, T_W_C, vo_synth.K_KITTI, 1.0, 1.0, 80.0, False)
+    st_ba, Xn_ba, _ = orc.candidate_triangulate(cur, first, T_first, T_W_C, vo_synth.K_KITTI, 1.0, 1.0, 80.0, True)
+    np.savez_compressed(os.path.join(HERE, "geometry.npz"), twists=twists, H=H, twists_back=back,
+                        p1=p1, p2=p2, M1=M1, M2=M2, P_lin=P_lin, P_ref=P_ref,
+                        C_rc=C_rc, P_rc=P_rc, new_xy=new_xy, keep=keep,
+                        cur_rc=cur, first_rc=first, T_first=T_first, T_W_C=T_W_C, K=vo_synth.K_KITTI,
+                        status=st, X_new=Xn, angles=ang, status_ba=st_ba, X_new_ba=Xn_ba)
+
+
+MAKERS = {"ransac": make_ransac, "geometry": make_geometry}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(MAKERS)

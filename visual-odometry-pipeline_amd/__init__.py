@@ -6,5 +6,7 @@ from . import _lib
 from ._lib import Context, VohipError, default_context
 from . import synth
 from .ransac import draw_triples, p3p, ransacLocalization
+from .geometry import (Cross2Matrix, HomogMatrix2twist, Matrix2Cross, candidate_filter, candidate_triangulate,
+                       linearTriangulation, linearTriangulation_refinement, twist2HomogMatrix)
 
 __all__ = ["Context", "VohipError", "default_context", "ransacLocalization", "p3p", "draw_triples"]

@@ -50,6 +50,24 @@ SIGNATURES = {
     "vohip_ransac_inlier_mask_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
                                                 c_double_p, C.c_void_p]),
     "vohip_p3p": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, c_double_p]),
+    "vohip_twist2homog": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
+    "vohip_homog2twist": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
+    "vohip_triangulate": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int,
+                                     C.c_int, C.c_int, c_double_p]),
+    "vohip_triangulate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int, C.c_int, C.c_void_p]),
+    "vohip_triangulate_refine": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p,
+                                            c_double_p, C.c_int, c_double_p]),
+    "vohip_candidate_filter": (C.c_int, [C.c_void_p, c_float_p, C.c_int, c_double_p, C.c_int, c_double_p,
+                                          C.c_int, C.c_double, c_uint8_p]),
+    "vohip_candidate_filter_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                              C.c_int, C.c_double, C.c_void_p]),
+    "vohip_candidate_triangulate": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int,
+                                               c_double_p, c_double_p, C.c_double, C.c_double, C.c_double,
+                                               C.c_int, c_uint8_p, c_double_p, c_double_p]),
+    "vohip_candidate_triangulate_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                   c_double_p, c_double_p, C.c_double, C.c_double, C.c_double,
+                                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

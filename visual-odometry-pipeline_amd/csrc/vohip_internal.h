@@ -67,6 +67,21 @@ void vohip_release(vohip_buf &b);
         if (!(cond)) return vohip_fail((ctx), VOHIP_ERR_INVALID_ARGUMENT, "%s", msg); \
     } while (0)
 
+// Reserve context buffer `id` for `bytes` and (when src != NULL) enqueue the host-to-device copy.
+static inline int vohip_upload(vohip_ctx *ctx, int id, const void *src, size_t bytes, void **dptr)
+{
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[id], bytes ? bytes : 1));
+    *dptr = ctx->bufs[id].ptr;
+    if (src && bytes)
+        VOHIP_HIP(ctx, hipMemcpyAsync(*dptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return VOHIP_OK;
+}
+static inline int vohip_download(vohip_ctx *ctx, void *dst, const void *dsrc, size_t bytes)
+{
+    if (bytes) VOHIP_HIP(ctx, hipMemcpyAsync(dst, dsrc, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return VOHIP_OK;
+}
+
 // Camera matrix passed to kernels by value (column-major, as MATLAB stores it).
 struct vohip_K {
     double k[9];

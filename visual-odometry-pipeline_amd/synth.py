@@ -41,3 +41,62 @@ def sample_triples(n, count, seed=42):
     """`count` triples of distinct indices in [0, n) from numpy's PCG64(seed)."""
     from .ransac import draw_triples
     return draw_triples(np.random.Generator(np.random.PCG64(seed)), n, count)
+
+
+def pose_matrix(rotvec, t):
+    """4x4 T_W_C from a rotation vector and a camera position."""
+    T = np.eye(4)
+    T[:3, :3] = rotation_from_rotvec(rotvec)
+    T[:3, 3] = t
+    return T
+
+
+def projection_matrix(K, T_W_C):
+    """3x4 M = K * inv(T_W_C)(1:3, :)."""
+    return K @ np.linalg.inv(T_W_C)[:3, :]
+
+
+def two_view_problem(n, noise_px=0.3, seed=0, K=K_KITTI, baseline=2.0):
+    """n world points seen from two cameras: returns p1, p2 (3xn homogeneous pixels), M1, M2, X (3xn)."""
+    rng = np.random.default_rng(seed)
+    T1 = pose_matrix(rng.normal(0, 0.02, 3), rng.normal(0, 0.1, 3))
+    T2 = pose_matrix(rng.normal(0, 0.05, 3), np.array([baseline, 0.2, 0.5]) + rng.normal(0, 0.1, 3))
+    X = np.stack([rng.uniform(-8, 8, n), rng.uniform(-3, 3, n), rng.uniform(8, 40, n)])
+    M1, M2 = projection_matrix(K, T1), projection_matrix(K, T2)
+    Xh = np.vstack([X, np.ones(n)])
+    p1 = M1 @ Xh
+    p1 /= p1[2]
+    p2 = M2 @ Xh
+    p2 /= p2[2]
+    p1[:2] += rng.normal(0, noise_px, (2, n))
+    p2[:2] += rng.normal(0, noise_px, (2, n))
+    return p1, p2, M1, M2, X
+
+
+def candidate_problem(n, seed=0, K=K_KITTI, noise_px=0.3):
+    """State of update_landmarks after tracking: n candidates first seen from one of 6 earlier
+    poses, now seen from the current pose.  Returns cur_rc, first_rc (2xn), T_first (12xn),
+    T_W_C (4x4), X_true (3xn).  Depths 3..150 m and baselines 0..5 m so that every status occurs."""
+    rng = np.random.default_rng(seed)
+    T_W_C = pose_matrix(rng.normal(0, 0.03, 3), np.array([0.3, -0.1, 6.0]))
+    firsts = [pose_matrix(rng.normal(0, 0.03, 3), np.array([rng.normal(0, 0.2), rng.normal(0, 0.05), z]))
+              for z in (0.0, 1.0, 2.5, 4.0, 5.0, 5.9)]
+    which = rng.integers(0, len(firsts), n)
+    Mc = projection_matrix(K, T_W_C)
+    u = rng.uniform(50, KITTI_W - 50, n)
+    v = rng.uniform(20, KITTI_H - 20, n)
+    z = rng.uniform(3, 150, n)
+    pc = np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z, np.ones(n)])
+    X = (T_W_C @ pc)[:3]
+    Xh = np.vstack([X, np.ones(n)])
+    cur = Mc @ Xh
+    cur = cur[:2] / cur[2] + rng.normal(0, noise_px, (2, n))
+    first = np.zeros((2, n))
+    T_first = np.zeros((12, n))
+    for i in range(n):
+        Tf = firsts[which[i]]
+        pf = projection_matrix(K, Tf) @ Xh[:, i]
+        first[:, i] = pf[:2] / pf[2] + rng.normal(0, noise_px, 2)
+        T_first[:9, i] = Tf[:3, :3].T.reshape(9)  # column-major R
+        T_first[9:, i] = Tf[:3, 3]
+    return cur[::-1].copy(), first[::-1].copy(), T_first, T_W_C, X
