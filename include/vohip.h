@@ -175,6 +175,37 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
                                     double max_depth, int is_BA, uint8_t *d_status, double *d_X,
                                     double *d_angles);
 
+/* ---- image pyramids and KLT tracking -------------------------------------------------------
+ * Stand in for vision.PointTracker as the reference uses it: constructed at
+ * main_demo.m:342-343,348-349 ('BlockSize',[21 21],'NumPyramidLevels',5,'MaxIterations',20,
+ * 'MaxBidirectionalError',6), initialize(obj, points, I) at main_demo.m:344,418,423,
+ * [points, validity] = obj(I) at main_demo.m:380 and update_landmarks.m:10.
+ * Because the reference re-initialises both trackers on every frame, tracking is a pure
+ * function of (previous image, current image, points): pyramids live in numbered slots of the
+ * context so that one pyramid per frame serves both trackers and the next frame.
+ * Images are uint8, rows x cols; colmajor != 0 means MATLAB's column-major storage (no
+ * transpose is made: the tracker is symmetric in the axes).  Points are (x, y), 1-based, stored
+ * n x 2 column-major exactly like MATLAB's N-by-2 matrices.
+ */
+int vohip_pyramid_build(vohip_ctx *ctx, int slot, const uint8_t *img, int rows, int cols, int colmajor,
+                        int levels);
+int vohip_pyramid_build_dev(vohip_ctx *ctx, int slot, const uint8_t *d_img, int rows, int cols,
+                            int colmajor, int levels);
+/* Copies one level (float, fast-axis-major) to `out` (may be NULL to query the size only);
+ * A = fast-axis length, B = slow-axis length. */
+int vohip_pyramid_level(vohip_ctx *ctx, int slot, int level, float *out, int *A, int *B);
+
+/* Tracks n points from the image in slot_prev to the image in slot_cur.  valid[i] = 1 iff the
+ * normal matrix is well conditioned in both directions, the new position lies inside the image
+ * and the forward-backward distance is <= max_bidir_error.  fb_err may be NULL.
+ * block_size: 21 or 31 (BlockSize [b b]). */
+int vohip_klt_track(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *pts_xy, int n,
+                    int block_size, int max_iter, double max_bidir_error, double *out_xy,
+                    uint8_t *valid, double *fb_err);
+int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int n,
+                        int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
+                        uint8_t *d_valid, double *d_fb_err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,18 @@ void vo_candidate_triangulate(const double *cur_rc, const double *first_rc, cons
                               double min_depth, double max_depth, int is_BA, uint8_t *status,
                               double *X_out, double *angles_deg);
 
+/* ---- klt_oracle.c ---------------------------------------------------------------------- */
+
+/* This project's definition of the pyramidal KLT that stands in for vision.PointTracker
+ * (main_demo.m:342-343,380; update_landmarks.m:10); see the header of klt_oracle.c.
+ * Images are img[b * A + a] (a = fast axis); a column-major MATLAB HxW image has A = H, B = W,
+ * a = row, b = column.  Coordinates are 0-based. */
+void vo_pyr_down(const float *src, int A, int B, float *dst);
+void vo_pyramid_level(const uint8_t *img, int A, int B, int level, float *out, int *Aout, int *Bout);
+void vo_klt_track(const uint8_t *prev, const uint8_t *cur, int A, int B, const double *pts, int n, int W,
+                  int levels, int max_iter, double max_bidir_error, double *out, uint8_t *valid,
+                  double *fb_err);
+
 #ifdef __cplusplus
 }
 #endif

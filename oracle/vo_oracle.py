@@ -195,3 +195,36 @@ def candidate_triangulate(cur_rc, first_rc, T_first, T_W_C, K, angle_threshold, 
                                    C.c_double(min_depth), C.c_double(max_depth), C.c_int(int(is_BA)),
                                    status.ctypes.data_as(_bp), _d(X), _d(ang))
     return status[:n], X[:n].T.copy(), ang[:n]
+
+
+# ---- KLT ----------------------------------------------------------------------------------
+
+def pyramid_level(img_ab, level):
+    """img_ab: uint8 array of shape (B, A) (slow axis first).  Returns float32 (B_l, A_l)."""
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    out = np.zeros(A * B, dtype=np.float32)
+    Ao, Bo = C.c_int(0), C.c_int(0)
+    lib().vo_pyramid_level(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_int(level),
+                           out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(Ao), C.byref(Bo))
+    return out[:Ao.value * Bo.value].reshape(Bo.value, Ao.value).copy()
+
+
+def klt_track(prev_ab, cur_ab, pts_ab, block=21, levels=5, max_iter=20, max_bidir_error=6.0):
+    """prev_ab, cur_ab uint8 (B, A); pts_ab (n, 2) 0-based (a, b) coordinates.
+    Returns (out (n, 2), valid bool (n,), fb_err (n,))."""
+    p = np.ascontiguousarray(prev_ab, dtype=np.uint8)
+    q = np.ascontiguousarray(cur_ab, dtype=np.uint8)
+    B, A = p.shape
+    pts = np.ascontiguousarray(np.asarray(pts_ab, dtype=np.float64).T)  # 2 x n -> [a..., b...]
+    n = pts.shape[1]
+    out = np.zeros((2, max(n, 1)))
+    valid = np.zeros(max(n, 1), dtype=np.uint8)
+    fb = np.zeros(max(n, 1))
+    if n:
+        outc = np.zeros(2 * n)
+        lib().vo_klt_track(p.ctypes.data_as(_bp), q.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), _d(pts), C.c_int(n),
+                           C.c_int(block), C.c_int(levels), C.c_int(max_iter), C.c_double(max_bidir_error),
+                           _d(outc), valid.ctypes.data_as(_bp), _d(fb))
+        out = outc.reshape(2, n)
+    return out[:, :n].T.copy(), valid[:n].astype(bool), fb[:n]

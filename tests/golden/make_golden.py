@@ -74,7 +74,33 @@ def make_geometry():
                         status=st, X_new=Xn, angles=ang, status_ba=st_ba, X_new_ba=Xn_ba)
 
 
-MAKERS = {"ransac": make_ransac, "geometry": make_geometry}
+def klt_frames(h=240, w=320, seed=31):
+    """Two uint8 frames: a band-limited texture and the same texture shifted by (3.3, -1.7) px plus
+    a smooth brightness change; and 200 points, a few of them in flat or out-of-range places."""
+    base = vo_synth.textured_image(h, w, seed=seed)
+    I0 = vo_synth.to_uint8(base)
+    I0[100:140, 200:250] = 128  # flat patch: untrackable
+    moved = vo_synth.shift_image(base, 3.3, -1.7)
+    I1 = vo_synth.to_uint8(moved * 0.98 + 2.0)
+    I1[100:140, 200:250] = 128
+    rng = np.random.default_rng(seed)
+    pts = np.stack([rng.uniform(5, w - 5, 200), rng.uniform(5, h - 5, 200)], axis=1)  # (x, y) 1-based
+    pts[0] = (225.0, 120.0)   # centre of the flat patch
+    pts[1] = (1.0, 1.0)       # image corner
+    pts[2] = (w, h)           # opposite corner
+    return I0, I1, pts
+
+
+def make_klt():
+    I0, I1, pts = klt_frames()
+    # row-major image: fast axis a = x, slow axis b = y; 0-based coordinates for the oracle
+    out, valid, fb = orc.klt_track(I0, I1, pts - 1.0, block=21, levels=5, max_iter=20, max_bidir_error=6.0)
+    lv = [orc.pyramid_level(I0, l) for l in range(5)]
+    np.savez_compressed(os.path.join(HERE, "klt_320x240.npz"), I0=I0, I1=I1, pts=pts, out=out + 1.0, valid=valid,
+                        fb_err=fb, level1=lv[1], level3=lv[3], level4=lv[4])
+
+
+MAKERS = {"ransac": make_ransac, "geometry": make_geometry, "klt": make_klt}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(MAKERS)

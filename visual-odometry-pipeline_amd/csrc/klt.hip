@@ -1,0 +1,368 @@
+// Image pyramids and the pyramidal Lucas-Kanade tracker for gfx950.
+//
+// Stands in for vision.PointTracker as the reference uses it (constructed at
+// main_demo.m:342-343,348-349 with BlockSize [21 21], NumPyramidLevels 5, MaxIterations 20,
+// MaxBidirectionalError 6; initialised and stepped at main_demo.m:344,380,417-424 and
+// update_landmarks.m:10).  The toolbox's internals are not public; the algorithm implemented
+// here is defined in full below and in the comments of the kernels.
+//
+// Layout: an image is img[b * A + a] with a the fast axis.  A MATLAB column-major HxW image is
+// exactly that with a = row, b = column; the tracker is symmetric in the two axes, so images
+// are never transposed -- only the point coordinates are mapped ((x, y) 1-based <-> (a, b)
+// 0-based).
+//
+// klt_track_kernel: ONE WAVEFRONT PER TRACK, forward then backward pass in the same launch.
+//   per pyramid level (coarse to fine):
+//     * the (W+3)^2 neighbourhood of the point in the previous image is staged in LDS; each lane
+//       owns ceil(W^2/64) window pixels and keeps their template value and central-difference
+//       gradients in registers;
+//     * G = sum [gx gx, gx gy; gy gy] and, per iteration, b = sum e [gx; gy] are accumulated
+//       in fp64 per lane and reduced across the wavefront with xor-shuffles (every lane ends up
+//       with the same bits, so the Gauss-Newton step is wave-uniform);
+//     * a (W+12)^2 region of the current image around the running estimate is staged in LDS and
+//       re-used by successive iterations while the estimate stays within +-5 px of its centre.
+//   Pixel arithmetic is fp32 with explicit fmaf (bit-identical to a scalar evaluation of the
+//   same formulas); all sums are fp64.
+#include "vohip_internal.h"
+
+namespace {
+
+constexpr int MAX_LEVELS = 8;
+constexpr double KLT_EPS_STEP = 0.01;  // px; iteration stops after a shorter step
+constexpr double KLT_MIN_EIG = 1e-3;   // lambda_min(G) / W^2 below this: untrackable
+
+struct pyr_desc {
+    const float *lvl[MAX_LEVELS];
+    int A[MAX_LEVELS], B[MAX_LEVELS];
+    int levels;
+};
+
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float tap5(float t0, float t1, float t2, float t3, float t4)
+{
+    return ((t0 + t4) + 4.0f * (t1 + t3) + 6.0f * t2) * 0.0625f;
+}
+
+__global__ __launch_bounds__(256) void u8_to_float_kernel(const uint8_t *__restrict__ src, int n,
+                                                          float *__restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+// [1 4 6 4 1]/16 along a then along b, replicated border, even samples kept.
+__global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__ src, int A, int B,
+                                                       float *__restrict__ dst, int A2, int B2)
+{
+    const int a = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int b = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (a >= A2 || b >= B2) return;
+    const int a0 = max(2 * a - 2, 0), a1 = max(2 * a - 1, 0), a2 = 2 * a, a3 = min(2 * a + 1, A - 1),
+              a4 = min(2 * a + 2, A - 1);
+    float col[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int bb = min(max(2 * b + j - 2, 0), B - 1);
+        const float *row = src + (size_t)bb * A;
+        col[j] = tap5(row[a0], row[a1], row[a2], row[a3], row[a4]);
+    }
+    dst[(size_t)b * A2 + a] = tap5(col[0], col[1], col[2], col[3], col[4]);
+}
+
+#pragma clang fp contract(fast)
+
+__device__ __forceinline__ float bilerp(float i00, float i01, float i10, float i11, float fa, float fb)
+{
+    const float top = __builtin_fmaf(fa, i01 - i00, i00);
+    const float bot = __builtin_fmaf(fa, i11 - i10, i10);
+    return __builtin_fmaf(fb, bot - top, top);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <int W>
+struct klt_cfg {
+    static constexpr int HALF = W / 2;
+    static constexpr int NPIX = W * W;
+    static constexpr int PER_LANE = (NPIX + 63) / 64;
+    static constexpr int SI = W + 3;        // template neighbourhood side
+    static constexpr int MARG = 5;          // px the estimate may drift before the region is re-staged
+    static constexpr int SJ = W + 2 * MARG + 2;
+};
+
+// Tracks (pa, pb) from pyramid P to pyramid Q.  sI / sJ: this wavefront's LDS.
+template <int W>
+__device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, double pa, double pb,
+                          double &qa, double &qb, float *sI, float *sJ)
+{
+    using C = klt_cfg<W>;
+    const int lane = threadIdx.x;
+    double da = 0.0, db = 0.0;
+    bool ok0 = true;
+    for (int l = P.levels - 1; l >= 0; --l) {
+        const int A = P.A[l], B = P.B[l];
+        const float *__restrict__ Pl = P.lvl[l];
+        const float *__restrict__ Ql = Q.lvl[l];
+        const double scale = 1.0 / (double)(1 << l);
+        const double ca = pa * scale, cb = pb * scale;
+        const double fca = floor(ca), fcb = floor(cb);
+        const int ia = (int)fca, ib = (int)fcb;
+        const float fa = (float)(ca - fca), fb = (float)(cb - fcb);
+
+        // stage the template neighbourhood: raw pixels at offsets -(HALF+1) .. HALF+2
+        __syncthreads();
+        for (int q = lane; q < C::SI * C::SI; q += 64) {
+            const int rb = q / C::SI, ra = q - rb * C::SI;
+            const int a = min(max(ia - C::HALF - 1 + ra, 0), A - 1);
+            const int b = min(max(ib - C::HALF - 1 + rb, 0), B - 1);
+            sI[q] = Pl[(size_t)b * A + a];
+        }
+        __syncthreads();
+
+        float T[C::PER_LANE], GX[C::PER_LANE], GY[C::PER_LANE];
+        double gxx = 0.0, gxy = 0.0, gyy = 0.0;
+#pragma unroll
+        for (int k = 0; k < C::PER_LANE; ++k) {
+            const int q = lane + 64 * k;
+            T[k] = GX[k] = GY[k] = 0.f;
+            if (q < C::NPIX) {
+                const int wb = q / W, wa = q - wb * W;
+                // raw index of the window pixel's top-left tap
+                const float *c = sI + (wb + 1) * C::SI + (wa + 1);
+                auto samp = [&](const float *p) { return bilerp(p[0], p[1], p[C::SI], p[C::SI + 1], fa, fb); };
+                const float v = samp(c);
+                const float ap = samp(c + 1), am = samp(c - 1);
+                const float bp = samp(c + C::SI), bm = samp(c - C::SI);
+                const float gx = (ap - am) * 0.5f, gy = (bp - bm) * 0.5f;
+                T[k] = v;
+                GX[k] = gx;
+                GY[k] = gy;
+                gxx += (double)gx * (double)gx;
+                gxy += (double)gx * (double)gy;
+                gyy += (double)gy * (double)gy;
+            }
+        }
+        gxx = wave_sum(gxx);
+        gxy = wave_sum(gxy);
+        gyy = wave_sum(gyy);
+        const double det = gxx * gyy - gxy * gxy;
+        const double lmin = 0.5 * ((gxx + gyy) - sqrt((gxx - gyy) * (gxx - gyy) + 4.0 * gxy * gxy));
+        const bool good = (lmin / (double)(W * W) >= KLT_MIN_EIG) && det > 0.0;
+        if (l == 0) ok0 = good;
+        if (good) {
+            int cja = 0, cjb = 0;
+            bool staged = false;
+            for (int it = 0; it < max_iter; ++it) {
+                const double ta = ca + da, tb = cb + db;
+                const double fta = floor(ta), ftb = floor(tb);
+                // positions far outside the image cannot come back; keep integer math bounded
+                const int ja = (int)fmin(fmax(fta, -1.0e6), 1.0e6), jb = (int)fmin(fmax(ftb, -1.0e6), 1.0e6);
+                const float ga = (float)(ta - fta), gb = (float)(tb - ftb);
+                if (!staged || abs(ja - cja) > C::MARG || abs(jb - cjb) > C::MARG) {
+                    cja = ja;
+                    cjb = jb;
+                    staged = true;
+                    __syncthreads();
+                    for (int q = lane; q < C::SJ * C::SJ; q += 64) {
+                        const int rb = q / C::SJ, ra = q - rb * C::SJ;
+                        const int a = min(max(cja - C::HALF - C::MARG + ra, 0), A - 1);
+                        const int b = min(max(cjb - C::HALF - C::MARG + rb, 0), B - 1);
+                        sJ[q] = Ql[(size_t)b * A + a];
+                    }
+                    __syncthreads();
+                }
+                const float *org = sJ + (jb - cjb + C::MARG) * C::SJ + (ja - cja + C::MARG);
+                double ba = 0.0, bb = 0.0;
+#pragma unroll
+                for (int k = 0; k < C::PER_LANE; ++k) {
+                    const int q = lane + 64 * k;
+                    if (q < C::NPIX) {
+                        const int wb = q / W, wa = q - wb * W;
+                        const float *p = org + wb * C::SJ + wa;
+                        const float j = bilerp(p[0], p[1], p[C::SJ], p[C::SJ + 1], ga, gb);
+                        const float e = T[k] - j;
+                        ba += (double)e * (double)GX[k];
+                        bb += (double)e * (double)GY[k];
+                    }
+                }
+                ba = wave_sum(ba);
+                bb = wave_sum(bb);
+                const double sa = (gyy * ba - gxy * bb) / det;
+                const double sb = (gxx * bb - gxy * ba) / det;
+                da += sa;
+                db += sb;
+                if (sa * sa + sb * sb < KLT_EPS_STEP * KLT_EPS_STEP) break;
+            }
+        }
+        if (l > 0) {
+            da *= 2.0;
+            db *= 2.0;
+        }
+    }
+    qa = pa + da;
+    qb = pb + db;
+    return ok0;
+}
+
+// pts_xy / out_xy: n x 2 column-major, MATLAB's (x, y), 1-based.  swap_xy: the image is a
+// column-major MATLAB image, so a = y - 1, b = x - 1; otherwise a = x - 1, b = y - 1.
+template <int W>
+__global__ __launch_bounds__(64) void klt_track_kernel(pyr_desc P, pyr_desc Q, const double *__restrict__ pts_xy,
+                                                       int n, int swap_xy, int max_iter, double max_bidir,
+                                                       double *__restrict__ out_xy, uint8_t *__restrict__ valid,
+                                                       double *__restrict__ fb_err)
+{
+    using C = klt_cfg<W>;
+    __shared__ float sI[C::SI * C::SI];
+    __shared__ float sJ[C::SJ * C::SJ];
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const double x = pts_xy[i] - 1.0, y = pts_xy[n + i] - 1.0;
+    const double pa = swap_xy ? y : x, pb = swap_xy ? x : y;
+    double qa, qb, ra, rb;
+    const bool ok_f = track_dir<W>(P, Q, max_iter, pa, pb, qa, qb, sI, sJ);
+    const bool ok_b = track_dir<W>(Q, P, max_iter, qa, qb, ra, rb, sI, sJ);
+    const double ea = ra - pa, eb = rb - pb;
+    const double err = sqrt(ea * ea + eb * eb);
+    const bool inside = qa >= 0.0 && qa <= (double)(P.A[0] - 1) && qb >= 0.0 && qb <= (double)(P.B[0] - 1);
+    if (threadIdx.x == 0) {
+        out_xy[i] = (swap_xy ? qb : qa) + 1.0;
+        out_xy[n + i] = (swap_xy ? qa : qb) + 1.0;
+        valid[i] = (ok_f && ok_b && inside && err <= max_bidir) ? 1 : 0;
+        if (fb_err) fb_err[i] = err;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+int vohip_pyramid_desc(vohip_ctx *ctx, int slot, pyr_desc &d)
+{
+    VOHIP_REQUIRE(ctx, slot >= 0 && slot < VOHIP_PYR_SLOTS, "pyramid slot out of range");
+    const vohip_pyramid &p = ctx->pyr[slot];
+    VOHIP_REQUIRE(ctx, p.levels > 0, "pyramid slot is empty");
+    d.levels = p.levels;
+    const float *base = (const float *)ctx->bufs[B_PYR0 + slot].ptr;
+    for (int l = 0; l < MAX_LEVELS; ++l) {
+        d.lvl[l] = l < p.levels ? base + p.offset[l] : nullptr;
+        d.A[l] = l < p.levels ? p.A[l] : 0;
+        d.B[l] = l < p.levels ? p.B[l] : 0;
+    }
+    return VOHIP_OK;
+}
+
+extern "C" {
+
+int vohip_pyramid_build_dev(vohip_ctx *ctx, int slot, const uint8_t *d_img, int rows, int cols, int colmajor,
+                            int levels)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, slot >= 0 && slot < VOHIP_PYR_SLOTS, "pyramid slot out of range");
+    VOHIP_REQUIRE(ctx, d_img && rows >= 1 && cols >= 1, "bad image");
+    VOHIP_REQUIRE(ctx, levels >= 1 && levels <= MAX_LEVELS, "levels must be 1..8");
+    vohip_pyramid &p = ctx->pyr[slot];
+    p.rows = rows;
+    p.cols = cols;
+    p.colmajor = colmajor ? 1 : 0;
+    p.levels = levels;
+    size_t total = 0;
+    int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
+    for (int l = 0; l < levels; ++l) {
+        p.A[l] = A;
+        p.B[l] = B;
+        p.offset[l] = total;
+        total += ((size_t)A * B + 63) / 64 * 64;
+        A = (A + 1) / 2;
+        B = (B + 1) / 2;
+    }
+    VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_PYR0 + slot], total * sizeof(float)));
+    float *base = (float *)ctx->bufs[B_PYR0 + slot].ptr;
+    const int n0 = p.A[0] * p.B[0];
+    hipLaunchKernelGGL(u8_to_float_kernel, dim3((n0 + 255) / 256), dim3(256), 0, ctx->stream, d_img, n0, base);
+    for (int l = 1; l < levels; ++l)
+        hipLaunchKernelGGL(pyr_down_kernel, dim3((p.A[l] + 63) / 64, (p.B[l] + 3) / 4), dim3(256), 0, ctx->stream,
+                           base + p.offset[l - 1], p.A[l - 1], p.B[l - 1], base + p.offset[l], p.A[l], p.B[l]);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+int vohip_pyramid_build(vohip_ctx *ctx, int slot, const uint8_t *img, int rows, int cols, int colmajor, int levels)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, img && rows >= 1 && cols >= 1, "bad image");
+    void *d_img;
+    VOHIP_TRY(vohip_upload(ctx, B_IMG_STAGE, img, (size_t)rows * cols, &d_img));
+    return vohip_pyramid_build_dev(ctx, slot, (const uint8_t *)d_img, rows, cols, colmajor, levels);
+}
+
+int vohip_pyramid_level(vohip_ctx *ctx, int slot, int level, float *out, int *A, int *B)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    pyr_desc d;
+    VOHIP_TRY(vohip_pyramid_desc(ctx, slot, d));
+    VOHIP_REQUIRE(ctx, level >= 0 && level < d.levels && A && B, "bad level");
+    *A = d.A[level];
+    *B = d.B[level];
+    if (out) {
+        VOHIP_TRY(vohip_download(ctx, out, d.lvl[level], sizeof(float) * (size_t)d.A[level] * d.B[level]));
+        VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return VOHIP_OK;
+}
+
+int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int n, int block_size,
+                        int max_iter, double max_bidir_error, double *d_out_xy, uint8_t *d_valid, double *d_fb_err)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, n >= 0 && max_iter >= 1, "bad argument");
+    if (n == 0) return VOHIP_OK;
+    VOHIP_REQUIRE(ctx, d_pts_xy && d_out_xy && d_valid, "NULL array");
+    pyr_desc P, Q;
+    VOHIP_TRY(vohip_pyramid_desc(ctx, slot_prev, P));
+    VOHIP_TRY(vohip_pyramid_desc(ctx, slot_cur, Q));
+    const vohip_pyramid &pp = ctx->pyr[slot_prev], &pq = ctx->pyr[slot_cur];
+    VOHIP_REQUIRE(ctx, pp.rows == pq.rows && pp.cols == pq.cols && pp.colmajor == pq.colmajor && pp.levels == pq.levels,
+                  "previous and current pyramids differ in shape");
+    const int swap_xy = pp.colmajor;
+    if (block_size == 21)
+        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, swap_xy,
+                           max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err);
+    else if (block_size == 31)
+        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, swap_xy,
+                           max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err);
+    else
+        return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "BlockSize %d not built (21 and 31 are)", block_size);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+int vohip_klt_track(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *pts_xy, int n, int block_size,
+                    int max_iter, double max_bidir_error, double *out_xy, uint8_t *valid, double *fb_err)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, n >= 0, "bad argument");
+    if (n == 0) return VOHIP_OK;
+    VOHIP_REQUIRE(ctx, pts_xy && out_xy && valid, "NULL array");
+    void *d_in, *d_out, *d_valid, *d_fb;
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE0, pts_xy, sizeof(double) * 2 * n, &d_in));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE1, nullptr, sizeof(double) * 2 * n, &d_out));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE2, nullptr, (size_t)n, &d_valid));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE3, nullptr, sizeof(double) * n, &d_fb));
+    VOHIP_TRY(vohip_klt_track_dev(ctx, slot_prev, slot_cur, (const double *)d_in, n, block_size, max_iter,
+                                  max_bidir_error, (double *)d_out, (uint8_t *)d_valid, (double *)d_fb));
+    VOHIP_TRY(vohip_download(ctx, out_xy, d_out, sizeof(double) * 2 * n));
+    VOHIP_TRY(vohip_download(ctx, valid, d_valid, (size_t)n));
+    if (fb_err) VOHIP_TRY(vohip_download(ctx, fb_err, d_fb, sizeof(double) * n));
+    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VOHIP_OK;
+}
+
+}  // extern "C"

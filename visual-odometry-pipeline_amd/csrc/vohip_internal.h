@@ -30,7 +30,17 @@ enum vohip_buf_id {
     H_RANSAC_COUNTS,
     B_STAGE0, B_STAGE1, B_STAGE2, B_STAGE3, B_STAGE4, B_STAGE5, B_STAGE6, B_STAGE7,
     H_STAGE0, H_STAGE1, H_STAGE2, H_STAGE3,
+    B_IMG_STAGE,
+    B_PYR0, B_PYR1, B_PYR2, B_PYR3, B_PYR4, B_PYR5, B_PYR6, B_PYR7,
     VOHIP_NBUF = 96
+};
+
+// One image pyramid (float levels, all in one context buffer B_PYR0 + slot).
+constexpr int VOHIP_PYR_SLOTS = 8;
+struct vohip_pyramid {
+    int rows = 0, cols = 0, colmajor = 0, levels = 0;
+    int A[8] = {0}, B[8] = {0};   // fast / slow axis length per level
+    size_t offset[8] = {0};       // in floats from the start of the buffer
 };
 
 struct vohip_ctx {
@@ -39,6 +49,7 @@ struct vohip_ctx {
     bool owns_stream = false;
     char err[512] = {0};
     vohip_buf bufs[VOHIP_NBUF];
+    vohip_pyramid pyr[VOHIP_PYR_SLOTS];
     int ransac_h = 0;  // hypotheses held by B_RANSAC_RT / B_RANSAC_M
     int opt_ransac_variant = -1;  // scoring-kernel geometry, see vohip_set_option
 };

@@ -100,3 +100,33 @@ def candidate_problem(n, seed=0, K=K_KITTI, noise_px=0.3):
         T_first[:9, i] = Tf[:3, :3].T.reshape(9)  # column-major R
         T_first[9:, i] = Tf[:3, 3]
     return cur[::-1].copy(), first[::-1].copy(), T_first, T_W_C, X
+
+
+def textured_image(height, width, seed=0, sigma=1.5, octaves=5):
+    """Natural-image-like random texture as a float64 array (height, width) in 0..255: a sum of
+    band-limited white-noise layers with Gaussian sigma, 2 sigma, 4 sigma, ... and equal
+    variance per octave (a 1/f-like spectrum, so every pyramid level has trackable structure).
+    Periodic, so it can be shifted exactly in the Fourier domain."""
+    rng = np.random.default_rng(seed)
+    fy = np.fft.fftfreq(height)[:, None]
+    fx = np.fft.fftfreq(width)[None, :]
+    img = np.zeros((height, width))
+    for o in range(octaves):
+        s = sigma * 2 ** o
+        gauss = np.exp(-2.0 * (np.pi * s) ** 2 * (fx ** 2 + fy ** 2))
+        layer = np.fft.ifft2(np.fft.fft2(rng.normal(size=(height, width))) * gauss).real
+        img += layer / layer.std()
+    lo, hi = np.percentile(img, [0.5, 99.5])
+    return 255.0 * np.clip((img - lo) / (hi - lo), 0.0, 1.0)
+
+
+def shift_image(img, dx, dy):
+    """Exact (Fourier) sub-pixel shift of a periodic float image: out(y, x) = img(y - dy, x - dx)."""
+    h, w = img.shape
+    fy = np.fft.fftfreq(h)[:, None]
+    fx = np.fft.fftfreq(w)[None, :]
+    return np.fft.ifft2(np.fft.fft2(img) * np.exp(-2j * np.pi * (fx * dx + fy * dy))).real
+
+
+def to_uint8(img):
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
