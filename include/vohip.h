@@ -42,7 +42,9 @@ typedef enum vohip_status {
     VOHIP_SAMPLES_EXHAUSTED = 4,    /* RANSAC: the adaptive stop was not reached within the supplied
                                        sample triples; outputs hold the best model so far */
     VOHIP_TOO_FEW_POINTS = 5,
-    VOHIP_ERR_NO_DEVICE = 6
+    VOHIP_ERR_NO_DEVICE = 6,
+    VOHIP_CAPACITY_EXCEEDED = 7     /* an output list was longer than the caller's capacity; the
+                                       first `cap` entries are valid but their choice is arbitrary */
 } vohip_status;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -205,6 +207,29 @@ int vohip_klt_track(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *p
 int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int n,
                         int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
                         uint8_t *d_valid, double *d_fb_err);
+
+/* ---- corner detection ----------------------------------------------------------------------
+ * Stands in for genKeypoints.m:1-33 with method 'Harris' or 'MinEigen': detectHarrisFeatures /
+ * detectMinEigenFeatures(image, 'MinQuality', q [, 'FilterSize', 5]) followed by extractFeatures,
+ * of which the continuous-operation loop only uses valid_key_points.Location
+ * (update_candidate.m:10,26,57) -- i.e. the detections that survive extractFeatures' border drop.
+ *   image      uint8 rows x cols, colmajor != 0 for MATLAB storage
+ *   border     detections closer than this to an image edge are dropped (extractFeatures' margin)
+ *   method     0 = Harris, 1 = MinEigen
+ *   xy_out     n x 2 single, (x, y) 1-based, column-major -- cornerPoints.Location
+ *   metric_out n single -- cornerPoints.Metric
+ *   cap        capacity of the two outputs (<= 16384); VOHIP_CAPACITY_EXCEEDED if more were found
+ * Output order: ascending linear index of the pixel in storage order (for a column-major image
+ * that is the order of MATLAB's find on the corner mask).
+ */
+int vohip_detect_corners(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor,
+                         double min_quality, int filter_size, int border, int method, float *xy_out,
+                         float *metric_out, int cap, int *n_out);
+/* Device-resident form: d_xy is cap x 2 (x column then y column, cap-strided), d_metric cap,
+ * d_count one int that receives the total number found (may exceed cap).  Asynchronous. */
+int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor,
+                             double min_quality, int filter_size, int border, int method, float *d_xy,
+                             float *d_metric, int cap, int *d_count);
 
 #ifdef __cplusplus
 }

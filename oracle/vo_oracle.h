@@ -101,6 +101,16 @@ void vo_klt_track(const uint8_t *prev, const uint8_t *cur, int A, int B, const d
                   int levels, int max_iter, double max_bidir_error, double *out, uint8_t *valid,
                   double *fb_err);
 
+/* ---- harris_oracle.c ------------------------------------------------------------------- */
+
+/* This project's definition of the corner detector that stands in for detectHarrisFeatures /
+ * detectMinEigenFeatures + extractFeatures' border drop (genKeypoints.m:16-18,31-32); see the
+ * header of harris_oracle.c.  method 0 = Harris, 1 = MinEigen. */
+void vo_gaussian_taps(int filter_size, float *w);
+void vo_corner_response(const uint8_t *img, int A, int B, int filter_size, int method, float *R);
+int vo_detect_corners(const uint8_t *img, int A, int B, double min_quality, int filter_size, int border,
+                      int method, float *ab_out, float *metric_out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

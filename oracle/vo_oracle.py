@@ -228,3 +228,29 @@ def klt_track(prev_ab, cur_ab, pts_ab, block=21, levels=5, max_iter=20, max_bidi
                            _d(outc), valid.ctypes.data_as(_bp), _d(fb))
         out = outc.reshape(2, n)
     return out[:, :n].T.copy(), valid[:n].astype(bool), fb[:n]
+
+
+# ---- corner detection -----------------------------------------------------------------------
+
+def corner_response(img_ab, filter_size=5, method=0):
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    R = np.zeros((B, A), dtype=np.float32)
+    lib().vo_corner_response(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_int(filter_size), C.c_int(method),
+                             R.ctypes.data_as(C.POINTER(C.c_float)))
+    return R
+
+
+def detect_corners(img_ab, min_quality=0.01, filter_size=5, border=16, method=0, cap=16384):
+    """img_ab uint8 (B, A).  Returns ab (n, 2) float32 0-based sub-pixel (a, b), metric (n,), total found."""
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    ab = np.zeros(2 * cap, dtype=np.float32)
+    metric = np.zeros(cap, dtype=np.float32)
+    lib().vo_detect_corners.restype = C.c_int
+    total = lib().vo_detect_corners(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_double(min_quality),
+                                    C.c_int(filter_size), C.c_int(border), C.c_int(method),
+                                    ab.ctypes.data_as(C.POINTER(C.c_float)), metric.ctypes.data_as(C.POINTER(C.c_float)),
+                                    C.c_int(cap))
+    n = min(total, cap)
+    return np.stack([ab[:n], ab[cap:cap + n]], axis=1).copy(), metric[:n].copy(), total

@@ -100,7 +100,26 @@ def make_klt():
                         fb_err=fb, level1=lv[1], level3=lv[3], level4=lv[4])
 
 
-MAKERS = {"ransac": make_ransac, "geometry": make_geometry, "klt": make_klt}
+def harris_frame(h=240, w=320, seed=41):
+    img = vo_synth.textured_image(h, w, seed=seed)
+    # a few synthetic corners: bright rectangles
+    rng = np.random.default_rng(seed)
+    for _ in range(12):
+        y, x = rng.integers(20, h - 40), rng.integers(20, w - 40)
+        img[y:y + rng.integers(8, 20), x:x + rng.integers(8, 20)] += rng.uniform(-80, 80)
+    return vo_synth.to_uint8(img)
+
+
+def make_harris():
+    img = harris_frame()
+    ab, metric, total = orc.detect_corners(img, min_quality=2e-4, filter_size=5, border=16, method=0)
+    ab_me, metric_me, _ = orc.detect_corners(img, min_quality=1e-2, filter_size=5, border=16, method=1)
+    R = orc.corner_response(img)
+    np.savez_compressed(os.path.join(HERE, "harris_320x240.npz"), img=img, xy=ab + 1.0, metric=metric,
+                        xy_mineigen=ab_me + 1.0, metric_mineigen=metric_me, R_row100=R[100], total=total)
+
+
+MAKERS = {"ransac": make_ransac, "geometry": make_geometry, "klt": make_klt, "harris": make_harris}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(MAKERS)

@@ -5,6 +5,7 @@ pipeline, behind the reference's own function names.  All arithmetic runs in lib
 from . import _lib
 from ._lib import Context, VohipError, default_context
 from . import synth
+from .keypoints import cornerPoints, genKeypoints
 from .klt import PointTracker, Pyramid
 from .ransac import draw_triples, p3p, ransacLocalization
 from .geometry import (Cross2Matrix, HomogMatrix2twist, Matrix2Cross, candidate_filter, candidate_triangulate,

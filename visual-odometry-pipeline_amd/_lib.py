@@ -16,10 +16,11 @@ VOHIP_NO_MODEL = 3
 VOHIP_SAMPLES_EXHAUSTED = 4
 VOHIP_TOO_FEW_POINTS = 5
 VOHIP_ERR_NO_DEVICE = 6
+VOHIP_CAPACITY_EXCEEDED = 7
 
 STATUS_NAMES = {
     0: "VOHIP_OK", 1: "VOHIP_ERR_INVALID_ARGUMENT", 2: "VOHIP_ERR_HIP", 3: "VOHIP_NO_MODEL",
-    4: "VOHIP_SAMPLES_EXHAUSTED", 5: "VOHIP_TOO_FEW_POINTS", 6: "VOHIP_ERR_NO_DEVICE",
+    4: "VOHIP_SAMPLES_EXHAUSTED", 5: "VOHIP_TOO_FEW_POINTS", 6: "VOHIP_ERR_NO_DEVICE", 7: "VOHIP_CAPACITY_EXCEEDED",
 }
 
 c_double_p = C.POINTER(C.c_double)
@@ -65,6 +66,10 @@ SIGNATURES = {
     "vohip_candidate_triangulate": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int,
                                                c_double_p, c_double_p, C.c_double, C.c_double, C.c_double,
                                                C.c_int, c_uint8_p, c_double_p, c_double_p]),
+    "vohip_detect_corners": (C.c_int, [C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                        C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, c_int_p]),
+    "vohip_detect_corners_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_pyramid_build": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vohip_pyramid_build_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vohip_pyramid_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_int_p, c_int_p]),

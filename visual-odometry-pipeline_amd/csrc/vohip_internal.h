@@ -31,6 +31,7 @@ enum vohip_buf_id {
     B_STAGE0, B_STAGE1, B_STAGE2, B_STAGE3, B_STAGE4, B_STAGE5, B_STAGE6, B_STAGE7,
     H_STAGE0, H_STAGE1, H_STAGE2, H_STAGE3,
     B_IMG_STAGE,
+    B_HARRIS_R, B_HARRIS_KEYS, B_HARRIS_MAX,
     B_PYR0, B_PYR1, B_PYR2, B_PYR3, B_PYR4, B_PYR5, B_PYR6, B_PYR7,
     VOHIP_NBUF = 96
 };

@@ -1,0 +1,74 @@
+"""Host-side mirror of utils/genKeypoints.m:1-33 for the detectors built natively
+('Harris', 'MinEigen').  Detection runs in libvohip.so on the GPU; no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+DEFAULT_BORDER = 16     # px dropped at the image edge, the stand-in for extractFeatures' margin
+DEFAULT_CAPACITY = 16384
+
+
+class cornerPoints:
+    """The fields of MATLAB's cornerPoints that the pipeline reads: Location (N x 2 single,
+    (x, y) 1-based), Metric (N single), Count."""
+
+    def __init__(self, Location, Metric):
+        self.Location = Location
+        self.Metric = Metric
+
+    @property
+    def Count(self):
+        return self.Location.shape[0]
+
+    def __len__(self):
+        return self.Count
+
+
+def _options(options):
+    """MATLAB name-value cell {'MinQuality', 2e-4, ...} as list/tuple or dict."""
+    if options is None:
+        return {}
+    if isinstance(options, dict):
+        return dict(options)
+    opts = list(options)
+    if len(opts) % 2:
+        raise ValueError("options must be name-value pairs")
+    return {opts[i]: opts[i + 1] for i in range(0, len(opts), 2)}
+
+
+def genKeypoints(image, method="SURF", options=None, ctx=None):
+    """[features, valid_key_points] = genKeypoints(image, method, options)
+
+    method 'Harris' or 'MinEigen'; options {'MinQuality', q, 'FilterSize', 5}.  Two extra options
+    have no MATLAB counterpart: 'Border' (default 16) and 'Capacity'.  `features` is None: the
+    continuous-operation loop never reads it (main_demo.m:377 discards it).  The other detectors
+    of the reference's table (SURF, FAST, BRISK, ORB, SIFT) are closed-source toolbox functions
+    that are not rebuilt here."""
+    if method not in ("Harris", "MinEigen"):
+        raise NotImplementedError("genKeypoints: method '%s' is not built natively (Harris, MinEigen are)" % method)
+    ctx = ctx or _lib.default_context()
+    opts = _options(options)
+    min_quality = float(opts.pop("MinQuality", 0.01))
+    filter_size = int(opts.pop("FilterSize", 5))
+    border = int(opts.pop("Border", DEFAULT_BORDER))
+    cap = int(opts.pop("Capacity", DEFAULT_CAPACITY))
+    if opts:
+        raise ValueError("unknown option(s): %s" % ", ".join(opts))
+    img = np.asarray(image)
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise TypeError("image must be a 2-D uint8 array")
+    colmajor = bool(img.flags.f_contiguous and not img.flags.c_contiguous)
+    if not (img.flags.c_contiguous or img.flags.f_contiguous):
+        img = np.ascontiguousarray(img)
+    xy = np.zeros(2 * cap, dtype=np.float32)
+    metric = np.zeros(cap, dtype=np.float32)
+    n = C.c_int(0)
+    ctx.check(_lib.load().vohip_detect_corners(
+        ctx.handle, img.ctypes.data_as(_lib.c_uint8_p), img.shape[0], img.shape[1], int(colmajor), min_quality,
+        filter_size, border, 0 if method == "Harris" else 1, xy.ctypes.data_as(_lib.c_float_p),
+        metric.ctypes.data_as(_lib.c_float_p), cap, C.byref(n)))
+    k = n.value
+    loc = np.stack([xy[:k], xy[k:2 * k]], axis=1).copy()
+    return None, cornerPoints(loc, metric[:k].copy())
