@@ -208,6 +208,37 @@ int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const doubl
                         int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
                         uint8_t *d_valid, double *d_fb_err);
 
+/* ---- bundle adjustment and pose refinement ------------------------------------------------
+ * hidden_state = [twists of T_W_C (6 x F, [v; w]); landmarks (3 x m)], observations =
+ * [F; m; per frame: n_i; n_i (row, col) pairs; n_i 1-based landmark indices] -- exactly the
+ * vectors VO_bundle_adjust.m:43-50 builds.  F <= 8.
+ */
+
+/* utils/exe9_BA/baError.m:2-65: r_out 2 x Nobs reprojection residuals (keypoint - projection,
+ * u then v).  n_obs_out (may be NULL) receives Nobs. */
+int vohip_ba_error(vohip_ctx *ctx, const double *state, int state_len, const double *obs, int obs_len,
+                   const double K[9], double *r_out, int *n_obs_out);
+
+/* utils/exe9_BA/runBA.m:2-88: minimises the sum of squared residuals over all twists and over
+ * the landmarks seen in at least 2 frames (the others stay fixed, runBA.m:45-49); state is
+ * updated in place.  The reference's two lsqnonlin calls (1 + 20 iterations; the second one only
+ * if the first took under 0.5 s of wall-clock, runBA.m:64-87) are replaced by one
+ * Levenberg-Marquardt run of at most max_iter accepted steps (21 = the reference's budget) with
+ * tolerances ftol (cost decrease relative to 1 + cost) and xtol (step relative to 1 + |x|).
+ * stats (may be NULL): [accepted iterations, initial cost, final cost, final lambda]. */
+int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs, int obs_len,
+                 const double K[9], int max_iter, double ftol, double xtol, double *stats);
+
+/* utils/T_refinement.m:1-21: refines T_W_C (4x4, in place) by minimising keypoints - K T_C_W X
+ * over the 6 twist coordinates; kp_uv 2xN in (u, v) order (callers pass flipud(S.P),
+ * main_demo.m:399), X 3xN.  max_iter 100 in the reference.  stats (may be NULL):
+ * [accepted iterations, initial cost, final cost]. */
+int vohip_pose_refine(vohip_ctx *ctx, double T_W_C[16], const double *kp_uv, const double *X, int n,
+                      const double K[9], int max_iter, double ftol, double xtol, double *stats);
+/* Device-resident form (d_T 16 doubles in/out, d_stats 3 doubles or NULL).  Asynchronous. */
+int vohip_pose_refine_dev(vohip_ctx *ctx, double *d_T_W_C, const double *d_kp_uv, const double *d_X, int n,
+                          const double K[9], int max_iter, double ftol, double xtol, double *d_stats);
+
 /* ---- corner detection ----------------------------------------------------------------------
  * Stands in for genKeypoints.m:1-33 with method 'Harris' or 'MinEigen': detectHarrisFeatures /
  * detectMinEigenFeatures(image, 'MinQuality', q [, 'FilterSize', 5]) followed by extractFeatures,

@@ -101,6 +101,19 @@ void vo_klt_track(const uint8_t *prev, const uint8_t *cur, int A, int B, const d
                   int levels, int max_iter, double max_bidir_error, double *out, uint8_t *valid,
                   double *fb_err);
 
+/* ---- ba_oracle.c ------------------------------------------------------------------------- */
+
+/* utils/exe9_BA/baError.m:2-65.  observations as the reference serialises them
+ * ([F; m; per frame: n_i; n_i (row, col) pairs; n_i 1-based landmark indices]).  r_out 2 x Nobs
+ * (u residual, v residual per observation).  Returns Nobs, -1 if the vector is malformed. */
+int vo_ba_error(const double *state, const double *obs, int obs_len, const double K[9], double *r_out);
+/* utils/exe9_BA/runBA.m:2-88 with this project's Levenberg-Marquardt (see ba_oracle.c). */
+int vo_run_ba(double *state, const double *obs, int obs_len, const double K[9], int max_iter, double ftol,
+              double xtol, double *stats);
+/* utils/T_refinement.m:1-21 with the same Levenberg-Marquardt on the 6 twist coordinates. */
+void vo_pose_refine(double T[16], const double *kp_uv, const double *X, int n, const double K[9],
+                    int max_iter, double ftol, double xtol, double *stats);
+
 /* ---- harris_oracle.c ------------------------------------------------------------------- */
 
 /* This project's definition of the corner detector that stands in for detectHarrisFeatures /

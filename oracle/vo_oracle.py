@@ -254,3 +254,43 @@ def detect_corners(img_ab, min_quality=0.01, filter_size=5, border=16, method=0,
                                     C.c_int(cap))
     n = min(total, cap)
     return np.stack([ab[:n], ab[cap:cap + n]], axis=1).copy(), metric[:n].copy(), total
+
+
+# ---- bundle adjustment / pose refinement ----------------------------------------------------
+
+def ba_error(state, obs, K):
+    """baError(hidden_state, observations, K): returns 2 x Nobs."""
+    s = _f64(state).reshape(-1)
+    o = _f64(obs).reshape(-1)
+    Kc = _f64(np.asarray(K).T)
+    r = np.zeros(2 * len(o))
+    lib().vo_ba_error.restype = C.c_int
+    n = lib().vo_ba_error(_d(s), _d(o), C.c_int(len(o)), _d(Kc), _d(r))
+    if n < 0:
+        raise ValueError("malformed observation vector")
+    return r[:2 * n].reshape(n, 2).T.copy()
+
+
+def run_ba(state, obs, K, max_iter=21, ftol=1e-10, xtol=1e-10):
+    s = _f64(state).reshape(-1).copy()
+    o = _f64(obs).reshape(-1)
+    Kc = _f64(np.asarray(K).T)
+    stats = np.zeros(4)
+    lib().vo_run_ba.restype = C.c_int
+    rc = lib().vo_run_ba(_d(s), _d(o), C.c_int(len(o)), _d(Kc), C.c_int(max_iter), C.c_double(ftol), C.c_double(xtol),
+                         _d(stats))
+    if rc < 0:
+        raise ValueError("malformed observation vector")
+    return s, dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2], lam=stats[3])
+
+
+def pose_refine(T_W_C, kp_uv, X, K, max_iter=100, ftol=1e-10, xtol=1e-10):
+    """T_refinement(T_W_C, keypoints (2xN (u,v)), landmarks (3xN), K)."""
+    T = _f64(np.asarray(T_W_C).T).copy()
+    kp = _f64(np.asarray(kp_uv).T)
+    Xc = _f64(np.asarray(X).T)
+    Kc = _f64(np.asarray(K).T)
+    stats = np.zeros(3)
+    lib().vo_pose_refine(_d(T), _d(kp), _d(Xc), C.c_int(kp.shape[0]), _d(Kc), C.c_int(max_iter), C.c_double(ftol),
+                         C.c_double(xtol), _d(stats))
+    return T.reshape(4, 4).T.copy(), dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2])

@@ -119,7 +119,24 @@ def make_harris():
                         xy_mineigen=ab_me + 1.0, metric_mineigen=metric_me, R_row100=R[100], total=total)
 
 
-MAKERS = {"ransac": make_ransac, "geometry": make_geometry, "klt": make_klt, "harris": make_harris}
+def make_ba():
+    K = vo_synth.K_KITTI
+    s0, obs, st = vo_synth.ba_problem(F=5, m=300, seed=9)
+    r0 = orc.ba_error(s0, obs, K)
+    s1, info = orc.run_ba(s0, obs, K)
+    kp_rc, X, R, t, _ = vo_synth.pnp_problem(500, inlier_ratio=1.0, seed=13)
+    T_C_W = np.eye(4)
+    T_C_W[:3, :3] = R
+    T_C_W[:3, 3] = t
+    T0 = np.linalg.inv(T_C_W) @ vo_synth.pose_matrix([0.01, -0.02, 0.015], [0.1, -0.05, 0.2])
+    T1, pinfo = orc.pose_refine(T0, kp_rc[::-1], X, K)
+    np.savez_compressed(os.path.join(HERE, "ba_f5_m300.npz"), state0=s0, obs=obs, state_true=st, K=K, r0=r0,
+                        state_opt=s1, iterations=info["iterations"], cost0=info["cost0"], cost=info["cost"],
+                        pr_T0=T0, pr_kp_uv=kp_rc[::-1], pr_X=X, pr_T1=T1, pr_iterations=pinfo["iterations"],
+                        pr_cost=pinfo["cost"])
+
+
+MAKERS = {"ba": make_ba, "ransac": make_ransac, "geometry": make_geometry, "klt": make_klt, "harris": make_harris}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(MAKERS)

@@ -5,6 +5,7 @@ pipeline, behind the reference's own function names.  All arithmetic runs in lib
 from . import _lib
 from ._lib import Context, VohipError, default_context
 from . import synth
+from .ba import T_refinement, baError, runBA
 from .keypoints import cornerPoints, genKeypoints
 from .klt import PointTracker, Pyramid
 from .ransac import draw_triples, p3p, ransacLocalization

@@ -66,6 +66,14 @@ SIGNATURES = {
     "vohip_candidate_triangulate": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int,
                                                c_double_p, c_double_p, C.c_double, C.c_double, C.c_double,
                                                C.c_int, c_uint8_p, c_double_p, c_double_p]),
+    "vohip_ba_error": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p, C.c_int, c_double_p, c_double_p,
+                                  c_int_p]),
+    "vohip_ba_run": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p, C.c_int, c_double_p, C.c_int,
+                                C.c_double, C.c_double, c_double_p]),
+    "vohip_pose_refine": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, C.c_int,
+                                     C.c_double, C.c_double, c_double_p]),
+    "vohip_pose_refine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
+                                         C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "vohip_detect_corners": (C.c_int, [C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                         C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, c_int_p]),
     "vohip_detect_corners_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,

@@ -1,0 +1,60 @@
+"""Host-side mirrors of the reference's bundle-adjustment interface (same names and argument
+meaning): runBA (utils/exe9_BA/runBA.m:2), baError (utils/exe9_BA/baError.m:2) and T_refinement
+(utils/T_refinement.m:1).  The arithmetic runs in libvohip.so on the GPU; no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64, colmajor, dptr
+
+BA_MAX_ITER = 21          # the reference's budget: lsqnonlin MaxIter 1 + MaxIter 20 (runBA.m:65-78)
+POSE_MAX_ITER = 100       # T_refinement.m:4
+FTOL = 1e-10
+XTOL = 1e-10
+
+
+def baError(hidden_state, observations, K, ctx=None):
+    """error_terms = baError(hidden_state, observations, K): 2 x Nobs reprojection errors."""
+    ctx = ctx or _lib.default_context()
+    s = as_f64(np.asarray(hidden_state).reshape(-1))
+    o = as_f64(np.asarray(observations).reshape(-1))
+    r = np.zeros(max(2 * len(o), 2))
+    n = C.c_int(0)
+    ctx.check(_lib.load().vohip_ba_error(ctx.handle, dptr(s), len(s), dptr(o), len(o), dptr(colmajor(K)), dptr(r),
+                                         C.byref(n)))
+    return r[:2 * n.value].reshape(n.value, 2).T.copy()
+
+
+def runBA(hidden_state, observations, K, max_iter=BA_MAX_ITER, ftol=FTOL, xtol=XTOL, return_stats=False, ctx=None):
+    """hidden_state = runBA(hidden_state, observations, K)"""
+    ctx = ctx or _lib.default_context()
+    shape = np.asarray(hidden_state).shape
+    s = as_f64(np.asarray(hidden_state).reshape(-1)).copy()
+    o = as_f64(np.asarray(observations).reshape(-1))
+    stats = np.zeros(4)
+    ctx.check(_lib.load().vohip_ba_run(ctx.handle, dptr(s), len(s), dptr(o), len(o), dptr(colmajor(K)), int(max_iter),
+                                       float(ftol), float(xtol), dptr(stats)))
+    out = s.reshape(shape)
+    if return_stats:
+        return out, dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2], lam=stats[3])
+    return out
+
+
+def T_refinement(T_W_C, keypoints, landmarks, K, max_iter=POSE_MAX_ITER, ftol=FTOL, xtol=XTOL, return_stats=False,
+                 ctx=None):
+    """refined_T_W_C = T_refinement(T_W_C, keypoints, landmarks, K): keypoints 2xN (u, v),
+    landmarks 3xN."""
+    ctx = ctx or _lib.default_context()
+    T = colmajor(T_W_C).copy()
+    kp = colmajor(np.asarray(keypoints, dtype=np.float64).reshape(2, -1))
+    X = colmajor(np.asarray(landmarks, dtype=np.float64).reshape(3, -1))
+    if kp.shape[0] != X.shape[0]:
+        raise ValueError("keypoints and landmarks differ in count")
+    stats = np.zeros(3)
+    ctx.check(_lib.load().vohip_pose_refine(ctx.handle, dptr(T), dptr(kp), dptr(X), kp.shape[0], dptr(colmajor(K)),
+                                            int(max_iter), float(ftol), float(xtol), dptr(stats)))
+    out = T.reshape(4, 4).T.copy()
+    if return_stats:
+        return out, dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2])
+    return out

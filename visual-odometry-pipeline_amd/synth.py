@@ -130,3 +130,54 @@ def shift_image(img, dx, dy):
 
 def to_uint8(img):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def twist_of(T):
+    """[v; w] of a 4x4 rigid transform (numpy, via the closed-form log)."""
+    R, t = T[:3, :3], T[:3, 3]
+    cs = (np.trace(R) - 1.0) / 2.0
+    s = 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    sn = np.linalg.norm(s)
+    th = np.arctan2(sn, cs)
+    w = s * (th / sn) if sn > 1e-12 else s
+    Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    th2 = th * th
+    if th2 < 1e-10:
+        Vinv = np.eye(3) - 0.5 * Wx + Wx @ Wx / 12.0
+    else:
+        A, B = np.sin(th) / th, (1 - np.cos(th)) / th2
+        Vinv = np.eye(3) - 0.5 * Wx + (1 - A / (2 * B)) / th2 * Wx @ Wx
+    return np.concatenate([Vinv @ t, w])
+
+
+def ba_problem(F=5, m=300, visible=0.6, noise_px=0.5, rot_perturb=1e-2, trans_perturb=5e-2, lm_perturb=0.2,
+               seed=9, K=K_KITTI, width=KITTI_W, height=KITTI_H):
+    """A sliding-window BA problem in the reference's serialisation (VO_bundle_adjust.m:43-50):
+    returns state0 (6F+3m, perturbed), obs ([F; m; per frame n_i; (row, col) pairs; 1-based ids]),
+    state_true."""
+    rng = np.random.default_rng(seed)
+    poses = [pose_matrix(np.array([0.0, 0.01 * f, 0.0]) + rng.normal(0, 0.005, 3),
+                         np.array([0.05 * f, 0.0, 0.8 * f]) + rng.normal(0, 0.02, 3)) for f in range(F)]
+    mid = poses[F // 2]
+    u = rng.uniform(60, width - 60, m)
+    v = rng.uniform(30, height - 30, m)
+    z = rng.uniform(6, 50, m)
+    pc = np.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z, np.ones(m)])
+    X = (mid @ pc)[:3]
+    obs = [float(F), float(m)]
+    for f in range(F):
+        h = projection_matrix(K, poses[f]) @ np.vstack([X, np.ones(m)])
+        uv = h[:2] / h[2]
+        ok = (h[2] > 1) & (uv[0] > 0) & (uv[0] < width) & (uv[1] > 0) & (uv[1] < height) & (rng.random(m) < visible)
+        idx = np.flatnonzero(ok)
+        uvn = uv[:, idx] + rng.normal(0, noise_px, (2, len(idx)))
+        obs.append(float(len(idx)))
+        obs.extend(np.stack([uvn[1], uvn[0]], axis=1).reshape(-1))  # (row, col) interleaved
+        obs.extend((idx + 1).astype(np.float64))
+    state_true = np.concatenate([np.concatenate([twist_of(T) for T in poses]), X.T.reshape(-1)])
+    state0 = state_true.copy()
+    for f in range(F):
+        Tp = poses[f] @ pose_matrix(rng.normal(0, rot_perturb, 3), rng.normal(0, trans_perturb, 3))
+        state0[6 * f:6 * f + 6] = twist_of(Tp)
+    state0[6 * F:] += rng.normal(0, lm_perturb, 3 * m)
+    return state0, np.array(obs), state_true
