@@ -208,6 +208,25 @@ int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const doubl
                         int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
                         uint8_t *d_valid, double *d_fb_err);
 
+/* ---- fundamental-matrix RANSAC -----------------------------------------------------------
+ * Stands in for [F, inliersIndex] = estimateFundamentalMatrix(p1, p2, 'NumTrials', 500, 'Method',
+ * 'RANSAC', 'DistanceThreshold', 5e-2) at update_landmarks.m:13-14 (Confidence 99, Sampson
+ * distance).  p1, p2 2xn (one column per point, any consistent axis order); samples
+ * 8 x num_trials 0-based index sets drawn by the caller (the toolbox draws them from MATLAB's
+ * global RNG); mask n bytes; best_count the inlier count of the winning trial; trials_run (may
+ * be NULL) the trials the adaptive budget consumed; F_best (may be NULL) the winning matrix,
+ * row-major 3x3, for points in the axis order given.  Needs n >= 8 (VOHIP_TOO_FEW_POINTS; the
+ * toolbox raises an error there too).
+ */
+int vohip_fmatrix_ransac(vohip_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *samples,
+                         int num_trials, double threshold, uint8_t *mask, int *best_count, int *trials_run,
+                         double *F_best);
+/* d_p1, d_p2, d_samples, d_mask on the device; best_count, trials_run, F_best on the host.
+ * Synchronises (the trial budget is replayed on the host). */
+int vohip_fmatrix_ransac_dev(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n,
+                             const int32_t *d_samples, int num_trials, double threshold, uint8_t *d_mask,
+                             int *best_count, int *trials_run, double *F_best);
+
 /* ---- bundle adjustment and pose refinement ------------------------------------------------
  * hidden_state = [twists of T_W_C (6 x F, [v; w]); landmarks (3 x m)], observations =
  * [F; m; per frame: n_i; n_i (row, col) pairs; n_i 1-based landmark indices] -- exactly the

@@ -114,6 +114,17 @@ int vo_run_ba(double *state, const double *obs, int obs_len, const double K[9], 
 void vo_pose_refine(double T[16], const double *kp_uv, const double *X, int n, const double K[9],
                     int max_iter, double ftol, double xtol, double *stats);
 
+/* ---- fmatrix_oracle.c --------------------------------------------------------------------- */
+
+/* This project's definition of the fundamental-matrix RANSAC that stands in for
+ * estimateFundamentalMatrix(..., 'NumTrials', 500, 'Method', 'RANSAC', 'DistanceThreshold', 5e-2)
+ * at update_landmarks.m:13-14; see the header of fmatrix_oracle.c. */
+int vo_fmatrix_8point(const double *p1, const double *p2, const int32_t idx[8], const double nrm[6], double F[9]);
+int vo_fmatrix_count(const double *p1, const double *p2, int n, const double F[9], double thr, uint8_t *mask);
+double vo_fmatrix_trial_budget(int inliers, int n, int num_trials);
+int vo_fmatrix_ransac(const double *p1, const double *p2, int n, const int32_t *samples, int num_trials,
+                      double thr, uint8_t *mask, int *best_count, double Fbest[9], int32_t *counts);
+
 /* ---- harris_oracle.c ------------------------------------------------------------------- */
 
 /* This project's definition of the corner detector that stands in for detectHarrisFeatures /

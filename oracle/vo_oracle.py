@@ -294,3 +294,21 @@ def pose_refine(T_W_C, kp_uv, X, K, max_iter=100, ftol=1e-10, xtol=1e-10):
     lib().vo_pose_refine(_d(T), _d(kp), _d(Xc), C.c_int(kp.shape[0]), _d(Kc), C.c_int(max_iter), C.c_double(ftol),
                          C.c_double(xtol), _d(stats))
     return T.reshape(4, 4).T.copy(), dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2])
+
+
+# ---- fundamental-matrix RANSAC ---------------------------------------------------------------
+
+def fmatrix_ransac(p1, p2, samples, threshold=5e-2):
+    """p1, p2: 2xn; samples (T, 8) 0-based.  Returns dict(mask, best_count, trials, F, counts)."""
+    a = _f64(np.asarray(p1).T)
+    b = _f64(np.asarray(p2).T)
+    s = np.ascontiguousarray(samples, dtype=np.int32)
+    n, T = a.shape[0], s.shape[0]
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    best = C.c_int(0)
+    F = np.zeros(9)
+    counts = np.zeros(max(T, 1), dtype=np.int32)
+    lib().vo_fmatrix_ransac.restype = C.c_int
+    trials = lib().vo_fmatrix_ransac(_d(a), _d(b), C.c_int(n), s.ctypes.data_as(_ip), C.c_int(T), C.c_double(threshold),
+                                     mask.ctypes.data_as(_bp), C.byref(best), _d(F), counts.ctypes.data_as(_ip))
+    return dict(mask=mask[:n].astype(bool), best_count=best.value, trials=trials, F=F.reshape(3, 3), counts=counts[:trials])

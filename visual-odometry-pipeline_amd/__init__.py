@@ -6,6 +6,7 @@ from . import _lib
 from ._lib import Context, VohipError, default_context
 from . import synth
 from .ba import T_refinement, baError, runBA
+from .fmatrix import draw_octets, estimateFundamentalMatrix
 from .keypoints import cornerPoints, genKeypoints
 from .klt import PointTracker, Pyramid
 from .ransac import draw_triples, p3p, ransacLocalization

@@ -1,0 +1,343 @@
+// Fundamental-matrix RANSAC for gfx950 (fp64).
+//
+// Stands in for estimateFundamentalMatrix(p1, p2, 'NumTrials', 500, 'Method', 'RANSAC',
+// 'DistanceThreshold', 5e-2) at update_landmarks.m:13-14, of which the reference only uses the
+// inlier index.  The toolbox function is closed source; the estimator is defined as:
+//   Hartley normalisation of all points (once); per trial 8 pairs (index sets supplied by the
+//   caller, who owns the RNG) -> null vector of the 8x9 system by Gaussian elimination with
+//   complete pivoting -> rank 2 by zeroing the smallest singular value (one-sided Jacobi) ->
+//   de-normalise; inlier <=> Sampson distance (pixels^2) <= threshold; winner = first trial with
+//   the largest count; trial budget shrinks to ceil(log(0.01)/log(1-(inl/n)^8)) after each
+//   improvement (Confidence 99).
+// Kernels: fm_normalise_kernel (one workgroup, two block reductions), fm_solve_kernel (one
+// thread per trial), fm_count_kernel (one wavefront per trial, ballot/popcount), fm_mask_kernel.
+#include "vohip_internal.h"
+
+#include <cmath>
+
+namespace {
+
+__device__ __forceinline__ double wsum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// nrm[6] = {s1, cx1, cy1, s2, cx2, cy2}.  Sums run in a fixed order (per-thread strided partial
+// sums, wave butterfly, then waves in order), so the result is reproducible.
+__global__ __launch_bounds__(256) void fm_normalise_kernel(const double *__restrict__ p1,
+                                                           const double *__restrict__ p2, int n,
+                                                           double *__restrict__ nrm)
+{
+    __shared__ double sW[4][4];
+    __shared__ double sMean[4];
+    const int tid = threadIdx.x;
+    double s[4] = {0, 0, 0, 0};
+    for (int i = tid; i < n; i += 256) {
+        s[0] += p1[2 * i];
+        s[1] += p1[2 * i + 1];
+        s[2] += p2[2 * i];
+        s[3] += p2[2 * i + 1];
+    }
+    for (int q = 0; q < 4; ++q) {
+        const double t = wsum(s[q]);
+        if ((tid & 63) == 0) sW[tid >> 6][q] = t;
+    }
+    __syncthreads();
+    if (tid < 4) sMean[tid] = (sW[0][tid] + sW[1][tid] + sW[2][tid] + sW[3][tid]) / (double)n;
+    __syncthreads();
+    double d[2] = {0, 0};
+    for (int i = tid; i < n; i += 256) {
+        const double ax = p1[2 * i] - sMean[0], ay = p1[2 * i + 1] - sMean[1];
+        const double bx = p2[2 * i] - sMean[2], by = p2[2 * i + 1] - sMean[3];
+        d[0] += sqrt(ax * ax + ay * ay);
+        d[1] += sqrt(bx * bx + by * by);
+    }
+    __syncthreads();
+    for (int q = 0; q < 2; ++q) {
+        const double t = wsum(d[q]);
+        if ((tid & 63) == 0) sW[tid >> 6][q] = t;
+    }
+    __syncthreads();
+    if (tid < 2) {
+        const double md = (sW[0][tid] + sW[1][tid] + sW[2][tid] + sW[3][tid]) / (double)n;
+        nrm[3 * tid] = md > 0.0 ? sqrt(2.0) / md : 1.0;
+        nrm[3 * tid + 1] = sMean[2 * tid];
+        nrm[3 * tid + 2] = sMean[2 * tid + 1];
+    }
+}
+
+__device__ bool null9(double A[8][9], double x[9])
+{
+    int perm[9];
+    for (int c = 0; c < 9; ++c) perm[c] = c;
+    for (int k = 0; k < 8; ++k) {
+        int pr = k, pc = k;
+        double best = 0.0;
+        for (int r = k; r < 8; ++r)
+            for (int c = k; c < 9; ++c)
+                if (fabs(A[r][c]) > best) {
+                    best = fabs(A[r][c]);
+                    pr = r;
+                    pc = c;
+                }
+        if (!(best > 0.0)) return false;
+        if (pr != k)
+            for (int c = 0; c < 9; ++c) {
+                const double t = A[k][c];
+                A[k][c] = A[pr][c];
+                A[pr][c] = t;
+            }
+        if (pc != k) {
+            for (int r = 0; r < 8; ++r) {
+                const double t = A[r][k];
+                A[r][k] = A[r][pc];
+                A[r][pc] = t;
+            }
+            const int t = perm[k];
+            perm[k] = perm[pc];
+            perm[pc] = t;
+        }
+        for (int r = k + 1; r < 8; ++r) {
+            const double f = A[r][k] / A[k][k];
+            for (int c = k; c < 9; ++c) A[r][c] -= f * A[k][c];
+        }
+    }
+    double y[9];
+    y[8] = 1.0;
+    for (int k = 7; k >= 0; --k) {
+        double s = 0.0;
+        for (int c = k + 1; c < 9; ++c) s += A[k][c] * y[c];
+        y[k] = -s / A[k][k];
+    }
+    double nn = 0.0;
+    for (int c = 0; c < 9; ++c) nn += y[c] * y[c];
+    nn = sqrt(nn);
+    for (int c = 0; c < 9; ++c) x[perm[c]] = y[c] / nn;
+    return true;
+}
+
+__device__ void rank2(double F[3][3])
+{
+    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) A[r][c] = F[r][c];
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = i + 1; j < 3; ++j) {
+                double al = 0, be = 0, ga = 0;
+                for (int r = 0; r < 3; ++r) {
+                    al += A[r][i] * A[r][i];
+                    be += A[r][j] * A[r][j];
+                    ga += A[r][i] * A[r][j];
+                }
+                if (ga == 0.0 || fabs(ga) <= 1e-15 * sqrt(al * be)) continue;
+                rotated = true;
+                const double zeta = (be - al) / (2.0 * ga);
+                const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int r = 0; r < 3; ++r) {
+                    const double ai = A[r][i], aj = A[r][j];
+                    A[r][i] = c * ai - s * aj;
+                    A[r][j] = s * ai + c * aj;
+                    const double vi = V[r][i], vj = V[r][j];
+                    V[r][i] = c * vi - s * vj;
+                    V[r][j] = s * vi + c * vj;
+                }
+            }
+        if (!rotated) break;
+    }
+    double nn[3];
+    for (int c = 0; c < 3; ++c) nn[c] = A[0][c] * A[0][c] + A[1][c] * A[1][c] + A[2][c] * A[2][c];
+    const int k = (nn[0] <= nn[1] && nn[0] <= nn[2]) ? 0 : (nn[1] <= nn[2] ? 1 : 2);
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+            double s = 0.0;
+            for (int q = 0; q < 3; ++q)
+                if (q != k) s += A[r][q] * V[c][q];
+            F[r][c] = s;
+        }
+}
+
+// One thread per trial; F_out[t] row-major 3x3 (all zeros for a degenerate sample).
+__global__ __launch_bounds__(64) void fm_solve_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                      int n, const int32_t *__restrict__ samples, int trials,
+                                                      const double *__restrict__ nrm, double *__restrict__ F_out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= trials) return;
+    const double s1 = nrm[0], cx1 = nrm[1], cy1 = nrm[2], s2 = nrm[3], cx2 = nrm[4], cy2 = nrm[5];
+    double A[8][9];
+    bool ok = true;
+    for (int r = 0; r < 8; ++r) {
+        int i = samples[8 * (size_t)t + r];
+        if (i < 0 || i >= n) {
+            ok = false;
+            i = 0;
+        }
+        const double x1 = s1 * (p1[2 * i] - cx1), y1 = s1 * (p1[2 * i + 1] - cy1);
+        const double x2 = s2 * (p2[2 * i] - cx2), y2 = s2 * (p2[2 * i + 1] - cy2);
+        A[r][0] = x2 * x1;
+        A[r][1] = x2 * y1;
+        A[r][2] = x2;
+        A[r][3] = y2 * x1;
+        A[r][4] = y2 * y1;
+        A[r][5] = y2;
+        A[r][6] = x1;
+        A[r][7] = y1;
+        A[r][8] = 1.0;
+    }
+    double f[9];
+    ok = ok && null9(A, f);
+    double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) {
+        double Fh[3][3] = {{f[0], f[1], f[2]}, {f[3], f[4], f[5]}, {f[6], f[7], f[8]}};
+        rank2(Fh);
+        const double T1[3][3] = {{s1, 0, -s1 * cx1}, {0, s1, -s1 * cy1}, {0, 0, 1}};
+        const double T2[3][3] = {{s2, 0, -s2 * cx2}, {0, s2, -s2 * cy2}, {0, 0, 1}};
+        double M[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) M[r][c] = Fh[r][0] * T1[0][c] + Fh[r][1] * T1[1][c] + Fh[r][2] * T1[2][c];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) F[3 * r + c] = T2[0][r] * M[0][c] + T2[1][r] * M[1][c] + T2[2][r] * M[2][c];
+    }
+    for (int q = 0; q < 9; ++q) F_out[9 * (size_t)t + q] = F[q];
+}
+
+__device__ __forceinline__ bool sampson_inlier(const double F[9], double x1, double y1, double x2, double y2,
+                                               double thr)
+{
+    const double a0 = F[0] * x1 + F[1] * y1 + F[2], a1 = F[3] * x1 + F[4] * y1 + F[5],
+                 a2 = F[6] * x1 + F[7] * y1 + F[8];
+    const double b0 = F[0] * x2 + F[3] * y2 + F[6], b1 = F[1] * x2 + F[4] * y2 + F[7];
+    const double e = x2 * a0 + y2 * a1 + a2;
+    const double d = e * e / (a0 * a0 + a1 * a1 + b0 * b0 + b1 * b1);
+    return d <= thr;
+}
+
+// One wavefront per trial, 4 trials per workgroup.
+__global__ __launch_bounds__(256) void fm_count_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                       int n, const double *__restrict__ Fs, int trials, double thr,
+                                                       int32_t *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (t >= trials) return;
+    double F[9];
+    bool zero = true;
+    for (int q = 0; q < 9; ++q) {
+        F[q] = Fs[9 * (size_t)t + q];
+        zero = zero && F[q] == 0.0;
+    }
+    int c = 0;
+    if (!zero)
+        for (int i = lane; i < n; i += 64)
+            c += __popcll(__ballot(sampson_inlier(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1], thr)));
+    if (lane == 0) counts[t] = c;
+}
+
+__global__ __launch_bounds__(256) void fm_mask_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
+                                                      int n, const double *__restrict__ F9, double thr,
+                                                      uint8_t *__restrict__ mask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double F[9];
+    for (int q = 0; q < 9; ++q) F[q] = F9[q];
+    mask[i] = sampson_inlier(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1], thr) ? 1 : 0;
+}
+
+double trial_budget(int inliers, int n, int num_trials)
+{
+    const double r = (double)inliers / (double)n;
+    const double r8 = std::pow(r, 8.0);
+    if (r8 >= 1.0) return 1.0;
+    if (r8 <= 0.0) return (double)num_trials;
+    const double t = std::ceil(std::log(1.0 - 0.99) / std::log(1.0 - r8));
+    return t < (double)num_trials ? t : (double)num_trials;
+}
+
+}  // namespace
+
+extern "C" {
+
+// d_p1, d_p2: 2 x n; d_samples 8 x num_trials; d_mask n bytes (device).  Synchronises once to
+// replay the trial budget on the host.  best_count / trials_run are host outputs.
+int vohip_fmatrix_ransac_dev(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n,
+                             const int32_t *d_samples, int num_trials, double threshold, uint8_t *d_mask,
+                             int *best_count, int *trials_run, double *F_best)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, d_p1 && d_p2 && d_samples && d_mask && best_count, "NULL argument");
+    VOHIP_REQUIRE(ctx, num_trials >= 1, "need at least one trial");
+    *best_count = 0;
+    if (trials_run) *trials_run = 0;
+    if (n < 8) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "the 8-point algorithm needs 8 pairs, got %d", n);
+    void *d_nrm, *d_F, *d_counts, *h_counts;
+    VOHIP_TRY(vohip_upload(ctx, B_FM_NRM, nullptr, 64, &d_nrm));
+    VOHIP_TRY(vohip_upload(ctx, B_FM_F, nullptr, sizeof(double) * 9 * (size_t)num_trials, &d_F));
+    VOHIP_TRY(vohip_upload(ctx, B_FM_COUNTS, nullptr, sizeof(int32_t) * (size_t)num_trials, &d_counts));
+    VOHIP_TRY(vohip_reserve_pinned(ctx, ctx->bufs[H_FM_COUNTS], sizeof(int32_t) * (size_t)num_trials));
+    h_counts = ctx->bufs[H_FM_COUNTS].ptr;
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(fm_normalise_kernel, dim3(1), dim3(256), 0, s, d_p1, d_p2, n, (double *)d_nrm);
+    hipLaunchKernelGGL(fm_solve_kernel, dim3((num_trials + 63) / 64), dim3(64), 0, s, d_p1, d_p2, n, d_samples,
+                       num_trials, (const double *)d_nrm, (double *)d_F);
+    hipLaunchKernelGGL(fm_count_kernel, dim3((num_trials + 3) / 4), dim3(256), 0, s, d_p1, d_p2, n, (const double *)d_F,
+                       num_trials, threshold, (int32_t *)d_counts);
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_TRY(vohip_download(ctx, h_counts, d_counts, sizeof(int32_t) * (size_t)num_trials));
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    const int32_t *c = (const int32_t *)h_counts;
+    double budget = (double)num_trials;
+    int t = 0, best = 0, best_t = -1;
+    while ((double)t < budget && t < num_trials) {
+        if (c[t] > best) {
+            best = c[t];
+            best_t = t;
+            budget = trial_budget(best, n, num_trials);
+        }
+        ++t;
+    }
+    *best_count = best;
+    if (trials_run) *trials_run = t;
+    if (best_t < 0) {
+        VOHIP_HIP(ctx, hipMemsetAsync(d_mask, 0, (size_t)n, s));
+        return vohip_fail(ctx, VOHIP_NO_MODEL, "no trial produced an inlier");
+    }
+    hipLaunchKernelGGL(fm_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, n,
+                       (const double *)d_F + 9 * (size_t)best_t, threshold, d_mask);
+    VOHIP_HIP(ctx, hipGetLastError());
+    if (F_best) {
+        VOHIP_TRY(vohip_download(ctx, F_best, (const double *)d_F + 9 * (size_t)best_t, sizeof(double) * 9));
+        VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    }
+    return VOHIP_OK;
+}
+
+int vohip_fmatrix_ransac(vohip_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *samples,
+                         int num_trials, double threshold, uint8_t *mask, int *best_count, int *trials_run,
+                         double *F_best)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, p1 && p2 && samples && mask && best_count, "NULL argument");
+    if (n < 8) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "the 8-point algorithm needs 8 pairs, got %d", n);
+    VOHIP_REQUIRE(ctx, num_trials >= 1, "need at least one trial");
+    void *d_p1, *d_p2, *d_s, *d_mask;
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE0, p1, sizeof(double) * 2 * n, &d_p1));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE1, p2, sizeof(double) * 2 * n, &d_p2));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE2, samples, sizeof(int32_t) * 8 * (size_t)num_trials, &d_s));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE3, nullptr, (size_t)n, &d_mask));
+    const int st = vohip_fmatrix_ransac_dev(ctx, (const double *)d_p1, (const double *)d_p2, n, (const int32_t *)d_s,
+                                            num_trials, threshold, (uint8_t *)d_mask, best_count, trials_run, F_best);
+    if (st != VOHIP_OK && st != VOHIP_NO_MODEL) return st;
+    VOHIP_TRY(vohip_download(ctx, mask, d_mask, (size_t)n));
+    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+"""Host-side mirror of estimateFundamentalMatrix as update_landmarks.m:13-14 calls it
+('Method','RANSAC'); the arithmetic runs in libvohip.so on the GPU, no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import VOHIP_NO_MODEL, dptr
+
+
+def draw_octets(rng, n, count):
+    """`count` sets of 8 distinct indices in [0, n): the stand-in for the toolbox's internal
+    sampling.  Rows with a repeated index are redrawn (whole row) until all are distinct."""
+    if n < 8:
+        raise ValueError("need at least 8 points")
+    out = np.minimum((rng.random((count, 8)) * n).astype(np.int64), n - 1)
+    while True:
+        srt = np.sort(out, axis=1)
+        bad = np.flatnonzero((np.diff(srt, axis=1) == 0).any(axis=1))
+        if bad.size == 0:
+            return out.astype(np.int32)
+        out[bad] = np.minimum((rng.random((bad.size, 8)) * n).astype(np.int64), n - 1)
+
+
+def estimateFundamentalMatrix(matchedPoints1, matchedPoints2, NumTrials=500, DistanceThreshold=0.01,
+                              Method="RANSAC", samples=None, rng=None, ctx=None):
+    """[F, inliersIndex] = estimateFundamentalMatrix(matchedPoints1, matchedPoints2, 'Method',
+    'RANSAC', 'NumTrials', T, 'DistanceThreshold', d).  Points are N-by-2.  `samples` (T x 8,
+    0-based) fixes the trials; otherwise they are drawn from `rng` (numpy Generator)."""
+    if Method != "RANSAC":
+        raise NotImplementedError("only Method = 'RANSAC' is built (the one the pipeline uses)")
+    ctx = ctx or _lib.default_context()
+    p1 = np.ascontiguousarray(np.asarray(matchedPoints1, dtype=np.float64).reshape(-1, 2))
+    p2 = np.ascontiguousarray(np.asarray(matchedPoints2, dtype=np.float64).reshape(-1, 2))
+    n = p1.shape[0]
+    if p2.shape[0] != n:
+        raise ValueError("point sets differ in count")
+    if samples is None:
+        samples = draw_octets(rng or np.random.default_rng(), n, int(NumTrials)) if n >= 8 else np.zeros((1, 8))
+    s = np.ascontiguousarray(samples, dtype=np.int32)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    best, trials = C.c_int(0), C.c_int(0)
+    F = np.zeros(9)
+    st = _lib.load().vohip_fmatrix_ransac(ctx.handle, dptr(p1), dptr(p2), n, s.ctypes.data_as(_lib.c_int32_p),
+                                          s.shape[0], float(DistanceThreshold), mask.ctypes.data_as(_lib.c_uint8_p),
+                                          C.byref(best), C.byref(trials), dptr(F))
+    ctx.check(st, allow=(VOHIP_NO_MODEL,))
+    return F.reshape(3, 3), mask[:n].astype(bool)

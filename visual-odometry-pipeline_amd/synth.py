@@ -181,3 +181,15 @@ def ba_problem(F=5, m=300, visible=0.6, noise_px=0.5, rot_perturb=1e-2, trans_pe
         state0[6 * f:6 * f + 6] = twist_of(Tp)
     state0[6 * F:] += rng.normal(0, lm_perturb, 3 * m)
     return state0, np.array(obs), state_true
+
+
+def two_view_matches(n, outlier_ratio=0.2, noise_px=0.2, seed=0, K=K_KITTI):
+    """Matched (row, col) points of a static scene seen from two poses, with gross outliers:
+    returns p1, p2 (n, 2) and the boolean inlier labels."""
+    rng = np.random.default_rng(seed)
+    p1h, p2h, _, _, _ = two_view_problem(n, noise_px=noise_px, seed=seed + 1000, K=K, baseline=1.0)
+    p1 = p1h[:2].T[:, ::-1].copy()
+    p2 = p2h[:2].T[:, ::-1].copy()
+    out = rng.random(n) < outlier_ratio
+    p2[out] += rng.uniform(-60, 60, (out.sum(), 2))
+    return p1, p2, ~out
