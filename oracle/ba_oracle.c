@@ -316,7 +316,10 @@ int vo_run_ba(double *state, const double *obs, int obs_len, const double K[9], 
             memcpy(Em + 9 * j, E, sizeof(E));
         }
         if (solvable) {
-            /* observations are grouped by frame; walk all pairs of observations of each landmark */
+            /* walk all pairs of observations of each landmark through the (landmark, frame) table */
+            int *index = (int *)malloc(sizeof(int) * (size_t)(m > 0 ? m : 1) * F);
+            for (int q = 0; q < m * F; ++q) index[q] = -1;
+            for (int k = 0; k < o.nobs; ++k) index[o.ol[k] * F + o.of[k]] = k;
             for (int k1 = 0; k1 < o.nobs; ++k1) {
                 int j = o.ol[k1], f1 = o.of[k1];
                 if (cnt[j] < 2) continue;
@@ -327,15 +330,16 @@ int vo_run_ba(double *state, const double *obs, int obs_len, const double K[9], 
                         Y[a][c] = Wb[18 * k1 + 3 * a] * E[c] + Wb[18 * k1 + 3 * a + 1] * E[3 + c] + Wb[18 * k1 + 3 * a + 2] * E[6 + c];
                 for (int a = 0; a < 6; ++a)
                     g[6 * f1 + a] -= Y[a][0] * gl[3 * j] + Y[a][1] * gl[3 * j + 1] + Y[a][2] * gl[3 * j + 2];
-                for (int k2 = 0; k2 < o.nobs; ++k2) {
-                    if (o.ol[k2] != j) continue;
-                    int f2 = o.of[k2];
+                for (int f2 = 0; f2 < F; ++f2) {
+                    int k2 = index[j * F + f2];
+                    if (k2 < 0) continue;
                     for (int a = 0; a < 6; ++a)
                         for (int b = 0; b < 6; ++b)
                             S[(6 * f1 + a) * np + 6 * f2 + b] -=
                                 Y[a][0] * Wb[18 * k2 + 3 * b] + Y[a][1] * Wb[18 * k2 + 3 * b + 1] + Y[a][2] * Wb[18 * k2 + 3 * b + 2];
                 }
             }
+            free(index);
             for (int i = 0; i < np; ++i) delta[i] = -g[i];
             solvable = chol_solve(S, delta, np);
         }

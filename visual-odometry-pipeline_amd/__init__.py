@@ -9,6 +9,8 @@ from .ba import T_refinement, baError, runBA
 from .fmatrix import draw_octets, estimateFundamentalMatrix
 from .keypoints import cornerPoints, genKeypoints
 from .klt import PointTracker, Pyramid
+from .pipeline import (VO_bundle_adjust, VOPipeline, default_hyper_paras, init_state, update_candidate,
+                       update_landmarks)
 from .ransac import draw_triples, p3p, ransacLocalization
 from .geometry import (Cross2Matrix, HomogMatrix2twist, Matrix2Cross, candidate_filter, candidate_triangulate,
                        linearTriangulation, linearTriangulation_refinement, twist2HomogMatrix)

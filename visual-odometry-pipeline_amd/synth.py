@@ -193,3 +193,91 @@ def two_view_matches(n, outlier_ratio=0.2, noise_px=0.2, seed=0, K=K_KITTI):
     out = rng.random(n) < outlier_ratio
     p2[out] += rng.uniform(-60, 60, (out.sum(), 2))
     return p1, p2, ~out
+
+
+class CorridorScene:
+    """A piecewise-planar street canyon with procedural texture, ray-cast exactly: floor, two side
+    walls, a ceiling far above and an end wall.  Camera convention: x right, y down, z forward
+    (KITTI).  Gives frames of any size for a pose T_W_C and exact 3-D points for pixels, so
+    synthetic sequences have known structure and motion (the reference's datasets are absent)."""
+
+    def __init__(self, seed=5678, K=K_KITTI, width=KITTI_W, height=KITTI_H, length=400.0, half_width=7.0,
+                 cam_height=1.65, roof=9.0, tile=1024, px_per_m=24.0):
+        self.K, self.width, self.height = np.asarray(K, dtype=np.float64), width, height
+        # planes as (normal n, offset d) with n.X = d; order: floor, left, right, roof, end
+        self.planes = [(np.array([0.0, 1.0, 0.0]), cam_height), (np.array([1.0, 0.0, 0.0]), -half_width),
+                       (np.array([1.0, 0.0, 0.0]), half_width), (np.array([0.0, 1.0, 0.0]), -roof),
+                       (np.array([0.0, 0.0, 1.0]), length)]
+        # in-plane axes used for the texture coordinates of each plane
+        self.axes = [(0, 2), (2, 1), (2, 1), (0, 2), (0, 1)]
+        self.tex = [textured_image(tile, tile, seed=seed + i, sigma=1.2, octaves=6) for i in range(5)]
+        self.tile, self.ppm = tile, px_per_m
+        v, u = np.mgrid[0:height, 0:width].astype(np.float64)
+        self.rays_c = np.stack([(u - self.K[0, 2]) / self.K[0, 0], (v - self.K[1, 2]) / self.K[1, 1], np.ones_like(u)])
+
+    def _cast(self, T_W_C, rays_c):
+        R, t = T_W_C[:3, :3], T_W_C[:3, 3]
+        d = np.tensordot(R, rays_c, axes=(1, 0))
+        best = np.full(d.shape[1:], np.inf)
+        which = np.zeros(d.shape[1:], dtype=np.int64)
+        for i, (n, off) in enumerate(self.planes):
+            den = np.tensordot(n, d, axes=(0, 0))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                s = (off - n @ t) / den
+            ok = (s > 1e-6) & (s < best)
+            best = np.where(ok, s, best)
+            which = np.where(ok, i, which)
+        X = t.reshape(3, *([1] * (d.ndim - 1))) + d * best
+        return X, which, best
+
+    def render(self, T_W_C):
+        """uint8 (height, width) view from T_W_C."""
+        X, which, _ = self._cast(np.asarray(T_W_C, dtype=np.float64), self.rays_c)
+        img = np.zeros(which.shape)
+        for i, (a, b) in enumerate(self.axes):
+            m = which == i
+            if not m.any():
+                continue
+            tu = (X[a][m] * self.ppm) % self.tile
+            tv = (X[b][m] * self.ppm) % self.tile
+            iu, iv = np.floor(tu).astype(int), np.floor(tv).astype(int)
+            fu, fv = tu - iu, tv - iv
+            iu1, iv1 = (iu + 1) % self.tile, (iv + 1) % self.tile
+            T = self.tex[i]
+            img[m] = ((1 - fv) * ((1 - fu) * T[iv, iu] + fu * T[iv, iu1]) + fv * ((1 - fu) * T[iv1, iu] + fu * T[iv1, iu1]))
+        return to_uint8(img)
+
+    def backproject(self, T_W_C, xy):
+        """World points (n, 3) seen at the 1-based pixel positions xy (n, 2) from T_W_C."""
+        xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+        rays = np.stack([(xy[:, 0] - 1.0 - self.K[0, 2]) / self.K[0, 0], (xy[:, 1] - 1.0 - self.K[1, 2]) / self.K[1, 1],
+                         np.ones(len(xy))])
+        X, _, _ = self._cast(np.asarray(T_W_C, dtype=np.float64), rays)
+        return X.T.copy()
+
+
+def corridor_trajectory(n_frames, step=1.0, yaw_deg=0.5, period=100.0):
+    """T_W_C per frame: `step` metres forward per frame with a sinusoidal yaw of +-yaw_deg."""
+    poses = []
+    for i in range(n_frames):
+        yaw = np.deg2rad(yaw_deg) * np.sin(2 * np.pi * i / period)
+        poses.append(pose_matrix(np.array([0.0, yaw, 0.0]), np.array([0.15 * np.sin(2 * np.pi * i / period), 0.0, step * i])))
+    return poses
+
+
+def corridor_sequence(n_frames, seed=5678, step=1.0, width=KITTI_W, height=KITTI_H, cache_dir=None):
+    """Frames (list of uint8 arrays) and ground-truth poses of a corridor drive; rendered once and
+    cached as .npy when cache_dir is given."""
+    import os
+    poses = corridor_trajectory(n_frames, step=step)
+    path = None
+    if cache_dir:
+        os.makedirs(cache_dir, exist_ok=True)
+        path = os.path.join(cache_dir, "corridor_%d_%d_%dx%d_%g.npy" % (seed, n_frames, width, height, step))
+        if os.path.exists(path):
+            return list(np.load(path)), poses
+    scene = CorridorScene(seed=seed, width=width, height=height)
+    frames = [scene.render(T) for T in poses]
+    if path:
+        np.save(path, np.stack(frames))
+    return frames, poses
