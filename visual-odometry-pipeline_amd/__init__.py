@@ -4,7 +4,7 @@ pipeline, behind the reference's own function names.  All arithmetic runs in lib
 """
 from . import _lib
 from ._lib import Context, VohipError, default_context
-from . import synth
+from . import batch, synth
 from .ba import T_refinement, baError, runBA
 from .fmatrix import draw_octets, estimateFundamentalMatrix
 from .keypoints import cornerPoints, genKeypoints

@@ -1,0 +1,82 @@
+"""Batch evaluation over independent runs, the only part of the reference that shards across
+GPUs: main_eval.m:22-23 loops `feats x repetition` full pipeline runs, each rebuilt from scratch
+(main_eval.m:26-284) and saved on its own (main_eval.m:491-494).
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X, "gloo" on
+CPU).  Work items are dealt round-robin; there is no data-path collective.  The only exchange
+is one all_gather of fixed-size result records at the end -- trajectory and per-frame counters,
+the arrays the evaluation notebook reads from the saved runs.
+"""
+import numpy as np
+
+T_MAX = 600           # frames a record can hold (the reference's longest run has 598)
+RECORD_DOUBLES = 4 + 15 * T_MAX   # [item id, frames, seconds, fps] + est_trans 3xT + est_rot 9xT + num_X, num_C, num_new
+
+
+def shard(items, rank, world):
+    """Round-robin assignment of work items to ranks (static, so results do not depend on timing)."""
+    return [it for k, it in enumerate(items) if k % world == rank]
+
+
+def pack_record(item_id, seconds, est_trans, est_rot, num_X, num_C, num_new):
+    """One run -> a fixed-size float64 record."""
+    T = est_trans.shape[1]
+    if T > T_MAX:
+        raise ValueError("run has %d frames, records hold %d" % (T, T_MAX))
+    rec = np.zeros(RECORD_DOUBLES)
+    rec[0], rec[1], rec[2] = item_id, T, seconds
+    rec[3] = (T - 1) / seconds if seconds > 0 else 0.0
+    body = rec[4:].reshape(15, T_MAX)
+    body[0:3, :T] = est_trans
+    body[3:12, :T] = est_rot
+    for row, arr in ((12, num_X), (13, num_C), (14, num_new)):
+        a = np.asarray(arr, dtype=np.float64)[:T]
+        body[row, :len(a)] = a
+    return rec
+
+
+def unpack_record(rec):
+    T = int(rec[1])
+    body = rec[4:].reshape(15, T_MAX)
+    return dict(item=int(rec[0]), frames=T, seconds=float(rec[2]), fps=float(rec[3]), est_trans=body[0:3, :T].copy(),
+                est_rot=body[3:12, :T].copy(), num_X=body[12, :T].copy(), num_C=body[13, :T].copy(),
+                num_new=body[14, :T].copy())
+
+
+def gather_records(local_records, n_items, device=None):
+    """All ranks receive every record (list indexed by item id).  Ranks hold different numbers of
+    items, so each contributes ceil(n_items / world) slots, unused ones marked with id -1."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        out = [None] * n_items
+        for r in local_records:
+            out[int(r[0])] = unpack_record(r)
+        return out
+    world = dist.get_world_size()
+    slots = (n_items + world - 1) // world
+    buf = np.zeros((slots, RECORD_DOUBLES))
+    buf[:, 0] = -1.0
+    for k, r in enumerate(local_records):
+        buf[k] = r
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    out = [None] * n_items
+    for p in parts:
+        for r in p.cpu().numpy():
+            if r[0] >= 0:
+                out[int(r[0])] = unpack_record(r)
+    return out
+
+
+def run_batch(items, runner, device=None):
+    """Runs `runner(item_id, item) -> record` for this rank's share of `items` and gathers all
+    records on every rank.  `runner` builds and drives one full pipeline run."""
+    import torch.distributed as dist
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    mine = shard(list(enumerate(items)), rank, world)
+    local = [runner(item_id, item) for item_id, item in mine]
+    return gather_records(local, len(items), device=device)

@@ -13,9 +13,10 @@
 //                           in LDS, separable Gaussian through LDS, response to global memory,
 //                           tile maximum -> one atomicMax per workgroup.  fp32, evaluated in a
 //                           fixed order without FMA contraction (bit-reproducible).
-//   corner_nms_kernel       threshold + 3x3 strict maximum, survivors appended (atomic counter).
-//   corner_sort_emit_kernel one workgroup: bitonic sort of the survivors' linear indices in LDS
-//                           (deterministic output order), sub-pixel refinement, output.
+//   corner_nms_kernel       threshold + 3x3 strict maximum -> one bit per pixel; every wavefront
+//                           owns one 64-bit bitmap word (ballot), so there are no atomics.
+//   corner_emit_kernel      one workgroup: popcount + block scan over the bitmap = ordered,
+//                           deterministic compaction; sub-pixel refinement; output.
 #include "vohip_internal.h"
 
 #include <cmath>
@@ -119,70 +120,85 @@ __global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t *__r
     if (tid == 0) atomicMax(max_bits, sMax);
 }
 
+// Threshold + strict 3x3 maximum.  Threads run over the linear pixel index, so each wavefront
+// covers 64 consecutive pixels and owns exactly one 64-bit word of the corner bitmap (written by
+// lane 0, no atomics, every word written on every call).
 __global__ __launch_bounds__(256) void corner_nms_kernel(const float *__restrict__ R, int A, int B, int lo,
                                                          float min_quality, const unsigned *__restrict__ max_bits,
-                                                         int *__restrict__ keys, int cap, int *__restrict__ count)
+                                                         unsigned long long *__restrict__ bitmap)
 {
-    const int a = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int b = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (a < lo || a >= A - lo || b < lo || b >= B - lo) return;
-    const float thr = min_quality * from_ordered_bits(*max_bits);
-    const float *c = R + (size_t)b * A + a;
-    const float r = c[0];
-    if (!(r > thr)) return;
-    if (r > c[-1] && r > c[1] && r > c[-A] && r > c[A] && r > c[-A - 1] && r > c[-A + 1] && r > c[A - 1] &&
-        r > c[A + 1]) {
-        const int idx = atomicAdd(count, 1);
-        if (idx < cap) keys[idx] = b * A + a;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int b = idx / A, a = idx - b * A;
+    bool corner = false;
+    if (idx < A * B && a >= lo && a < A - lo && b >= lo && b < B - lo) {
+        const float thr = min_quality * from_ordered_bits(*max_bits);
+        const float *c = R + idx;
+        const float r = c[0];
+        corner = r > thr && r > c[-1] && r > c[1] && r > c[-A] && r > c[A] && r > c[-A - 1] && r > c[-A + 1] &&
+                 r > c[A - 1] && r > c[A + 1];
     }
+    const unsigned long long m = __ballot(corner);
+    if ((threadIdx.x & 63) == 0 && (idx & ~63) < A * B) bitmap[idx >> 6] = m;
 }
 
-// One workgroup of 1024 threads.  Sorts min(*count, cap) keys ascending, then writes the
-// sub-pixel position (x, y 1-based; swap_xy as in the tracker) and the metric of each.
-__global__ __launch_bounds__(1024) void corner_sort_emit_kernel(const float *__restrict__ R, int A,
-                                                                const int *__restrict__ keys_in, int cap,
-                                                                const int *__restrict__ count, int swap_xy,
-                                                                float *__restrict__ xy_out,
-                                                                float *__restrict__ metric_out,
-                                                                int *__restrict__ keys_sorted)
+// One workgroup of 1024 threads walks the bitmap in index order: popcount per thread chunk,
+// block-wide exclusive scan, then every set bit is written at its rank -- a deterministic,
+// sorted compaction.  Sub-pixel position (x, y 1-based; swap_xy as in the tracker) and metric.
+__global__ __launch_bounds__(1024) void corner_emit_kernel(const float *__restrict__ R, int A, int B,
+                                                           const unsigned long long *__restrict__ bitmap, int cap,
+                                                           int swap_xy, float *__restrict__ xy_out,
+                                                           float *__restrict__ metric_out, int *__restrict__ count)
 {
-    extern __shared__ int sk[];
-    const int n = min(*count, cap);
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int i = threadIdx.x; i < np2; i += 1024) sk[i] = i < n ? keys_in[i] : 0x7fffffff;
+    __shared__ int sWave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwords = (A * B + 63) / 64;
+    const int per = (nwords + 1023) / 1024;
+    const int w0 = tid * per, w1 = min(w0 + per, nwords);
+    int c = 0;
+    for (int w = w0; w < w1; ++w) c += __popcll(bitmap[w]);
+    // inclusive scan within the wave
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) sWave[wave] = incl;
     __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += 1024) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const int x = sk[i], y = sk[p];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) {
-                        sk[i] = y;
-                        sk[p] = x;
-                    }
-                }
-            }
-            __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int t = sWave[w];
+            sWave[w] = run;
+            run += t;
         }
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const int key = sk[i];
-        const int b = key / A, a = key - b * A;
-        const float *c = R + key;
-        const float r = c[0];
-        const float da = c[1] - c[-1], dda = (c[1] - 2.0f * r) + c[-1];
-        const float db = c[A] - c[-A], ddb = (c[A] - 2.0f * r) + c[-A];
-        float oa = dda < 0.0f ? -0.5f * da / dda : 0.0f;
-        float ob = ddb < 0.0f ? -0.5f * db / ddb : 0.0f;
-        oa = fminf(fmaxf(oa, -0.5f), 0.5f);
-        ob = fminf(fmaxf(ob, -0.5f), 0.5f);
-        const float pa = (float)a + oa + 1.0f, pb = (float)b + ob + 1.0f;
-        xy_out[i] = swap_xy ? pb : pa;
-        xy_out[cap + i] = swap_xy ? pa : pb;
-        metric_out[i] = r;
-        if (keys_sorted) keys_sorted[i] = key;
+        *count = run;
+    }
+    __syncthreads();
+    int pos = sWave[wave] + incl - c;
+    for (int w = w0; w < w1; ++w) {
+        unsigned long long m = bitmap[w];
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (pos < cap) {
+                const int key = w * 64 + bit;
+                const int b = key / A, a = key - b * A;
+                const float *cc = R + key;
+                const float r = cc[0];
+                const float da = cc[1] - cc[-1], dda = (cc[1] - 2.0f * r) + cc[-1];
+                const float db = cc[A] - cc[-A], ddb = (cc[A] - 2.0f * r) + cc[-A];
+                float oa = dda < 0.0f ? -0.5f * da / dda : 0.0f;
+                float ob = ddb < 0.0f ? -0.5f * db / ddb : 0.0f;
+                oa = fminf(fmaxf(oa, -0.5f), 0.5f);
+                ob = fminf(fmaxf(ob, -0.5f), 0.5f);
+                const float pa = (float)a + oa + 1.0f, pb = (float)b + ob + 1.0f;
+                xy_out[pos] = swap_xy ? pb : pa;
+                xy_out[cap + pos] = swap_xy ? pa : pb;
+                metric_out[pos] = r;
+            }
+            ++pos;
+        }
     }
 }
 
@@ -219,25 +235,22 @@ int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int
     VOHIP_REQUIRE(ctx, cap >= 1 && cap <= 16384, "cap must be 1..16384");
     VOHIP_REQUIRE(ctx, border >= 0, "negative border");
     const int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
-    void *d_R, *d_keys, *d_max;
+    void *d_R, *d_bitmap, *d_max;
+    const int nwords = (A * B + 63) / 64;
     VOHIP_TRY(vohip_upload(ctx, B_HARRIS_R, nullptr, sizeof(float) * (size_t)A * B, &d_R));
-    VOHIP_TRY(vohip_upload(ctx, B_HARRIS_KEYS, nullptr, sizeof(int) * (size_t)cap, &d_keys));
+    VOHIP_TRY(vohip_upload(ctx, B_HARRIS_KEYS, nullptr, sizeof(unsigned long long) * (size_t)nwords, &d_bitmap));
     VOHIP_TRY(vohip_upload(ctx, B_HARRIS_MAX, nullptr, 256, &d_max));
     taps5 G;
     gaussian_taps(filter_size, G.w);
     hipStream_t st = ctx->stream;
     VOHIP_HIP(ctx, hipMemsetAsync(d_max, 0, 256, st));
-    VOHIP_HIP(ctx, hipMemsetAsync(d_count, 0, sizeof(int), st));
     hipLaunchKernelGGL(corner_response_kernel, dim3((A + TA - 1) / TA, (B + TB - 1) / TB), dim3(256), 0, st, d_img, A,
                        B, G, method, (float *)d_R, (unsigned *)d_max);
     const int lo = border < 1 ? 1 : border;
-    hipLaunchKernelGGL(corner_nms_kernel, dim3((A + 63) / 64, (B + 3) / 4), dim3(256), 0, st, (const float *)d_R, A, B,
-                       lo, (float)min_quality, (const unsigned *)d_max, (int *)d_keys, cap, d_count);
-    int np2 = 1;
-    while (np2 < cap) np2 <<= 1;
-    hipLaunchKernelGGL(corner_sort_emit_kernel, dim3(1), dim3(1024), sizeof(int) * (size_t)np2, st,
-                       (const float *)d_R, A, (const int *)d_keys, cap, (const int *)d_count, colmajor ? 1 : 0, d_xy,
-                       d_metric, (int *)nullptr);
+    hipLaunchKernelGGL(corner_nms_kernel, dim3((A * B + 255) / 256), dim3(256), 0, st, (const float *)d_R, A, B, lo,
+                       (float)min_quality, (const unsigned *)d_max, (unsigned long long *)d_bitmap);
+    hipLaunchKernelGGL(corner_emit_kernel, dim3(1), dim3(1024), 0, st, (const float *)d_R, A, B,
+                       (const unsigned long long *)d_bitmap, cap, colmajor ? 1 : 0, d_xy, d_metric, d_count);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }

@@ -116,12 +116,24 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
         const float fa = (float)(ca - fca), fb = (float)(cb - fcb);
 
         // stage the template neighbourhood: raw pixels at offsets -(HALF+1) .. HALF+2
+        // (all loads are issued before the first LDS store so that their latencies overlap)
         __syncthreads();
-        for (int q = lane; q < C::SI * C::SI; q += 64) {
-            const int rb = q / C::SI, ra = q - rb * C::SI;
-            const int a = min(max(ia - C::HALF - 1 + ra, 0), A - 1);
-            const int b = min(max(ib - C::HALF - 1 + rb, 0), B - 1);
-            sI[q] = Pl[(size_t)b * A + a];
+        {
+            constexpr int NLD = (C::SI * C::SI + 63) / 64;
+            float tmp[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int q = lane + 64 * k;
+                const int rb = q / C::SI, ra = q - rb * C::SI;
+                const int a = min(max(ia - C::HALF - 1 + ra, 0), A - 1);
+                const int b = min(max(ib - C::HALF - 1 + rb, 0), B - 1);
+                tmp[k] = Pl[(size_t)b * A + a];   // rows past the patch are clamped reads, never stored
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int q = lane + 64 * k;
+                if (q < C::SI * C::SI) sI[q] = tmp[k];
+            }
         }
         __syncthreads();
 
@@ -169,11 +181,22 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                     cjb = jb;
                     staged = true;
                     __syncthreads();
-                    for (int q = lane; q < C::SJ * C::SJ; q += 64) {
-                        const int rb = q / C::SJ, ra = q - rb * C::SJ;
-                        const int a = min(max(cja - C::HALF - C::MARG + ra, 0), A - 1);
-                        const int b = min(max(cjb - C::HALF - C::MARG + rb, 0), B - 1);
-                        sJ[q] = Ql[(size_t)b * A + a];
+                    {
+                        constexpr int NLD = (C::SJ * C::SJ + 63) / 64;
+                        float tmp[NLD];
+#pragma unroll
+                        for (int k = 0; k < NLD; ++k) {
+                            const int q = lane + 64 * k;
+                            const int rb = q / C::SJ, ra = q - rb * C::SJ;
+                            const int a = min(max(cja - C::HALF - C::MARG + ra, 0), A - 1);
+                            const int b = min(max(cjb - C::HALF - C::MARG + rb, 0), B - 1);
+                            tmp[k] = Ql[(size_t)b * A + a];
+                        }
+#pragma unroll
+                        for (int k = 0; k < NLD; ++k) {
+                            const int q = lane + 64 * k;
+                            if (q < C::SJ * C::SJ) sJ[q] = tmp[k];
+                        }
                     }
                     __syncthreads();
                 }

@@ -38,6 +38,29 @@ def _options(options):
     return {opts[i]: opts[i + 1] for i in range(0, len(opts), 2)}
 
 
+def _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap):
+    """Detection on a uint8 image already resident on the GPU (an object with data_ptr() and
+    shape, row-major): only the keypoint list crosses the bus."""
+    import torch
+    rows, cols = int(image.shape[0]), int(image.shape[1])
+    scratch = ctx.__dict__.setdefault("_corner_scratch", {})
+    if scratch.get("cap") != cap:
+        scratch["cap"] = cap
+        scratch["xy"] = torch.empty(2 * cap, dtype=torch.float32, device=image.device)
+        scratch["metric"] = torch.empty(cap, dtype=torch.float32, device=image.device)
+        scratch["count"] = torch.zeros(1, dtype=torch.int32, device=image.device)
+    xy, metric, count = scratch["xy"], scratch["metric"], scratch["count"]
+    ctx.check(_lib.load().vohip_detect_corners_dev(ctx.handle, image.data_ptr(), rows, cols, 0, min_quality,
+                                                   filter_size, border, 0 if method == "Harris" else 1,
+                                                   xy.data_ptr(), metric.data_ptr(), cap, count.data_ptr()))
+    ctx.synchronize()
+    total = int(count.item())
+    if total > cap:
+        raise _lib.VohipError(_lib.VOHIP_CAPACITY_EXCEEDED, "%d corners found, capacity %d" % (total, cap))
+    loc = torch.stack([xy[:total], xy[cap:cap + total]], dim=1).cpu().numpy()
+    return cornerPoints(loc, metric[:total].cpu().numpy())
+
+
 def genKeypoints(image, method="SURF", options=None, ctx=None):
     """[features, valid_key_points] = genKeypoints(image, method, options)
 
@@ -56,6 +79,8 @@ def genKeypoints(image, method="SURF", options=None, ctx=None):
     cap = int(opts.pop("Capacity", DEFAULT_CAPACITY))
     if opts:
         raise ValueError("unknown option(s): %s" % ", ".join(opts))
+    if hasattr(image, "data_ptr"):
+        return None, _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap)
     img = np.asarray(image)
     if img.dtype != np.uint8 or img.ndim != 2:
         raise TypeError("image must be a 2-D uint8 array")

@@ -21,6 +21,17 @@ class Pyramid:
         if not free:
             raise RuntimeError("all 8 pyramid slots of the context are in use; release() some")
         self.slot = free.pop(0)
+        if hasattr(image, "data_ptr"):
+            # a uint8 image already resident on the GPU (e.g. a torch tensor), row-major
+            shape = tuple(image.shape)
+            self.shape, self.levels = shape, levels
+            try:
+                self.ctx.check(_lib.load().vohip_pyramid_build_dev(self.ctx.handle, self.slot, image.data_ptr(), shape[0],
+                                                                   shape[1], 0, levels))
+            except Exception:
+                self.release()
+                raise
+            return
         img = np.asarray(image)
         if img.dtype != np.uint8 or img.ndim != 2:
             self.release()

@@ -279,5 +279,7 @@ def corridor_sequence(n_frames, seed=5678, step=1.0, width=KITTI_W, height=KITTI
     scene = CorridorScene(seed=seed, width=width, height=height)
     frames = [scene.render(T) for T in poses]
     if path:
-        np.save(path, np.stack(frames))
+        tmp = "%s.%d.tmp.npy" % (path, os.getpid())   # atomic: several ranks may render at once
+        np.save(tmp, np.stack(frames))
+        os.replace(tmp, path)
     return frames, poses
