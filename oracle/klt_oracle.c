@@ -24,7 +24,10 @@
  *    (gx = (prev(p + w + ea) - prev(p + w - ea)) / 2), G = sum [gx gx, gx gy; gx gy, gy gy],
  *    then at most max_iter Gauss-Newton steps d += G^-1 sum (T - cur(p + d + w)) [gx; gy]
  *    (G^-1 = adj(G) * (1 / det G)),
- *    stopping after a step shorter than 0.01 px.  Products and sums in double.
+ *    stopping after a step shorter than 0.01 px, or when a step cancels the previous one to
+ *    within 0.01 px (oscillation: half of the last step is taken back).  G is summed in double; the right-hand side is
+ *    summed in float within each of 64 pixel groups (pixel q in group q mod 64, increasing q,
+ *    fmaf) and in double across the groups.
  *    The displacement doubles between levels.
  *  - A point is valid iff at level 0 G is well conditioned in both directions
  *    (lambda_min(G) / W^2 >= 1e-3), the forward result lies inside the image, and the
@@ -148,24 +151,39 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
         if (l == 0) ok0 = good;
         const double inv_det = 1.0 / det;
         if (good) {
+            double psa = 0.0, psb = 0.0;
             for (int it = 0; it < max_iter; ++it) {
                 const double ta = ca + da, tb = cb + db;
                 const int ja = (int)floor(ta), jb = (int)floor(tb);
                 const float ga = (float)(ta - ja), gb = (float)(tb - jb);
+                /* right-hand side: window pixel q = (wb + half) W + (wa + half) belongs to group
+                 * q mod 64; each group is summed in float with fmaf in increasing q, the 64 group
+                 * sums are added in double */
                 double ba = 0, bb = 0;
-                for (int wb = -half; wb <= half; ++wb)
-                    for (int wa = -half; wa <= half; ++wa) {
-                        int k = (wb + half) * W + (wa + half);
+                for (int grp = 0; grp < 64; ++grp) {
+                    float baf = 0.f, bbf = 0.f;
+                    for (int k = grp; k < W * W; k += 64) {
+                        int wb = k / W - half, wa = k % W - half;
                         float j = bilinear(Q[l], A, B, ja + wa, jb + wb, ga, gb);
                         float e = T[k] - j;
-                        ba += (double)e * (double)GX[k];
-                        bb += (double)e * (double)GY[k];
+                        baf = fmaf(e, GX[k], baf);
+                        bbf = fmaf(e, GY[k], bbf);
                     }
+                    ba += (double)baf;
+                    bb += (double)bbf;
+                }
                 const double sa = (gyy * ba - gxy * bb) * inv_det;
                 const double sb = (gxx * bb - gxy * ba) * inv_det;
                 da += sa;
                 db += sb;
                 if (sa * sa + sb * sb < KLT_EPS_STEP * KLT_EPS_STEP) break;
+                if (it > 0 && (sa + psa) * (sa + psa) + (sb + psb) * (sb + psb) < KLT_EPS_STEP * KLT_EPS_STEP) {
+                    da -= 0.5 * sa; /* oscillation around the minimum: settle half-way */
+                    db -= 0.5 * sb;
+                    break;
+                }
+                psa = sa;
+                psb = sb;
             }
         }
         if (l > 0) {

@@ -22,7 +22,9 @@
 //     * a (W+12)^2 region of the current image around the running estimate is staged in LDS and
 //       re-used by successive iterations while the estimate stays within +-5 px of its centre.
 //   Pixel arithmetic is fp32 with explicit fmaf (bit-identical to a scalar evaluation of the
-//   same formulas); all sums are fp64.
+//   same formulas).  G is summed in fp64; the right-hand side b is summed per lane in fp32 over
+//   the lane's <= ceil(W^2/64) pixels (pixel q belongs to lane q mod 64, in increasing q) and
+//   across lanes in fp64.
 #include "vohip_internal.h"
 #include "wave_reduce.h"
 
@@ -101,6 +103,17 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
     const int lane = threadIdx.x;
     double da = 0.0, db = 0.0;
     bool ok0 = true;
+    // window pixels owned by this lane: q = lane + 64 k  ->  (wb, wa) = (q / W, q % W)
+    int offI[C::PER_LANE], offJ[C::PER_LANE];
+    bool live[C::PER_LANE];
+#pragma unroll
+    for (int k = 0; k < C::PER_LANE; ++k) {
+        const int q = lane + 64 * k;
+        live[k] = q < C::NPIX;
+        const int wb = live[k] ? q / W : 0, wa = live[k] ? q - wb * W : 0;
+        offI[k] = (wb + 1) * C::SI + (wa + 1);
+        offJ[k] = wb * C::SJ + wa;
+    }
     for (int l = P.levels - 1; l >= 0; --l) {
         const int A = P.A[l], B = P.B[l];
         const float *__restrict__ Pl = P.lvl[l];
@@ -137,24 +150,19 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
         double gxx = 0.0, gxy = 0.0, gyy = 0.0;
 #pragma unroll
         for (int k = 0; k < C::PER_LANE; ++k) {
-            const int q = lane + 64 * k;
-            T[k] = GX[k] = GY[k] = 0.f;
-            if (q < C::NPIX) {
-                const int wb = q / W, wa = q - wb * W;
-                // raw index of the window pixel's top-left tap
-                const float *c = sI + (wb + 1) * C::SI + (wa + 1);
-                auto samp = [&](const float *p) { return bilerp(p[0], p[1], p[C::SI], p[C::SI + 1], fa, fb); };
-                const float v = samp(c);
-                const float ap = samp(c + 1), am = samp(c - 1);
-                const float bp = samp(c + C::SI), bm = samp(c - C::SI);
-                const float gx = (ap - am) * 0.5f, gy = (bp - bm) * 0.5f;
-                T[k] = v;
-                GX[k] = gx;
-                GY[k] = gy;
-                gxx += (double)gx * (double)gx;
-                gxy += (double)gx * (double)gy;
-                gyy += (double)gy * (double)gy;
-            }
+            // lanes past the window read pixel (0, 0) and have their template zeroed: no branches
+            const float *c = sI + offI[k];
+            auto samp = [&](const float *p) { return bilerp(p[0], p[1], p[C::SI], p[C::SI + 1], fa, fb); };
+            const float v = samp(c);
+            const float ap = samp(c + 1), am = samp(c - 1);
+            const float bp = samp(c + C::SI), bm = samp(c - C::SI);
+            const float gx = live[k] ? (ap - am) * 0.5f : 0.f, gy = live[k] ? (bp - bm) * 0.5f : 0.f;
+            T[k] = live[k] ? v : 0.f;
+            GX[k] = gx;
+            GY[k] = gy;
+            gxx += (double)gx * (double)gx;
+            gxy += (double)gx * (double)gy;
+            gyy += (double)gy * (double)gy;
         }
         gxx = wave_sum(gxx);
         gxy = wave_sum(gxy);
@@ -167,6 +175,7 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
         if (good) {
             int cja = 0, cjb = 0;
             bool staged = false;
+            double pa_prev = 0.0, pb_prev = 0.0;
             for (int it = 0; it < max_iter; ++it) {
                 const double ta = ca + da, tb = cb + db;
                 const double fta = floor(ta), ftb = floor(tb);
@@ -198,19 +207,18 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                     __syncthreads();
                 }
                 const float *org = sJ + (jb - cjb + C::MARG) * C::SJ + (ja - cja + C::MARG);
-                double ba = 0.0, bb = 0.0;
+                // per-lane partial sums in fp32 (at most PER_LANE fused multiply-adds, fixed order),
+                // widened to fp64 for the reduction across the wavefront
+                float baf = 0.f, bbf = 0.f;
 #pragma unroll
                 for (int k = 0; k < C::PER_LANE; ++k) {
-                    const int q = lane + 64 * k;
-                    if (q < C::NPIX) {
-                        const int wb = q / W, wa = q - wb * W;
-                        const float *p = org + wb * C::SJ + wa;
-                        const float j = bilerp(p[0], p[1], p[C::SJ], p[C::SJ + 1], ga, gb);
-                        const float e = T[k] - j;
-                        ba += (double)e * (double)GX[k];
-                        bb += (double)e * (double)GY[k];
-                    }
+                    const float *p = org + offJ[k];
+                    const float j = bilerp(p[0], p[1], p[C::SJ], p[C::SJ + 1], ga, gb);
+                    const float e = T[k] - j;
+                    baf = __builtin_fmaf(e, GX[k], baf);
+                    bbf = __builtin_fmaf(e, GY[k], bbf);
                 }
+                double ba = (double)baf, bb = (double)bbf;
                 ba = wave_sum(ba);
                 bb = wave_sum(bb);
                 const double sa = (gyy * ba - gxy * bb) * inv_det;
@@ -218,6 +226,16 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                 da += sa;
                 db += sb;
                 if (sa * sa + sb * sb < KLT_EPS_STEP * KLT_EPS_STEP) break;
+                // a step that undoes the previous one: the estimate oscillates around the minimum;
+                // settle half-way and stop
+                if (it > 0 && (sa + pa_prev) * (sa + pa_prev) + (sb + pb_prev) * (sb + pb_prev) <
+                                  KLT_EPS_STEP * KLT_EPS_STEP) {
+                    da -= 0.5 * sa;
+                    db -= 0.5 * sb;
+                    break;
+                }
+                pa_prev = sa;
+                pb_prev = sb;
             }
         }
         if (l > 0) {

@@ -52,32 +52,46 @@ def ransacLocalization(matched_query_keypoints, corresponding_landmarks, K, samp
     n = kp.shape[0]
     if X.shape[0] != n:
         raise ValueError("keypoints and landmarks differ in count")
-    rng_state = None
-    if samples is None:
-        if rng is None:
-            rng = np.random.default_rng()
-        rng_state = rng.bit_generator.state
-        samples = draw_triples(rng, n, MAX_ITERATIONS - 1) if n >= 3 else np.zeros((1, 3), np.int32)
-    samples = np.ascontiguousarray(samples, dtype=np.int32)
-    h = samples.shape[0]
     R = np.zeros(9)
     t = np.zeros(3)
     mask = np.zeros(max(n, 1), dtype=np.uint8)
-    max_hist = np.zeros(h)
-    iter_hist = np.zeros(h)
     n_iter = C.c_int(0)
-    st = lib.vohip_ransac_p3p(ctx.handle, dptr(kp), dptr(X), n, dptr(Kc),
-                              samples.ctypes.data_as(_lib.c_int32_p), h, dptr(R), dptr(t),
-                              mask.ctypes.data_as(_lib.c_uint8_p), dptr(max_hist), dptr(iter_hist),
-                              C.byref(n_iter))
-    ctx.check(st, allow=(VOHIP_NO_MODEL, VOHIP_SAMPLES_EXHAUSTED))
-    if st == VOHIP_SAMPLES_EXHAUSTED and rng_state is None:
-        raise _lib.VohipError(st, lib.vohip_last_error(ctx.handle).decode())
-    k = n_iter.value
-    if rng_state is not None:
+
+    def lib_call(smp, mh, ih, n_iter):
+        return lib.vohip_ransac_p3p(ctx.handle, dptr(kp), dptr(X), n, dptr(Kc), smp.ctypes.data_as(_lib.c_int32_p),
+                                    smp.shape[0], dptr(R), dptr(t), mask.ctypes.data_as(_lib.c_uint8_p), dptr(mh),
+                                    dptr(ih), C.byref(n_iter))
+
+    if samples is not None:
+        samples = np.ascontiguousarray(samples, dtype=np.int32)
+        max_hist = np.zeros(samples.shape[0])
+        iter_hist = np.zeros(samples.shape[0])
+        st = lib_call(samples, max_hist, iter_hist, n_iter)
+        ctx.check(st, allow=(VOHIP_NO_MODEL,))
+    else:
+        # Draw only as many triples as the adaptive loop turns out to need: first the 104 of the
+        # library's first chunk, then 8x more whenever they run out.  The prefix property of
+        # draw_triples makes every attempt see the same leading triples.
+        if rng is None:
+            rng = np.random.default_rng()
+        rng_state = rng.bit_generator.state
+        have = 104
+        while True:
+            rng.bit_generator.state = rng_state
+            samples = draw_triples(rng, n, have) if n >= 3 else np.zeros((1, 3), np.int32)
+            max_hist = np.zeros(samples.shape[0])
+            iter_hist = np.zeros(samples.shape[0])
+            st = lib_call(samples, max_hist, iter_hist, n_iter)
+            if st == VOHIP_SAMPLES_EXHAUSTED and have < MAX_ITERATIONS - 1:
+                have = min(8 * have, MAX_ITERATIONS - 1)
+                continue
+            ctx.check(st, allow=(VOHIP_NO_MODEL,))
+            break
+        # leave the generator where n_iter single draws would have left it
         rng.bit_generator.state = rng_state
-        if k > 0:
-            draw_triples(rng, n, k)
+        if n_iter.value > 0:
+            draw_triples(rng, n, n_iter.value)
+    k = n_iter.value
     if st == VOHIP_NO_MODEL:
         return (np.zeros((0, 0)), np.zeros((0, 0)), np.zeros((1, n)), max_hist[:k].copy(),
                 iter_hist[:k].copy())
