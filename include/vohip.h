@@ -177,6 +177,18 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
                                     double max_depth, int is_BA, uint8_t *d_status, double *d_X,
                                     double *d_angles);
 
+/* ---- relative pose (bootstrap) ---------------------------------------------------------------
+ * Stands in for [orientation, location] = relativeCameraPose(E, cameraParams, pts1, pts2) at
+ * Initialization/pose_estimation_init.m:29-33 (decomposition as in
+ * utils/exe6_8point/decomposeEssentialMatrix.m:12-32; the candidate with the fewest triangulated
+ * points behind either camera wins).  E, K 3x3 column-major; p1, p2 2xn (x; y) pixel coordinates
+ * in images 1 and 2.  orientation 3x3 column-major and location[3] follow the toolbox convention:
+ * x_cam2 = orientation * (x_cam1 - location), |location| = 1.  valid_fraction (may be NULL) is the
+ * share of points in front of both cameras.  VOHIP_NO_MODEL when E has fewer than two non-zero
+ * singular values. */
+int vohip_relative_pose(vohip_ctx *ctx, const double *E, const double *K, const double *p1, const double *p2,
+                        int n, double *orientation, double *location, double *valid_fraction);
+
 /* ---- image pyramids and KLT tracking -------------------------------------------------------
  * Stand in for vision.PointTracker as the reference uses it: constructed at
  * main_demo.m:342-343,348-349 ('BlockSize',[21 21],'NumPyramidLevels',5,'MaxIterations',20,
@@ -210,8 +222,10 @@ int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const doubl
 
 /* ---- fundamental-matrix RANSAC -----------------------------------------------------------
  * Stands in for [F, inliersIndex] = estimateFundamentalMatrix(p1, p2, 'NumTrials', 500, 'Method',
- * 'RANSAC', 'DistanceThreshold', 5e-2) at update_landmarks.m:13-14 (Confidence 99, Sampson
- * distance).  p1, p2 2xn (one column per point, any consistent axis order); samples
+ * 'RANSAC', 'DistanceThreshold', 5e-2) at update_landmarks.m:13-14 (Sampson distance; the toolbox
+ * default Confidence is 99) and for the 2000-trial, 1e-2, Confidence 99.9 call of the bootstrap,
+ * Initialization/pose_estimation_init.m:7-12.  confidence is in percent, in (0, 100).
+ * p1, p2 2xn (one column per point, any consistent axis order); samples
  * 8 x num_trials 0-based index sets drawn by the caller (the toolbox draws them from MATLAB's
  * global RNG); mask n bytes; best_count the inlier count of the winning trial; trials_run (may
  * be NULL) the trials the adaptive budget consumed; F_best (may be NULL) the winning matrix,
@@ -219,13 +233,13 @@ int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const doubl
  * toolbox raises an error there too).
  */
 int vohip_fmatrix_ransac(vohip_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *samples,
-                         int num_trials, double threshold, uint8_t *mask, int *best_count, int *trials_run,
-                         double *F_best);
+                         int num_trials, double threshold, double confidence, uint8_t *mask, int *best_count,
+                         int *trials_run, double *F_best);
 /* d_p1, d_p2, d_samples, d_mask on the device; best_count, trials_run, F_best on the host.
  * Synchronises (the trial budget is replayed on the host). */
 int vohip_fmatrix_ransac_dev(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n,
-                             const int32_t *d_samples, int num_trials, double threshold, uint8_t *d_mask,
-                             int *best_count, int *trials_run, double *F_best);
+                             const int32_t *d_samples, int num_trials, double threshold, double confidence,
+                             uint8_t *d_mask, int *best_count, int *trials_run, double *F_best);
 
 /* ---- bundle adjustment and pose refinement ------------------------------------------------
  * hidden_state = [twists of T_W_C (6 x F, [v; w]); landmarks (3 x m)], observations =

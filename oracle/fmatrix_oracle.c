@@ -12,7 +12,7 @@
  *     enforces rank 2 (smallest singular value set to zero, one-sided Jacobi), de-normalises;
  *   - a pair is an inlier when its Sampson distance, in pixels^2, is <= the threshold;
  *   - the best trial is the first with the largest inlier count; after every improvement the
- *     trial budget shrinks to ceil(log(1 - 0.99) / log(1 - (inliers / n)^8)) (Confidence 99),
+ *     trial budget shrinks to ceil(log(1 - c) / log(1 - (inliers / n)^8)) (c = Confidence / 100),
  *     never above NumTrials.
  */
 #include "vo_oracle.h"
@@ -155,20 +155,21 @@ int vo_fmatrix_count(const double *p1, const double *p2, int n, const double F[9
     return cnt;
 }
 
-double vo_fmatrix_trial_budget(int inliers, int n, int num_trials)
+double vo_fmatrix_trial_budget(int inliers, int n, int num_trials, double confidence)
 {
     double r = (double)inliers / (double)n;
     double r8 = pow(r, 8.0);
     if (r8 >= 1.0) return 1.0;
     if (r8 <= 0.0) return (double)num_trials;
-    double t = ceil(log(1.0 - 0.99) / log(1.0 - r8));
+    double t = ceil(log(1.0 - confidence / 100.0) / log(1.0 - r8));
     return t < (double)num_trials ? t : (double)num_trials;
 }
 
 /* p1, p2: 2 x n (x; y) column-major.  samples 8 x num_trials (0-based).  mask n bytes.
  * Returns the number of trials executed; *best_count the inlier count (0 = no model). */
 int vo_fmatrix_ransac(const double *p1, const double *p2, int n, const int32_t *samples, int num_trials,
-                      double thr, uint8_t *mask, int *best_count, double Fbest[9], int32_t *counts)
+                      double thr, double confidence, uint8_t *mask, int *best_count, double Fbest[9],
+                      int32_t *counts)
 {
     double nrm[6];
     hartley(p1, n, &nrm[0], &nrm[1], &nrm[2]);
@@ -186,7 +187,7 @@ int vo_fmatrix_ransac(const double *p1, const double *p2, int n, const int32_t *
             *best_count = c;
             vo_fmatrix_count(p1, p2, n, F, thr, mask);
             if (Fbest) memcpy(Fbest, F, sizeof(F));
-            budget = vo_fmatrix_trial_budget(c, n, num_trials);
+            budget = vo_fmatrix_trial_budget(c, n, num_trials, confidence);
         }
         ++t;
     }

@@ -223,3 +223,70 @@ class OraclePipeline:
         S.num_X.append(S.X.shape[1]); S.num_C.append(S.C.shape[1])                          # :426-427
         self.S, self.B = S, B
         return T_W_C
+
+
+# ---- bootstrap (main_demo.m:252-264) --------------------------------------------------------------
+
+def matching_init(img0, img_seqs, hp):
+    """Initialization/matching_init.m:1-45, 'KLT' branch: detect in img0, track through every
+    image of img_seqs with a 31x31 / 5-level / 30-iteration tracker, forward-backward bound 3 px;
+    a point lost in an intermediate image stays lost."""
+    img0 = np.ascontiguousarray(img0)
+    opts = dict(zip(hp.feature_extract_options[::2], hp.feature_extract_options[1::2]))
+    ab, _, _ = orc.detect_corners(img0, min_quality=opts.get("MinQuality", 0.01), filter_size=5, border=16,
+                                  method=0 if hp.feature_extract == "Harris" else 1)        # :12
+    init_points_ = ab + np.float32(1.0)                                                    # :13 (single)
+    pts = init_points_.astype(np.float64)
+    alive = np.ones(len(pts), dtype=bool)
+    prev = img0
+    for img in img_seqs:                                                                   # :16-21
+        img = np.ascontiguousarray(img)
+        out, valid, _ = orc.klt_track(prev, img, pts - 1.0, block=31, levels=5, max_iter=30, max_bidir_error=3.0)
+        pts = out + 1.0
+        alive &= valid
+        prev = img
+    return init_points_[alive], pts[alive]                                                 # :23-24
+
+
+def pose_estimation_init(init_points, matched_points, K, draw_octets, rng):
+    """Initialization/pose_estimation_init.m:1-37, 'fundamental' branch."""
+    K = np.asarray(K, dtype=np.float64)
+    p1 = np.asarray(init_points, dtype=np.float64)
+    p2 = np.asarray(matched_points, dtype=np.float64)
+    res = orc.fmatrix_ransac(p1.T, p2.T, draw_octets(rng, p1.shape[0], 2000), 1e-2, 99.9)  # :7-12
+    inl = res["mask"]
+    essMat = K.T @ res["F"] @ K                                                            # :15
+    init_valid, matched_valid = np.asarray(init_points)[inl], np.asarray(matched_points)[inl]   # :25-26
+    R, loc, _ = orc.relative_pose(essMat, K, p1[inl].T, p2[inl].T)                         # :29-33
+    T_W_C = np.eye(4)
+    T_W_C[:3, :3] = R                                                                      # :35
+    T_W_C[:3, 3] = loc
+    return T_W_C, init_valid, matched_valid
+
+
+def triangulation_init(init_valid, matched_valid, T_init_WC, K, hp):
+    """Initialization/triangulation_init.m:1-34."""
+    T_C_W = np.linalg.inv(T_init_WC)                                                       # :2-4
+    K = np.asarray(K, dtype=np.float64)
+    proj_mat0 = K @ np.hstack([np.eye(3), np.zeros((3, 1))])                               # :7-8, compProjMat.m:5
+    proj_mat1 = K @ np.hstack([T_C_W[:3, :3], T_C_W[:3, 3:4]])
+    p0 = np.asarray(init_valid, dtype=np.float64)
+    p1 = np.asarray(matched_valid, dtype=np.float64)
+    n = p0.shape[0]
+    P = orc.linear_triangulation(np.vstack([p0.T, np.ones((1, n))]), np.vstack([p1.T, np.ones((1, n))]), proj_mat0,
+                                 proj_mat1)                                                # :11-18
+    pts3d = P[:3].T                                                                        # :20
+    ok = (pts3d[:, 2] >= hp.min_depth) & (pts3d[:, 2] <= hp.max_depth)                     # :28
+    return pts3d[ok], np.asarray(matched_valid)[ok]                                        # :29-31
+
+
+def bootstrap(img0, img_seqs, K, hp, draw_octets, rng):
+    """main_demo.m:252-264."""
+    init_points, matched_points = matching_init(img0, img_seqs, hp)
+    T_init_WC, init_valid, matched_valid = pose_estimation_init(init_points, matched_points, K, draw_octets, rng)
+    pts3d, matched_valid = triangulation_init(init_valid, matched_valid, T_init_WC, K, hp)
+    p_W_landmarks = np.asarray(pts3d, dtype=np.float64)
+    keypoints = np.asarray(matched_valid, dtype=np.float64)
+    if hp.is_refine_pose:
+        T_init_WC, _ = orc.pose_refine(T_init_WC, keypoints.T, p_W_landmarks.T, K)
+    return p_W_landmarks, keypoints, T_init_WC

@@ -121,9 +121,18 @@ void vo_pose_refine(double T[16], const double *kp_uv, const double *X, int n, c
  * at update_landmarks.m:13-14; see the header of fmatrix_oracle.c. */
 int vo_fmatrix_8point(const double *p1, const double *p2, const int32_t idx[8], const double nrm[6], double F[9]);
 int vo_fmatrix_count(const double *p1, const double *p2, int n, const double F[9], double thr, uint8_t *mask);
-double vo_fmatrix_trial_budget(int inliers, int n, int num_trials);
+double vo_fmatrix_trial_budget(int inliers, int n, int num_trials, double confidence);
 int vo_fmatrix_ransac(const double *p1, const double *p2, int n, const int32_t *samples, int num_trials,
-                      double thr, uint8_t *mask, int *best_count, double Fbest[9], int32_t *counts);
+                      double thr, double confidence, uint8_t *mask, int *best_count, double Fbest[9],
+                      int32_t *counts);
+
+/* ---- bootstrap_oracle.c -------------------------------------------------------------------- */
+
+/* This project's definition of the relative-pose step that stands in for relativeCameraPose at
+ * Initialization/pose_estimation_init.m:29-33; see the header of bootstrap_oracle.c. */
+int vo_decompose_essential(const double E[9], double R[2][9], double u3[3]);
+int vo_relative_pose(const double E[9], const double K[9], const double *p1, const double *p2, int n,
+                     double orientation[9], double location[3], double *valid_fraction);
 
 /* ---- harris_oracle.c ------------------------------------------------------------------- */
 

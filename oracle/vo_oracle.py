@@ -296,9 +296,26 @@ def pose_refine(T_W_C, kp_uv, X, K, max_iter=100, ftol=1e-10, xtol=1e-10):
     return T.reshape(4, 4).T.copy(), dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2])
 
 
+# ---- relative pose (bootstrap) -----------------------------------------------------------------
+
+def relative_pose(E, K, p1, p2):
+    """E, K 3x3; p1, p2 2xn (x; y).  Returns (orientation 3x3, location (3,), valid fraction) or None."""
+    a = _f64(np.asarray(p1).T)
+    b = _f64(np.asarray(p2).T)
+    R = np.zeros(9)
+    loc = np.zeros(3)
+    frac = C.c_double(0.0)
+    lib().vo_relative_pose.restype = C.c_int
+    ok = lib().vo_relative_pose(_d(_f64(np.asarray(E).T)), _d(_f64(np.asarray(K).T)), _d(a), _d(b), C.c_int(a.shape[0]),
+                                _d(R), _d(loc), C.byref(frac))
+    if not ok:
+        return None
+    return R.reshape(3, 3).T.copy(), loc, frac.value
+
+
 # ---- fundamental-matrix RANSAC ---------------------------------------------------------------
 
-def fmatrix_ransac(p1, p2, samples, threshold=5e-2):
+def fmatrix_ransac(p1, p2, samples, threshold=5e-2, confidence=99.0):
     """p1, p2: 2xn; samples (T, 8) 0-based.  Returns dict(mask, best_count, trials, F, counts)."""
     a = _f64(np.asarray(p1).T)
     b = _f64(np.asarray(p2).T)
@@ -310,5 +327,6 @@ def fmatrix_ransac(p1, p2, samples, threshold=5e-2):
     counts = np.zeros(max(T, 1), dtype=np.int32)
     lib().vo_fmatrix_ransac.restype = C.c_int
     trials = lib().vo_fmatrix_ransac(_d(a), _d(b), C.c_int(n), s.ctypes.data_as(_ip), C.c_int(T), C.c_double(threshold),
+                                     C.c_double(confidence),
                                      mask.ctypes.data_as(_bp), C.byref(best), _d(F), counts.ctypes.data_as(_ip))
     return dict(mask=mask[:n].astype(bool), best_count=best.value, trials=trials, F=F.reshape(3, 3), counts=counts[:trials])

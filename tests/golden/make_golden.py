@@ -153,7 +153,28 @@ def make_fmatrix():
                         is_inlier=is_in)
 
 
-MAKERS = {"fmatrix": make_fmatrix, "ba": make_ba, "ransac": make_ransac, "geometry": make_geometry, "klt": make_klt, "harris": make_harris}
+def make_bootstrap():
+    """Relative pose from a noisy essential matrix, 600 pairs of which 60 are gross outliers."""
+    K = vo_synth.K_KITTI
+    rng = np.random.default_rng(77)
+    n = 600
+    R = vo_synth.rotation_from_rotvec(np.array([0.01, -0.03, 0.005]))
+    C2 = np.array([0.15, -0.05, 1.0])
+    t = -R @ C2
+    X = np.stack([rng.uniform(-10, 10, n), rng.uniform(-3, 2, n), rng.uniform(5, 60, n)])
+    x1 = K @ X
+    x2 = K @ (R @ X + t[:, None])
+    p1 = x1[:2] / x1[2] + rng.normal(size=(2, n)) * 0.3
+    p2 = x2[:2] / x2[2] + rng.normal(size=(2, n)) * 0.3
+    p2[:, :60] = rng.uniform(0, 376, size=(2, 60))
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R + rng.normal(size=(3, 3)) * 1e-3
+    ori, loc, frac = orc.relative_pose(E, K, p1, p2)
+    np.savez_compressed(os.path.join(HERE, "relative_pose_n600.npz"), E=E, K=K, p1=p1, p2=p2, orientation=ori,
+                        location=loc, valid_fraction=frac, R_true=R, C_true=C2)
+
+
+MAKERS = {"bootstrap": make_bootstrap, "fmatrix": make_fmatrix, "ba": make_ba, "ransac": make_ransac, "geometry": make_geometry, "klt": make_klt, "harris": make_harris}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(MAKERS)

@@ -1,0 +1,100 @@
+"""Parity of the HIP bootstrap path (relative pose kernel; matching_init / pose_estimation_init /
+triangulation_init over the GPU kernels) with the CPU oracle.
+Bars: relative pose within 1e-9 (fp64, same algorithm; the candidate choice is an integer count
+and must agree exactly); the composed bootstrap selects the same points and its landmarks / pose
+agree within the bars of the stages underneath (1e-6 relative, 1e-5 rad / m)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_relative_pose_matches_golden(vo, ctx):
+    g = np.load(os.path.join(GOLD, "relative_pose_n600.npz"))
+    ori, loc, frac = vo.relativeCameraPose(g["E"], g["K"], g["p1"].T, g["p2"].T, ctx=ctx)
+    np.testing.assert_allclose(ori, g["orientation"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(loc[0], g["location"], rtol=0, atol=1e-9)
+    assert frac == float(g["valid_fraction"])
+
+
+@pytest.mark.parametrize("n,seed", [(1, 0), (7, 1), (255, 2), (256, 3), (257, 4), (3000, 5)])
+def test_relative_pose_matches_oracle(vo, ctx, oracle, n, seed):
+    rng = np.random.default_rng(seed)
+    K = vo.synth.K_KITTI
+    R = vo.synth.rotation_from_rotvec(rng.normal(size=3) * 0.1)
+    C2 = rng.normal(size=3) + np.array([0, 0, 1.0])
+    t = -R @ C2
+    X = np.stack([rng.uniform(-10, 10, n), rng.uniform(-3, 3, n), rng.uniform(4, 50, n)])
+    x1, x2 = K @ X, K @ (R @ X + t[:, None])
+    p1 = x1[:2] / x1[2] + rng.normal(size=(2, n)) * 0.2
+    p2 = x2[:2] / x2[2] + rng.normal(size=(2, n)) * 0.2
+    p2[:, : n // 8] = rng.uniform(0, 400, size=(2, n // 8))
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R + rng.normal(size=(3, 3)) * 1e-3
+    want = oracle.relative_pose(E, K, p1, p2)
+    ori, loc, frac = vo.relativeCameraPose(E, K, p1.T, p2.T, ctx=ctx)
+    np.testing.assert_allclose(ori, want[0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(loc[0], want[1], rtol=0, atol=1e-9)
+    assert frac == want[2]
+
+
+def test_relative_pose_degenerate(vo, ctx):
+    p = np.random.default_rng(0).uniform(0, 300, size=(10, 2))
+    with pytest.raises(vo.VohipError) as ei:
+        vo.relativeCameraPose(np.zeros((3, 3)), vo.synth.K_KITTI, p, p, ctx=ctx)
+    assert ei.value.status == vo._lib.VOHIP_NO_MODEL
+
+
+def test_tracker_keeps_lost_points_lost(vo, ctx):
+    """A point that fails in one step stays invalid in the next (matching_init.m:16-21 relies on it)."""
+    img = vo.synth.to_uint8(vo.synth.textured_image(240, 320, seed=3))
+    blank = np.full_like(img, 128)
+    pts = np.array([[100.0, 100.0], [200.0, 120.0]])
+    trk = vo.PointTracker(NumPyramidLevels=3, MaxBidirectionalError=3, ctx=ctx)
+    trk.initialize(pts, img)
+    _, v1 = trk(blank)          # no texture: every point is lost
+    _, v2 = trk(img)
+    trk.release()
+    assert not v1.any() and not v2.any()
+
+
+def test_bootstrap_matches_cpu_restatement(vo, ctx, oracle):
+    from oracle import pipeline_oracle as po
+    K = np.array([[400.0, 0, 320], [0, 400.0, 120], [0, 0, 1]])
+    scene = vo.synth.CorridorScene(K=K, width=640, height=240)
+    poses = vo.synth.corridor_trajectory(8, step=0.5)
+    frames = [scene.render(T) for T in poses]
+    hp = vo.default_hyper_paras("kitti")
+
+    ip_r, mp_r = po.matching_init(frames[0], frames[1:3], hp)
+    ip_g, mp_g = vo.matching_init(frames[0], frames[1:3], hp, ctx=ctx)
+    assert ip_g.shape == ip_r.shape
+    np.testing.assert_array_equal(ip_g, ip_r)                         # detections are bit-exact
+    np.testing.assert_allclose(mp_g, mp_r, rtol=0, atol=0.05)          # tracks within 0.05 px
+
+    # same matches into both -> same inliers, same pose
+    T_r, iv_r, mv_r = po.pose_estimation_init(ip_r, mp_r, K, vo.draw_octets, np.random.default_rng(3))
+    T_g, iv_g, mv_g = vo.pose_estimation_init(ip_r, mp_r, K, hp, rng=np.random.default_rng(3), ctx=ctx)
+    assert iv_g.shape == iv_r.shape
+    np.testing.assert_allclose(T_g, T_r, rtol=0, atol=1e-7)
+    X_r, kp_r = po.triangulation_init(iv_r, mv_r, T_r, K, hp)
+    X_g, kp_g = vo.triangulation_init(iv_r, mv_r, T_r, K, hp, ctx=ctx)
+    assert X_g.shape == X_r.shape
+    np.testing.assert_allclose(X_g, X_r, rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal(kp_g, kp_r)
+
+    # the composed bootstrap on the GPU, then continuous operation from its result
+    X, kp, T0 = vo.bootstrap(frames[0], frames[1:3], K, hp, rng=np.random.default_rng(3), ctx=ctx)
+    assert X.shape[0] == kp.shape[0] > 500
+    pipe = vo.VOPipeline(K, frames[2], X, kp, T0, hyper_paras=hp, rng=np.random.default_rng(4), ctx=ctx)
+    for f in frames[3:]:
+        pipe.process_frame(f)
+    et, _ = pipe.trajectory()
+    pipe.close()
+    # the estimate lives in the frame of camera 0 with the 0->2 baseline as unit: the camera keeps
+    # moving forward by about half a unit per frame
+    steps = np.diff(et, axis=1)
+    assert np.all(steps[2] > 0.3) and np.all(steps[2] < 0.7), steps[2]

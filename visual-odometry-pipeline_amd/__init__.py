@@ -6,6 +6,8 @@ from . import _lib
 from ._lib import Context, VohipError, default_context
 from . import batch, synth
 from .ba import T_refinement, baError, runBA
+from .bootstrap import (bootstrap, compProjMat, matching_init, pose_estimation_init, relativeCameraPose,
+                        triangulation_init)
 from .fmatrix import draw_octets, estimateFundamentalMatrix
 from .keypoints import cornerPoints, genKeypoints
 from .klt import PointTracker, Pyramid

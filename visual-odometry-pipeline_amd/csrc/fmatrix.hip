@@ -7,8 +7,8 @@
 //   caller, who owns the RNG) -> null vector of the 8x9 system by Gaussian elimination with
 //   complete pivoting -> rank 2 by zeroing the smallest singular value (one-sided Jacobi) ->
 //   de-normalise; inlier <=> Sampson distance (pixels^2) <= threshold; winner = first trial with
-//   the largest count; trial budget shrinks to ceil(log(0.01)/log(1-(inl/n)^8)) after each
-//   improvement (Confidence 99).
+//   the largest count; trial budget shrinks to ceil(log(1-c)/log(1-(inl/n)^8)) after each
+//   improvement (c = Confidence / 100; the toolbox default is 99).
 // Kernels: fm_normalise_kernel (one workgroup, two block reductions), fm_solve_kernel (one
 // thread per trial), fm_count_kernel (one wavefront per trial, ballot/popcount), fm_mask_kernel.
 #include "vohip_internal.h"
@@ -251,13 +251,13 @@ __global__ __launch_bounds__(256) void fm_mask_kernel(const double *__restrict__
     mask[i] = sampson_inlier(F, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1], thr) ? 1 : 0;
 }
 
-double trial_budget(int inliers, int n, int num_trials)
+double trial_budget(int inliers, int n, int num_trials, double confidence)
 {
     const double r = (double)inliers / (double)n;
     const double r8 = std::pow(r, 8.0);
     if (r8 >= 1.0) return 1.0;
     if (r8 <= 0.0) return (double)num_trials;
-    const double t = std::ceil(std::log(1.0 - 0.99) / std::log(1.0 - r8));
+    const double t = std::ceil(std::log(1.0 - confidence / 100.0) / std::log(1.0 - r8));
     return t < (double)num_trials ? t : (double)num_trials;
 }
 
@@ -268,12 +268,13 @@ extern "C" {
 // d_p1, d_p2: 2 x n; d_samples 8 x num_trials; d_mask n bytes (device).  Synchronises once to
 // replay the trial budget on the host.  best_count / trials_run are host outputs.
 int vohip_fmatrix_ransac_dev(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n,
-                             const int32_t *d_samples, int num_trials, double threshold, uint8_t *d_mask,
-                             int *best_count, int *trials_run, double *F_best)
+                             const int32_t *d_samples, int num_trials, double threshold, double confidence,
+                             uint8_t *d_mask, int *best_count, int *trials_run, double *F_best)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, d_p1 && d_p2 && d_samples && d_mask && best_count, "NULL argument");
     VOHIP_REQUIRE(ctx, num_trials >= 1, "need at least one trial");
+    VOHIP_REQUIRE(ctx, confidence > 0.0 && confidence < 100.0, "confidence must lie in (0, 100)");
     *best_count = 0;
     if (trials_run) *trials_run = 0;
     if (n < 8) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "the 8-point algorithm needs 8 pairs, got %d", n);
@@ -299,7 +300,7 @@ int vohip_fmatrix_ransac_dev(vohip_ctx *ctx, const double *d_p1, const double *d
         if (c[t] > best) {
             best = c[t];
             best_t = t;
-            budget = trial_budget(best, n, num_trials);
+            budget = trial_budget(best, n, num_trials, confidence);
         }
         ++t;
     }
@@ -320,8 +321,8 @@ int vohip_fmatrix_ransac_dev(vohip_ctx *ctx, const double *d_p1, const double *d
 }
 
 int vohip_fmatrix_ransac(vohip_ctx *ctx, const double *p1, const double *p2, int n, const int32_t *samples,
-                         int num_trials, double threshold, uint8_t *mask, int *best_count, int *trials_run,
-                         double *F_best)
+                         int num_trials, double threshold, double confidence, uint8_t *mask, int *best_count,
+                         int *trials_run, double *F_best)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, p1 && p2 && samples && mask && best_count, "NULL argument");
@@ -333,7 +334,8 @@ int vohip_fmatrix_ransac(vohip_ctx *ctx, const double *p1, const double *p2, int
     VOHIP_TRY(vohip_upload(ctx, B_STAGE2, samples, sizeof(int32_t) * 8 * (size_t)num_trials, &d_s));
     VOHIP_TRY(vohip_upload(ctx, B_STAGE3, nullptr, (size_t)n, &d_mask));
     const int st = vohip_fmatrix_ransac_dev(ctx, (const double *)d_p1, (const double *)d_p2, n, (const int32_t *)d_s,
-                                            num_trials, threshold, (uint8_t *)d_mask, best_count, trials_run, F_best);
+                                            num_trials, threshold, confidence, (uint8_t *)d_mask, best_count, trials_run,
+                                            F_best);
     if (st != VOHIP_OK && st != VOHIP_NO_MODEL) return st;
     VOHIP_TRY(vohip_download(ctx, mask, d_mask, (size_t)n));
     VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -23,9 +23,9 @@ def draw_octets(rng, n, count):
 
 
 def estimateFundamentalMatrix(matchedPoints1, matchedPoints2, NumTrials=500, DistanceThreshold=0.01,
-                              Method="RANSAC", samples=None, rng=None, ctx=None):
+                              Confidence=99.0, Method="RANSAC", samples=None, rng=None, ctx=None):
     """[F, inliersIndex] = estimateFundamentalMatrix(matchedPoints1, matchedPoints2, 'Method',
-    'RANSAC', 'NumTrials', T, 'DistanceThreshold', d).  Points are N-by-2.  `samples` (T x 8,
+    'RANSAC', 'NumTrials', T, 'DistanceThreshold', d, 'Confidence', c).  Points are N-by-2.  `samples` (T x 8,
     0-based) fixes the trials; otherwise they are drawn from `rng` (numpy Generator)."""
     if Method != "RANSAC":
         raise NotImplementedError("only Method = 'RANSAC' is built (the one the pipeline uses)")
@@ -42,7 +42,7 @@ def estimateFundamentalMatrix(matchedPoints1, matchedPoints2, NumTrials=500, Dis
     best, trials = C.c_int(0), C.c_int(0)
     F = np.zeros(9)
     st = _lib.load().vohip_fmatrix_ransac(ctx.handle, dptr(p1), dptr(p2), n, s.ctypes.data_as(_lib.c_int32_p),
-                                          s.shape[0], float(DistanceThreshold), mask.ctypes.data_as(_lib.c_uint8_p),
+                                          s.shape[0], float(DistanceThreshold), float(Confidence), mask.ctypes.data_as(_lib.c_uint8_p),
                                           C.byref(best), C.byref(trials), dptr(F))
     ctx.check(st, allow=(VOHIP_NO_MODEL,))
     return F.reshape(3, 3), mask[:n].astype(bool)

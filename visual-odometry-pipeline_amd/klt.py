@@ -103,9 +103,11 @@ class PointTracker:
         self.release()
         self._prev, self._own_prev = self._as_pyramid(I)
         self._points = np.array(points, dtype=np.float64).reshape(-1, 2)
+        self._valid = np.ones(self._points.shape[0], dtype=bool)
 
     def __call__(self, I):
-        """[points, validity] = tracker(I)"""
+        """[points, validity] = tracker(I).  A point that was lost stays lost in later steps
+        (the tracker only follows valid points), until initialize() is called again."""
         if self._prev is None:
             raise RuntimeError("PointTracker: call initialize() before stepping")
         cur, own = self._as_pyramid(I)
@@ -122,7 +124,8 @@ class PointTracker:
             self._prev.release()
         self._prev, self._own_prev = cur, own
         points = out[:, :n].T.copy()
-        validity = valid[:n].astype(bool)
+        validity = valid[:n].astype(bool) & self._valid
+        self._valid = validity
         self._points = points
         self.last_fb_error = fb[:n]
         return points, validity

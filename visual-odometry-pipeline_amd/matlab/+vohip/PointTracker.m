@@ -11,6 +11,7 @@ classdef PointTracker < handle
     end
     properties (Access = private)
         Points = zeros(0, 2)
+        Valid = false(0, 1)
         PrevSlot = -1
     end
     methods
@@ -23,6 +24,7 @@ classdef PointTracker < handle
             obj.PrevSlot = vohip.PointTracker.slotFor(obj, 0);
             vohip_mex('pyramid_build', obj.PrevSlot, I, obj.NumPyramidLevels);
             obj.Points = double(points);
+            obj.Valid = true(size(points, 1), 1);
         end
         function [points, validity] = step(obj, I)
             cur = vohip.PointTracker.slotFor(obj, 1);
@@ -30,6 +32,8 @@ classdef PointTracker < handle
             e = obj.MaxBidirectionalError; if isinf(e), e = 1e300; end
             [points, validity] = vohip_mex('klt_track', obj.PrevSlot, cur, obj.Points, obj.BlockSize(1), ...
                 obj.MaxIterations, e);
+            validity = validity & obj.Valid;   % a lost point stays lost until initialize()
+            obj.Valid = validity;
             obj.Points = points;
             vohip.PointTracker.slotFor(obj, -1);   % swap roles: current becomes previous
             obj.PrevSlot = cur;

@@ -12,7 +12,7 @@ for t = 1:500
     samples(:, t) = randperm(size(p1, 1), 8)';
 end
 rng(s); rand(1);                         % leave the stream advanced, as any RANSAC call would
-[~, inl] = vohip_mex('fmatrix_ransac', double(p1), double(matched), samples, 5e-2);
+[~, inl] = vohip_mex('fmatrix_ransac', double(p1), double(matched), samples, 5e-2, 99);
 matched = matched(inl, :);
 S.F = S.F(:, valid); S.F = S.F(:, inl);
 S.T = S.T(:, valid); S.T = S.T(:, inl);

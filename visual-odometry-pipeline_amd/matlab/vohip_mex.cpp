@@ -133,7 +133,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         std::vector<uint8_t>().swap(st);
         check(rc);
     } else if (op == "fmatrix_ransac") {
-        // [F, inliers] = vohip_mex('fmatrix_ransac', p1 (n x 2), p2 (n x 2), samples 8 x T (1-based), threshold)
+        // [F, inliers] = vohip_mex('fmatrix_ransac', p1 (n x 2), p2 (n x 2), samples 8 x T (1-based), threshold, confidence)
         // MATLAB's N-by-2 matrices are [x...; y...] in memory; the library wants 2 x n, so transpose here.
         const int n = rows(in[0]), T = cols(in[2]);
         std::vector<double> a((size_t)2 * n), b((size_t)2 * n);
@@ -146,13 +146,30 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         mxArray *inl = mxCreateLogicalMatrix(n, 1);
         double F[9];
         int best = 0, trials = 0;
-        const int rc = vohip_fmatrix_ransac(c, a.data(), b.data(), n, s.data(), T, mxGetScalar(in[3]),
+        const int rc = vohip_fmatrix_ransac(c, a.data(), b.data(), n, s.data(), T, mxGetScalar(in[3]), mxGetScalar(in[4]),
                                             (uint8_t *)mxGetLogicals(inl), &best, &trials, F);
         std::vector<double>().swap(a); std::vector<double>().swap(b); std::vector<int32_t>().swap(s);
         check(rc, true);
         plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
         for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) mxGetDoubles(plhs[0])[3 * q + r] = F[3 * r + q];
         plhs[1] = inl;
+    } else if (op == "relative_pose") {
+        // [orientation, location, validFraction] = vohip_mex('relative_pose', E, K, p1 (n x 2), p2 (n x 2))
+        const int n = rows(in[2]);
+        std::vector<double> a((size_t)2 * n), b((size_t)2 * n);
+        const double *p1 = dbl(in[2], "p1"), *p2 = dbl(in[3], "p2");
+        for (int i = 0; i < n; ++i) {
+            a[2 * i] = p1[i]; a[2 * i + 1] = p1[n + i];
+            b[2 * i] = p2[i]; b[2 * i + 1] = p2[n + i];
+        }
+        plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
+        plhs[1] = mxCreateDoubleMatrix(1, 3, mxREAL);
+        double frac = 0.0;
+        const int rc = vohip_relative_pose(c, dbl(in[0], "E"), dbl(in[1], "K"), a.data(), b.data(), n,
+                                           mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]), &frac);
+        std::vector<double>().swap(a); std::vector<double>().swap(b);
+        check(rc);
+        plhs[2] = mxCreateDoubleScalar(frac);
     } else if (op == "ba_error") {
         int nobs = 0;
         std::vector<double> r((size_t)2 * numel(in[1]));

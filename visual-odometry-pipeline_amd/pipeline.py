@@ -27,7 +27,8 @@ from .ransac import ransacLocalization
 def default_hyper_paras(dataset="kitti", is_BA=False):
     """hyper_paras of main_demo.m:21-46 with the per-dataset overrides of :62-75 (kitti),
     :92-97 (malaga), :107-112 (parking); the detector is Harris (main_eval.m:168-169)."""
-    hp = SimpleNamespace(is_BA=is_BA, is_refine_pose=True, feature_extract="Harris",
+    hp = SimpleNamespace(is_BA=is_BA, is_refine_pose=True, feature_extract="Harris", init_matching_method="KLT",
+                         show_matching_res=False, sfm_pose="fundamental",
                          feature_extract_options=["MinQuality", 2e-4], min_depth=0.0, max_depth=100.0,
                          r_discard_redundant=5.0, angle_threshold=5.0)
     if dataset == "kitti":
