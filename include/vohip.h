@@ -177,6 +177,16 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
                                     double max_depth, int is_BA, uint8_t *d_status, double *d_X,
                                     double *d_angles);
 
+/* ---- trajectory alignment (evaluation) ---------------------------------------------------------
+ * utils/exe9_BA/alignEstimateToGroundTruth.m:1-27 with the residual of alignError.m:1-17, as
+ * utils/quantitative_eval.m:23-24 calls it: finds x = [twist of T_G_V (v; w); scale] minimising
+ * |pp_G_C - (scale * R * p_V_C + t)|^2 from the identity twist and scale 1, and returns the aligned
+ * points p_G_C.  pp_G_C, p_V_C, p_G_C 3xn column-major; x[7] and stats[3] = {iterations, initial
+ * cost, final cost} may be NULL.  The reference's lsqnonlin call is replaced by the
+ * Levenberg-Marquardt of vohip_pose_refine with analytic Jacobians. */
+int vohip_align_sim3(vohip_ctx *ctx, const double *pp_G_C, const double *p_V_C, int n, int max_iter, double ftol,
+                     double xtol, double *x, double *p_G_C, double *stats);
+
 /* ---- relative pose (bootstrap) ---------------------------------------------------------------
  * Stands in for [orientation, location] = relativeCameraPose(E, cameraParams, pts1, pts2) at
  * Initialization/pose_estimation_init.m:29-33 (decomposition as in

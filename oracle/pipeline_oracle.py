@@ -290,3 +290,28 @@ def bootstrap(img0, img_seqs, K, hp, draw_octets, rng):
     if hp.is_refine_pose:
         T_init_WC, _ = orc.pose_refine(T_init_WC, keypoints.T, p_W_landmarks.T, K)
     return p_W_landmarks, keypoints, T_init_WC
+
+
+# ---- evaluation (utils/quantitative_eval.m) -------------------------------------------------------
+
+def quantitative_eval(ground_truth, est_trans, bootstrap_frames):
+    """utils/quantitative_eval.m:5-63 without the plotting: errs 3 x k."""
+    gt = np.asarray(ground_truth, dtype=np.float64)
+    est = np.asarray(est_trans, dtype=np.float64)
+    T = est.shape[1]
+    b2 = int(bootstrap_frames[1])
+    GT = gt[b2:b2 + T].T                                                    # :5
+    GT = np.vstack([GT[0], np.zeros(T), GT[1]])                             # :6
+    d = np.linalg.norm(GT[:, 1:] - GT[:, :-1], axis=0)                      # :9
+    cps = [c * 0.2 for c in (10, 40, 90, 160, 250, 360)]                    # :11-12
+    errs = []
+    cur, nxt = 0.0, cps.pop(0)                                              # :15-17
+    for i in range(1, T):                                                   # :20, i as in MATLAB
+        cur += d[i - 1]                                                     # :21
+        if cur > nxt:                                                       # :22
+            aligned, _, _ = orc.align_sim3(GT[:, :i], est[:, :i])           # :23-24
+            errs.append(np.abs((aligned[:, -1] - aligned[:, 0]) - (GT[:, i - 1] - GT[:, 0])))   # :25-27
+            if not cps:                                                     # :53-61
+                break
+            nxt = cps.pop(0)
+    return np.array(errs).T.reshape(3, -1)

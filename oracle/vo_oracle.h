@@ -134,6 +134,14 @@ int vo_decompose_essential(const double E[9], double R[2][9], double u3[3]);
 int vo_relative_pose(const double E[9], const double K[9], const double *p1, const double *p2, int n,
                      double orientation[9], double location[3], double *valid_fraction);
 
+/* ---- align_oracle.c ------------------------------------------------------------------------ */
+
+/* utils/exe9_BA/alignError.m:1-17. */
+void vo_align_error(const double x[7], const double *pp_G_C, const double *p_V_C, int n, double *error);
+/* utils/exe9_BA/alignEstimateToGroundTruth.m:1-27 with this project's Levenberg-Marquardt. */
+void vo_align_sim3(const double *pp_G_C, const double *p_V_C, int n, int max_iter, double ftol, double xtol,
+                   double x_out[7], double *p_G_C, double *stats);
+
 /* ---- harris_oracle.c ------------------------------------------------------------------- */
 
 /* This project's definition of the corner detector that stands in for detectHarrisFeatures /

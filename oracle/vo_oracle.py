@@ -296,6 +296,30 @@ def pose_refine(T_W_C, kp_uv, X, K, max_iter=100, ftol=1e-10, xtol=1e-10):
     return T.reshape(4, 4).T.copy(), dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2])
 
 
+# ---- trajectory alignment (evaluation) ----------------------------------------------------------
+
+def align_error(x, gt, est):
+    """x (7,), gt / est 3xn.  Returns the 3n error vector of alignError.m."""
+    g = _f64(np.asarray(gt).T)
+    e = _f64(np.asarray(est).T)
+    out = np.zeros(3 * g.shape[0])
+    lib().vo_align_error(_d(_f64(np.asarray(x).reshape(-1))), _d(g), _d(e), C.c_int(g.shape[0]), _d(out))
+    return out
+
+
+def align_sim3(gt, est, max_iter=100, ftol=1e-10, xtol=1e-10):
+    """gt, est 3xn.  Returns (aligned 3xn, x (7,), stats dict)."""
+    g = _f64(np.asarray(gt).T)
+    e = _f64(np.asarray(est).T)
+    n = g.shape[0]
+    x = np.zeros(7)
+    out = np.zeros((n, 3))
+    stats = np.zeros(3)
+    lib().vo_align_sim3(_d(g), _d(e), C.c_int(n), C.c_int(max_iter), C.c_double(ftol), C.c_double(xtol), _d(x), _d(out),
+                        _d(stats))
+    return out.T.copy(), x, dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2])
+
+
 # ---- relative pose (bootstrap) -----------------------------------------------------------------
 
 def relative_pose(E, K, p1, p2):

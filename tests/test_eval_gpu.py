@@ -1,0 +1,66 @@
+"""Parity of the HIP trajectory alignment and of the evaluation built on it with the CPU oracle, and
+the stand-alone run (bootstrap -> continuous operation -> evaluation -> result file).
+Bar: aligned points and checkpoint errors within 1e-6 m (the GPU uses analytic Jacobians, the
+oracle central differences; both stop at the same minimum to that accuracy)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _trajectory(vo, n, seed, noise=0.02):
+    rng = np.random.default_rng(seed)
+    est = np.cumsum(np.vstack([rng.normal(0, 0.05, n), rng.normal(0, 0.01, n), np.full(n, 0.5)]), axis=1)
+    R = vo.synth.rotation_from_rotvec(rng.normal(size=3) * 0.3)
+    s, t = 1.7 + 0.2 * rng.normal(), rng.normal(size=(3, 1)) * 2
+    return s * R @ est + t + rng.normal(size=(3, n)) * noise, est
+
+
+@pytest.mark.parametrize("n,seed", [(4, 0), (40, 1), (255, 2), (540, 3), (3000, 4)])
+def test_alignment_matches_oracle(vo, ctx, oracle, n, seed):
+    gt, est = _trajectory(vo, n, seed)
+    want, xw, sw = oracle.align_sim3(gt, est)
+    got, xg, sg = vo.alignEstimateToGroundTruth(gt, est, return_x=True, ctx=ctx)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(xg, xw, rtol=0, atol=1e-6)
+    assert abs(sg["cost"] - sw["cost"]) < 1e-9 * (1 + sw["cost"])
+    assert sg["cost0"] == pytest.approx(sw["cost0"], rel=1e-12)
+    # alignError of the mirror agrees with the oracle's
+    np.testing.assert_allclose(vo.alignError(xg, gt, est, ctx=ctx), oracle.align_error(xg, gt, est), atol=1e-12)
+
+
+def test_quantitative_eval_matches_oracle(vo, ctx, oracle):
+    from types import SimpleNamespace
+    from oracle import pipeline_oracle as po
+    n = 210
+    z = np.arange(n) * 0.5
+    gt_xz = np.stack([0.05 * z * np.sin(z / 15), z], axis=1)
+    GT3 = np.vstack([gt_xz[2:, 0], np.zeros(n - 2), gt_xz[2:, 1]])
+    rng = np.random.default_rng(0)
+    est = (GT3 - GT3[:, :1]) / 2.5 + np.cumsum(rng.normal(size=(3, n - 2)) * 0.004, axis=1)
+    want = po.quantitative_eval(gt_xz, est, (0, 2))
+    got = vo.quantitative_eval(gt_xz, SimpleNamespace(est_trans=est), (0, 2), ctx=ctx)
+    assert got.shape == want.shape == (3, 6)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    # a short run passes fewer checkpoints
+    short = vo.quantitative_eval(gt_xz, SimpleNamespace(est_trans=est[:, :30]), (0, 2), ctx=ctx)
+    assert short.shape == (3, 2)
+
+
+def test_run_sequence_writes_the_result_file(vo, ctx, tmp_path):
+    K = np.array([[400.0, 0, 320], [0, 400.0, 120], [0, 0, 1]])
+    scene = vo.synth.CorridorScene(K=K, width=640, height=240)
+    poses = vo.synth.corridor_trajectory(14, step=0.5)
+    frames = [scene.render(T) for T in poses]
+    gt_xz = np.array([[T[0, 3], T[2, 3]] for T in poses])
+    hp = vo.default_hyper_paras("kitti")
+    out = vo.run_sequence(frames, K, hp, ground_truth=gt_xz, bootstrap_frames=(0, 2), dataset="corridor",
+                          save_dir=str(tmp_path), rng=np.random.default_rng(5), ctx=ctx)
+    assert out["frame_ct"] == 11 and out["frame_init"] == 3
+    assert out["S"].est_trans.shape == (3, 12)          # bootstrap pose + 11 frames
+    assert out["errs"].shape[0] == 3 and out["errs"].shape[1] >= 1      # 5.5 m travelled: the 2 m checkpoint
+    assert np.all(out["errs"] < 0.5)
+    back = vo.load_results(out["path"])
+    np.testing.assert_array_equal(back["S"]["est_trans"], out["S"].est_trans)
+    np.testing.assert_array_equal(back["errs"], out["errs"])
+    assert back["fps_ct"] == pytest.approx(out["fps_ct"]) and back["frame_ct"] == 11.0

@@ -66,6 +66,8 @@ SIGNATURES = {
     "vohip_candidate_triangulate": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int,
                                                c_double_p, c_double_p, C.c_double, C.c_double, C.c_double,
                                                C.c_int, c_uint8_p, c_double_p, c_double_p]),
+    "vohip_align_sim3": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                    c_double_p, c_double_p, c_double_p]),
     "vohip_relative_pose": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int,
                                        c_double_p, c_double_p, c_double_p]),
     "vohip_fmatrix_ransac": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, c_int32_p, C.c_int, C.c_double,

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's evaluation and result files:
+
+  alignError                    utils/exe9_BA/alignError.m:1-17
+  alignEstimateToGroundTruth    utils/exe9_BA/alignEstimateToGroundTruth.m:1-27
+  quantitative_eval             utils/quantitative_eval.m:1-70 (the plotting at :29-50 is left out)
+  experiment_name, save_results main_demo.m:453-463 and the save call at :473-476
+  run_sequence                  the stand-alone run of main_demo.m:249-476 / one item of
+                                main_eval.m:22-23: bootstrap, continuous operation, timing,
+                                evaluation, result file
+
+The alignment's non-linear least squares runs in libvohip.so on the GPU.  The result file is a
+MAT v5 file with the key set the reference saves, which is what its evaluation notebook reads
+(errs, fps_ct, frame_ct, toc_ct, S).
+"""
+import datetime
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import colmajor, dptr
+from .geometry import twist2HomogMatrix
+
+ALIGN_MAX_ITER = 100
+DIST_CHECKPOINTS = np.array([10.0, 40.0, 90.0, 160.0, 250.0, 360.0]) * 0.2   # quantitative_eval.m:11-12
+
+
+def alignError(x, pp_G_C, p_V_C, ctx=None):
+    """error = alignError(x, pp_G_C, p_V_C): x = [twist; scale], points 3xN -> 3N-vector."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    T_G_V = twist2HomogMatrix(x[:6], ctx=ctx)
+    p_G_C = x[6] * T_G_V[:3, :3] @ np.asarray(p_V_C, dtype=np.float64) + T_G_V[:3, 3:4]
+    return (np.asarray(pp_G_C, dtype=np.float64) - p_G_C).reshape(-1, order="F")
+
+
+def alignEstimateToGroundTruth(pp_G_C, p_V_C, return_x=False, ctx=None):
+    """p_G_C = alignEstimateToGroundTruth(pp_G_C, p_V_C): the estimated trajectory p_V_C (3xN)
+    under the similarity transform that best maps it onto the ground truth pp_G_C (3xN)."""
+    ctx = ctx or _lib.default_context()
+    g = colmajor(np.asarray(pp_G_C, dtype=np.float64).reshape(3, -1))
+    e = colmajor(np.asarray(p_V_C, dtype=np.float64).reshape(3, -1))
+    if g.shape != e.shape:
+        raise ValueError("trajectories differ in length")
+    n = g.shape[0]
+    x = np.zeros(7)
+    out = np.zeros((max(n, 1), 3))
+    stats = np.zeros(3)
+    ctx.check(_lib.load().vohip_align_sim3(ctx.handle, dptr(g), dptr(e), n, ALIGN_MAX_ITER, 1e-10, 1e-10, dptr(x),
+                                           dptr(out), dptr(stats)))
+    p_G_C = out[:n].T.copy()
+    if return_x:
+        return p_G_C, x, dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2])
+    return p_G_C
+
+
+def quantitative_eval(ground_truth, S, bootstrap_frames, save_name=None, ctx=None):
+    """errs = quantitative_eval(ground_truth, S, bootstrap_frames, save_name): ground_truth is the
+    N-by-2 (x, z) table the scripts build, S.est_trans 3xT.  errs is 3-by-k, one column per distance
+    checkpoint passed (k <= 6).  save_name only names the figure in the reference and is unused."""
+    gt = np.asarray(ground_truth, dtype=np.float64)
+    est = np.asarray(S.est_trans, dtype=np.float64)
+    T = est.shape[1]
+    b2 = int(bootstrap_frames[1])
+    GT = gt[b2:b2 + T].T                                                    # :5
+    if GT.shape[1] != T:
+        raise ValueError("ground truth has %d rows after the bootstrap frame, the estimate %d" % (GT.shape[1], T))
+    GT = np.vstack([GT[0], np.zeros(T), GT[1]])                             # :6
+    dist = np.linalg.norm(GT[:, 1:] - GT[:, :-1], axis=0)                   # :9
+    checkpoints = list(DIST_CHECKPOINTS)
+    errs = np.zeros((3, 0))
+    current = 0.0
+    nxt = checkpoints.pop(0)                                                # :16-17
+    for i in range(1, T):                                                   # :20 (1-based i)
+        current += dist[i - 1]
+        if current > nxt:
+            aligned = alignEstimateToGroundTruth(GT[:, :i], est[:, :i], ctx=ctx)        # :23-24
+            replacement_gt = GT[:, i - 1] - GT[:, 0]
+            replacement_est = aligned[:, -1] - aligned[:, 0]
+            errs = np.hstack([errs, np.abs(replacement_est - replacement_gt).reshape(3, 1)])   # :27
+            if not checkpoints:                                             # :53-61
+                break
+            nxt = checkpoints.pop(0)
+    return errs
+
+
+def experiment_name(dataset, hyper_paras, now=None):
+    """main_demo.m:455-462: 'dataset@<name>_feat@<method>_time@HH_mm_ss[_NoRefined]'."""
+    now = now or datetime.datetime.now()
+    name = "dataset@%s_feat@%s_time@%s" % (dataset, hyper_paras.feature_extract, now.strftime("%H_%M_%S"))
+    if not hyper_paras.is_refine_pose:
+        name += "_NoRefined"
+    return name
+
+
+def _state_struct(S):
+    col = lambda a: np.asarray(a, dtype=np.float64).reshape(-1, 1)          # noqa: E731
+    return dict(P=S.P, X=S.X, C=S.C, F=S.F, T=S.T, est_trans=S.est_trans, est_rot=S.est_rot, num_X=col(S.num_X),
+                num_C=col(S.num_C), num_new=col(S.num_new))
+
+
+def save_results(save_name, errs, S, total_time, frame_init, frame_ct, toc_param, toc_bootstrap, toc_ct, fps_ct):
+    """save([save_name '_res.mat'], 'errs', 'S', 'total_time', 'frame_init', 'frame_ct',
+    'toc_param', 'toc_bootstrap', 'toc_ct', 'fps_ct') -- main_demo.m:473-476."""
+    from scipy.io import savemat
+    path = save_name + "_res.mat"
+    mat = dict(S=_state_struct(S), total_time=float(total_time), frame_init=float(frame_init),
+               frame_ct=float(frame_ct), toc_param=float(toc_param), toc_bootstrap=float(toc_bootstrap),
+               toc_ct=float(toc_ct), fps_ct=float(fps_ct))
+    if errs is not None:
+        mat["errs"] = np.asarray(errs, dtype=np.float64)
+    savemat(path, mat, oned_as="column")
+    return path
+
+
+def load_results(path):
+    """The saved variables as a dict (S as a dict of arrays)."""
+    from scipy.io import loadmat
+    raw = loadmat(path, squeeze_me=False, struct_as_record=True)
+    out = {k: v for k, v in raw.items() if not k.startswith("__")}
+    if "S" in out:
+        s = out["S"][0, 0]
+        out["S"] = {name: s[name] for name in s.dtype.names}
+    for k in ("total_time", "frame_init", "frame_ct", "toc_param", "toc_bootstrap", "toc_ct", "fps_ct"):
+        if k in out:
+            out[k] = float(np.asarray(out[k]).reshape(-1)[0])
+    return out
+
+
+def run_sequence(images, K, hyper_paras, ground_truth=None, bootstrap_frames=(0, 2), dataset="synthetic",
+                 save_dir=None, rng=None, ctx=None, window_size=3, keyframe_d=2, now=None):
+    """One full run as main_demo.m:249-476 does it: bootstrap on images[b1..b2], continuous
+    operation on the remaining images, timing, evaluation against ground_truth (N-by-2 (x, z) table,
+    optional) and, when save_dir is given, the '<experiment>_res.mat' file.
+    Returns a dict with the saved variables plus 'S' (the final state) and 'path'."""
+    from .bootstrap import bootstrap
+    from .pipeline import VOPipeline
+    ctx = ctx or _lib.default_context()
+    rng = rng or np.random.default_rng()
+    t_param = time.perf_counter()
+    b1, b2 = int(bootstrap_frames[0]), int(bootstrap_frames[1])
+    K = np.asarray(K, dtype=np.float64)
+    toc_param = time.perf_counter() - t_param
+    t_boot = time.perf_counter()                                            # :162
+    img0 = images[b1]
+    img_seqs = list(images[b1 + 1:b2 + 1])                                  # :173-179
+    p_W_landmarks, keypoints, T_init_WC = bootstrap(img0, img_seqs, K, hyper_paras, rng=rng, ctx=ctx)   # :252-264
+    toc_bootstrap = time.perf_counter() - t_boot                            # :266
+    t_ct = time.perf_counter()                                              # :270
+    pipe = VOPipeline(K, img_seqs[-1], p_W_landmarks, keypoints, T_init_WC, hyper_paras=hyper_paras,
+                      window_size=window_size, keyframe_d=keyframe_d, rng=rng, ctx=ctx)
+    frame_range = range(b2 + 1, len(images))                                # :351
+    for i in frame_range:
+        pipe.process_frame(images[i])
+    toc_ct = time.perf_counter() - t_ct                                     # :446
+    S = pipe.S
+    pipe.close()
+    frame_init = len(img_seqs) + 1                                          # :447
+    frame_ct = len(frame_range)                                             # :448
+    fps_ct = frame_ct / toc_ct if toc_ct > 0 else 0.0                       # :449
+    total_time = toc_param + toc_bootstrap + toc_ct                         # :451
+    errs = None
+    if ground_truth is not None:                                            # :465-471
+        errs = quantitative_eval(ground_truth, S, (b1, b2), ctx=ctx)
+    out = dict(errs=errs, S=S, total_time=total_time, frame_init=frame_init, frame_ct=frame_ct, toc_param=toc_param,
+               toc_bootstrap=toc_bootstrap, toc_ct=toc_ct, fps_ct=fps_ct, path=None)
+    if save_dir is not None:
+        import os
+        os.makedirs(save_dir, exist_ok=True)
+        out["path"] = save_results(os.path.join(save_dir, experiment_name(dataset, hyper_paras, now)), errs, S,
+                                   total_time, frame_init, frame_ct, toc_param, toc_bootstrap, toc_ct, fps_ct)
+    return out

@@ -153,6 +153,13 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
         for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) mxGetDoubles(plhs[0])[3 * q + r] = F[3 * r + q];
         plhs[1] = inl;
+    } else if (op == "align_sim3") {
+        // [p_G_C, x] = vohip_mex('align_sim3', pp_G_C 3xN, p_V_C 3xN)
+        const int n = cols(in[0]);
+        plhs[0] = mxCreateDoubleMatrix(3, n, mxREAL);
+        plhs[1] = mxCreateDoubleMatrix(7, 1, mxREAL);
+        check(vohip_align_sim3(c, dbl(in[0], "pp_G_C"), dbl(in[1], "p_V_C"), n, 100, 1e-10, 1e-10,
+                               mxGetDoubles(plhs[1]), mxGetDoubles(plhs[0]), nullptr));
     } else if (op == "relative_pose") {
         // [orientation, location, validFraction] = vohip_mex('relative_pose', E, K, p1 (n x 2), p2 (n x 2))
         const int n = rows(in[2]);
