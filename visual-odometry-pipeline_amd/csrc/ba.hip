@@ -28,6 +28,7 @@
 // (block-wide fp64 reductions of the 6x6 normal equations, Cholesky by one lane).
 #include "vohip_internal.h"
 #include "se3_device.h"
+#include "wave_reduce.h"
 
 #include <vector>
 
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
                                                                  double *__restrict__ stats /*3*/)
 {
     __shared__ frame_lin sF, sFn;
-    __shared__ double sTw[6], sTwN[6], sH[36], sG[6], sD[6], sWave[16];
+    __shared__ double sTw[6], sTwN[6], sH[36], sG[6], sD[6], sWave[16], sPart[27 * (PR_THREADS / 64)];
     __shared__ int sOk;
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -612,16 +613,36 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
                 for (int b = a; b < 6; ++b) h[q++] += Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b];
             }
         }
+        // all 27 sums at once: DPP wave sums, one row of partials per wave, one barrier
         {
-            int q = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int b = a; b < 6; ++b) {
-                    const double s = block_sum(h[q++], sWave);
-                    if (tid == 0) sH[6 * a + b] = sH[6 * b + a] = s;
+#pragma unroll
+            for (int q = 0; q < 21; ++q) h[q] = wave_sum_f64(h[q]);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) g[q] = wave_sum_f64(g[q]);
+            __syncthreads();
+            if ((tid & 63) == 0) {
+                double *row = sPart + 27 * (tid >> 6);
+#pragma unroll
+                for (int q = 0; q < 21; ++q) row[q] = h[q];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) row[21 + q] = g[q];
+            }
+            __syncthreads();
+            if (tid < 27) {
+                double s = 0.0;
+                for (int w = 0; w < PR_THREADS / 64; ++w) s += sPart[27 * w + tid];
+                if (tid < 21) {
+                    // upper-triangle index -> (a, b)
+                    int a = 0, rem = tid;
+                    while (rem >= 6 - a) {
+                        rem -= 6 - a;
+                        ++a;
+                    }
+                    const int b = a + rem;
+                    sH[6 * a + b] = sH[6 * b + a] = s;
+                } else {
+                    sG[tid - 21] = s;
                 }
-            for (int a = 0; a < 6; ++a) {
-                const double s = block_sum(g[a], sWave);
-                if (tid == 0) sG[a] = s;
             }
         }
         __syncthreads();

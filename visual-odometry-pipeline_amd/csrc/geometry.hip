@@ -80,43 +80,41 @@ __global__ __launch_bounds__(128) void triangulate_refine_kernel(const double *_
     P[4 * (size_t)j + 3] = P_init[4 * (size_t)j + 3];
 }
 
-// update_candidate.m:14-24.  One thread per new detection; the existing points (S.C then S.P,
-// rounded to single exactly as MATLAB's single/double comparison does) are streamed through
-// LDS in tiles shared by the workgroup.
-constexpr int FILTER_TILE = 1024;
+// update_candidate.m:14-24.  One wavefront per new detection; its lanes stride over the existing
+// points (S.C then S.P, rounded to single exactly as MATLAB's single/double comparison does) and a
+// ballot ends the search at the first hit.
 __global__ __launch_bounds__(256) void candidate_filter_kernel(const float *__restrict__ new_xy, int n_new,
                                                                const double *__restrict__ C_rc, int nC,
                                                                const double *__restrict__ P_rc, int nP,
                                                                float r, uint8_t *__restrict__ keep)
 {
-    __shared__ float2 tile[FILTER_TILE];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n_new;
-    float x = 0.f, y = 0.f;
-    if (live) {
-        x = new_xy[i];
-        y = new_xy[n_new + i];
-    }
+    // one wavefront per new point: the lanes stride over C and then P, 4 loads in flight each
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (i >= n_new) return;
+    const float x = new_xy[i], y = new_xy[n_new + i];
     const float u0 = x - r, u1 = x + r, v0 = y - r, v1 = y + r;
     bool near = false;
     const int total = nC + nP;
-    for (int base = 0; base < total; base += FILTER_TILE) {
-        const int tn = min(FILTER_TILE, total - base);
-        __syncthreads();
-        for (int k = threadIdx.x; k < tn; k += blockDim.x) {
-            const int g = base + k;
-            const double *src = g < nC ? C_rc + 2 * (size_t)g : P_rc + 2 * (size_t)(g - nC);
-            tile[k] = make_float2((float)src[1], (float)src[0]);  // (u = col, v = row)
+    for (int base = 0; base < total; base += 256) {
+        double qr[4], qc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = base + 64 * u + lane;
+            const int gg = g < total ? g : 0;
+            const double *src = gg < nC ? C_rc + 2 * (size_t)gg : P_rc + 2 * (size_t)(gg - nC);
+            qr[u] = src[0];
+            qc[u] = src[1];
         }
-        __syncthreads();
-        if (live && !near) {
-            for (int k = 0; k < tn; ++k) {
-                const float2 q = tile[k];
-                near = near || (q.x >= u0 && q.x <= u1 && q.y >= v0 && q.y <= v1);
-            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float qx = (float)qc[u], qy = (float)qr[u];  // (u = col, v = row)
+            near = near || (base + 64 * u + lane < total && qx >= u0 && qx <= u1 && qy >= v0 && qy <= v1);
         }
+        if (__ballot(near)) break;
     }
-    if (live) keep[i] = (nC == 0) ? 1 : (near ? 0 : 1);
+    const bool any = __ballot(near) != 0ull;
+    if (lane == 0) keep[i] = (nC == 0) ? 1 : (any ? 0 : 1);
 }
 
 struct cand_params {
@@ -243,7 +241,7 @@ int vohip_candidate_filter_dev(vohip_ctx *ctx, const float *d_new_xy, int n_new,
     VOHIP_REQUIRE(ctx, n_new >= 0 && nC >= 0 && nP >= 0 && d_keep, "bad argument");
     VOHIP_REQUIRE(ctx, (n_new == 0 || d_new_xy) && (nC == 0 || d_C_rc) && (nP == 0 || d_P_rc), "NULL array");
     if (n_new == 0) return VOHIP_OK;
-    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new + 255) / 256), dim3(256), 0, ctx->stream, d_new_xy,
+    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new + 3) / 4), dim3(256), 0, ctx->stream, d_new_xy,
                        n_new, d_C_rc, nC, d_P_rc, nP, (float)r, d_keep);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;

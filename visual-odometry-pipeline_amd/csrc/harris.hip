@@ -15,8 +15,8 @@
 //                           fixed order without FMA contraction (bit-reproducible).
 //   corner_nms_kernel       threshold + 3x3 strict maximum -> one bit per pixel; every wavefront
 //                           owns one 64-bit bitmap word (ballot), so there are no atomics.
-//   corner_emit_kernel      one workgroup: popcount + block scan over the bitmap = ordered,
-//                           deterministic compaction; sub-pixel refinement; output.
+//   corner_emit_kernel      popcount prefix + block scan over the bitmap = ordered, deterministic
+//                           compaction; sub-pixel refinement; output.
 #include "vohip_internal.h"
 
 #include <cmath>
@@ -141,22 +141,28 @@ __global__ __launch_bounds__(256) void corner_nms_kernel(const float *__restrict
     if ((threadIdx.x & 63) == 0 && (idx & ~63) < A * B) bitmap[idx >> 6] = m;
 }
 
-// One workgroup of 1024 threads walks the bitmap in index order: popcount per thread chunk,
-// block-wide exclusive scan, then every set bit is written at its rank -- a deterministic,
-// sorted compaction.  Sub-pixel position (x, y 1-based; swap_xy as in the tracker) and metric.
-__global__ __launch_bounds__(1024) void corner_emit_kernel(const float *__restrict__ R, int A, int B,
-                                                           const unsigned long long *__restrict__ bitmap, int cap,
-                                                           int swap_xy, float *__restrict__ xy_out,
-                                                           float *__restrict__ metric_out, int *__restrict__ count)
+// Ordered, deterministic compaction of the corner bitmap.  Thread t of workgroup g owns bitmap word
+// 256 g + t.  Every workgroup first sums the popcounts of all words before its own (a redundant
+// but cheap read of at most the whole bitmap from L2; no inter-workgroup hand-off), then scans its
+// own 256 counts, and every thread writes the corners of its word at their ranks: sub-pixel
+// position (x, y 1-based; swap_xy as in the tracker) and metric.  The last workgroup stores the
+// total.
+__global__ __launch_bounds__(256) void corner_emit_kernel(const float *__restrict__ R, int A, int B,
+                                                          const unsigned long long *__restrict__ bitmap, int cap,
+                                                          int swap_xy, float *__restrict__ xy_out,
+                                                          float *__restrict__ metric_out, int *__restrict__ count)
 {
-    __shared__ int sWave[16];
+    __shared__ int sPre[4], sWave[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwords = (A * B + 63) / 64;
-    const int per = (nwords + 1023) / 1024;
-    const int w0 = tid * per, w1 = min(w0 + per, nwords);
-    int c = 0;
-    for (int w = w0; w < w1; ++w) c += __popcll(bitmap[w]);
-    // inclusive scan within the wave
+    const int first = blockIdx.x * 256;
+    int before = 0;
+    for (int w = tid; w < first; w += 256) before += __popcll(bitmap[w]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) before += __shfl_xor(before, m, 64);
+    const int w = first + tid;
+    unsigned long long m = w < nwords ? bitmap[w] : 0ull;
+    const int c = __popcll(m);
     int incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -164,41 +170,31 @@ __global__ __launch_bounds__(1024) void corner_emit_kernel(const float *__restri
         if (lane >= d) incl += t;
     }
     if (lane == 63) sWave[wave] = incl;
+    if (lane == 0) sPre[wave] = before;
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int w = 0; w < 16; ++w) {
-            const int t = sWave[w];
-            sWave[w] = run;
-            run += t;
+    int pos = sPre[0] + sPre[1] + sPre[2] + sPre[3] + incl - c;
+    for (int q = 0; q < wave; ++q) pos += sWave[q];
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) *count = pos + c;
+    while (m) {
+        const int bit = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (pos < cap) {
+            const int key = w * 64 + bit;
+            const int b = key / A, a = key - b * A;
+            const float *cc = R + key;
+            const float r = cc[0];
+            const float da = cc[1] - cc[-1], dda = (cc[1] - 2.0f * r) + cc[-1];
+            const float db = cc[A] - cc[-A], ddb = (cc[A] - 2.0f * r) + cc[-A];
+            float oa = dda < 0.0f ? -0.5f * da / dda : 0.0f;
+            float ob = ddb < 0.0f ? -0.5f * db / ddb : 0.0f;
+            oa = fminf(fmaxf(oa, -0.5f), 0.5f);
+            ob = fminf(fmaxf(ob, -0.5f), 0.5f);
+            const float pa = (float)a + oa + 1.0f, pb = (float)b + ob + 1.0f;
+            xy_out[pos] = swap_xy ? pb : pa;
+            xy_out[cap + pos] = swap_xy ? pa : pb;
+            metric_out[pos] = r;
         }
-        *count = run;
-    }
-    __syncthreads();
-    int pos = sWave[wave] + incl - c;
-    for (int w = w0; w < w1; ++w) {
-        unsigned long long m = bitmap[w];
-        while (m) {
-            const int bit = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (pos < cap) {
-                const int key = w * 64 + bit;
-                const int b = key / A, a = key - b * A;
-                const float *cc = R + key;
-                const float r = cc[0];
-                const float da = cc[1] - cc[-1], dda = (cc[1] - 2.0f * r) + cc[-1];
-                const float db = cc[A] - cc[-A], ddb = (cc[A] - 2.0f * r) + cc[-A];
-                float oa = dda < 0.0f ? -0.5f * da / dda : 0.0f;
-                float ob = ddb < 0.0f ? -0.5f * db / ddb : 0.0f;
-                oa = fminf(fmaxf(oa, -0.5f), 0.5f);
-                ob = fminf(fmaxf(ob, -0.5f), 0.5f);
-                const float pa = (float)a + oa + 1.0f, pb = (float)b + ob + 1.0f;
-                xy_out[pos] = swap_xy ? pb : pa;
-                xy_out[cap + pos] = swap_xy ? pa : pb;
-                metric_out[pos] = r;
-            }
-            ++pos;
-        }
+        ++pos;
     }
 }
 
@@ -249,7 +245,7 @@ int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int
     const int lo = border < 1 ? 1 : border;
     hipLaunchKernelGGL(corner_nms_kernel, dim3((A * B + 255) / 256), dim3(256), 0, st, (const float *)d_R, A, B, lo,
                        (float)min_quality, (const unsigned *)d_max, (unsigned long long *)d_bitmap);
-    hipLaunchKernelGGL(corner_emit_kernel, dim3(1), dim3(1024), 0, st, (const float *)d_R, A, B,
+    hipLaunchKernelGGL(corner_emit_kernel, dim3((nwords + 255) / 256), dim3(256), 0, st, (const float *)d_R, A, B,
                        (const unsigned long long *)d_bitmap, cap, colmajor ? 1 : 0, d_xy, d_metric, d_count);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
