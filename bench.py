@@ -6,7 +6,8 @@ python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch
 Workload (N = 1): the per-frame continuous-operation loop on a rendered KITTI-shape sequence
 (1241 x 376, ~2k tracked keypoints, Harris MinQuality 2e-4, 21x21 / 5-level KLT, adaptive P3P
 RANSAC, pose refinement, F-matrix filter, triangulation, candidate filter; no BA) -- one step = one
-frame, frames resident in HBM before the timed region.  N > 1: every rank runs its own replica of
+frame, frames resident in HBM before the timed region; the loop state stays on the GPU
+(VOPipelineDevice over the vohip_frame_* entry points).  N > 1: every rank runs its own replica of
 that sequence (the reference's batch mode, main_eval.m:22-23, shards independent runs) and the
 trajectory records are gathered with one all_gather (RCCL) inside the timed region.
 
@@ -60,8 +61,8 @@ def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barr
     d_frames = [torch.from_numpy(f).to(dev) for f in frames[:warmup + steps + 1]]
     X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
     hp = vo.default_hyper_paras("kitti", is_BA=False)
-    pipe = vo.VOPipeline(vo.synth.K_KITTI, d_frames[0], X0, xy0, poses[0], hyper_paras=hp,
-                         rng=np.random.default_rng(seed), ctx=ctx)
+    pipe = vo.VOPipelineDevice(vo.synth.K_KITTI, d_frames[0], X0, xy0, poses[0], hyper_paras=hp,
+                               rng=np.random.default_rng(seed), ctx=ctx)
     for i in range(1, warmup + 1):
         pipe.process_frame(d_frames[i])
     barrier()
@@ -72,8 +73,8 @@ def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barr
     barrier()
     elapsed = time.perf_counter() - t0
     last = warmup + steps
-    T = pipe.S.est_trans[:, -1]
-    info = dict(n_landmarks=int(np.mean(pipe.S.num_X[-steps:])), n_candidates=int(np.mean(pipe.S.num_C[-steps:])),
+    T = pipe.est_trans[-1]
+    info = dict(n_landmarks=int(np.mean(pipe.num_X[-steps:])), n_candidates=int(np.mean(pipe.num_C[-steps:])),
                 final_position_error_m=float(np.linalg.norm(T - poses[last][:3, 3])), records=len(records))
     pipe.close()
     return elapsed, info
@@ -172,7 +173,7 @@ def main():
 
         def gather(pipe, seconds):
             et, er = pipe.trajectory()
-            rec = vo.batch.pack_record(rank, seconds, et, er, pipe.S.num_X, pipe.S.num_C, pipe.S.num_new)
+            rec = vo.batch.pack_record(rank, seconds, et, er, pipe.num_X, pipe.num_C, pipe.num_new)
             return vo.batch.gather_records([rec], world, device=torch.device("cuda", local_rank) if world > 1 else None)
 
         n_frames = args.warmup + args.steps + 1

@@ -177,6 +177,76 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
                                     double max_depth, int is_BA, uint8_t *d_status, double *d_X,
                                     double *d_angles);
 
+/* ---- the frame loop with device-resident state -------------------------------------------------
+ * The loop body main_demo.m:377-427 (is_BA = false) as three calls per frame.  S.P, S.X, S.C, S.F
+ * and S.T (main_demo.m:272-279) stay in GPU memory between frames; the stages are the kernels behind
+ * the entry points above, chained through device-side counts, so the state after each frame is the
+ * one the stage-by-stage calls produce (genKeypoints.m, ransacLocalization.m, T_refinement.m,
+ * update_landmarks.m, update_candidate.m).  Bundle adjustment is not part of this path.
+ *
+ * Random numbers: the caller passes uniform draws in [0, 1) instead of index sets, because the
+ * sizes they index are only known on the device: 3 per P3P hypothesis (mapped to 3 distinct
+ * landmark indices: a = floor(u0 n), b = floor(u1 (n-1)) skipping a, c = floor(u2 (n-2)) skipping
+ * both) and 8 per fundamental-matrix trial (draw k picks the floor(u_k (n-k))-th index not picked
+ * before).
+ *
+ * Per frame: vohip_frame_track (enqueue only), vohip_frame_localize (returns the pose and n_iter,
+ * the number of hypotheses the adaptive rule of ransacLocalization.m:118-131 consumed; when it
+ * returns VOHIP_SAMPLES_EXHAUSTED call it again with more uniforms, the first `evaluated` of
+ * which must be the ones already passed), vohip_frame_map.
+ */
+typedef struct vohip_frame vohip_frame;
+
+typedef struct vohip_frame_params {
+    int klt_block, klt_levels, klt_max_iter;   /* vision.PointTracker arguments, main_demo.m:342-343 */
+    double klt_max_bidir_error;
+    int detector;                              /* 0 Harris, 1 MinEigen (genKeypoints.m:16-18,31-32) */
+    double min_quality;
+    int filter_size, border;
+    double r_discard_redundant;                /* hyper_paras, main_demo.m:36-43, 72-75 */
+    double angle_threshold_deg, min_depth, max_depth;
+    int refine_pose, refine_max_iter;          /* hyper_paras.is_refine_pose; T_refinement.m:4 */
+    int fm_trials;                             /* update_landmarks.m:13-14 */
+    double fm_threshold, fm_confidence;
+    int cap_landmarks, cap_candidates, cap_corners;   /* capacities of the device arrays */
+    int max_hypotheses;                        /* 15000, ransacLocalization.m:128 */
+    int slot_a, slot_b;                        /* the two pyramid slots of the context this loop uses */
+} vohip_frame_params;
+
+typedef struct vohip_frame_pose {
+    double T_W_C[16];          /* 4x4 column-major, after refinement when enabled */
+    double Rt[12];             /* [R_C_W (column-major) | t_C_W] of the winning hypothesis */
+    double refine_stats[3];    /* iterations, initial cost, final cost */
+    double num_iterations;     /* the adaptive bound when the loop stopped */
+    int n_tracked, n_inliers, max_num_inliers, n_iter, found, exhausted, evaluated;
+} vohip_frame_pose;
+
+typedef struct vohip_frame_counts {
+    int n_landmarks, n_candidates;   /* size(S.X, 2), size(S.C, 2) at the end of the frame */
+    int num_new;                     /* S.num_new(end), update_landmarks.m:124 */
+    int n_detected, n_kept;          /* corners found / kept as new candidates */
+    int n_candidates_tracked, n_candidates_inliers, fm_trials_run;
+    int overflow;
+} vohip_frame_counts;
+
+void vohip_frame_default_params(vohip_frame_params *p);
+/* rows x cols uint8 images, row-major (colmajor = 0) or MATLAB's column-major (colmajor = 1). */
+int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor,
+                       const vohip_frame_params *params, vohip_frame **out);
+int vohip_frame_destroy(vohip_frame *f);
+/* State initialisation, main_demo.m:268-303, 342-344: X 3xn, ids n (NULL = 1..n), P_rc 2xn (row;
+ * col) in `image`, T_W_C 4x4 column-major.  image on the host, or on the device when the flag is set. */
+int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device, const double *X, const double *ids,
+                      const double *P_rc, int n, const double T_W_C[16]);
+int vohip_frame_track(vohip_frame *f, const uint8_t *image, int image_on_device);
+/* uniforms 3 x h.  VOHIP_NO_MODEL: no hypothesis reached 30 inliers (the reference stops there too). */
+int vohip_frame_localize(vohip_frame *f, const double *uniforms, int h, vohip_frame_pose *out);
+/* uniforms 8 x fm_trials (may be NULL while there are no candidates yet). */
+int vohip_frame_map(vohip_frame *f, const double *uniforms, vohip_frame_counts *out);
+int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates);
+/* Copies of S.P (2xn), S.X(1:3,:) (3xn), S.X(4,:), S.C, S.F (2xm), S.T (12xm); any pointer may be NULL. */
+int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc, double *T12);
+
 /* ---- trajectory alignment (evaluation) ---------------------------------------------------------
  * utils/exe9_BA/alignEstimateToGroundTruth.m:1-27 with the residual of alignError.m:1-17, as
  * utils/quantitative_eval.m:23-24 calls it: finds x = [twist of T_G_V (v; w); scale] minimising

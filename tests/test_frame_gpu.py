@@ -1,0 +1,120 @@
+"""The device-resident frame loop (vohip_frame_* behind VOPipelineDevice) against the stage-by-stage
+loop (VOPipeline) and the CPU restatement, same sequence and RNG seed.
+Bar: identical landmark / candidate counts and landmark ids every frame; poses, landmarks and
+keypoints within 1e-8 of the stage-by-stage GPU loop (same kernels, the only difference is the
+closed-form inverse of the RANSAC pose before refinement) and within the end-to-end bar
+(1e-5 m / rad) of the CPU restatement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 240
+K = np.array([[400.0, 0, 320], [0, 400.0, 120], [0, 0, 1]])
+
+
+@pytest.fixture(scope="module")
+def sequence(vo):
+    scene = vo.synth.CorridorScene(K=K, width=W, height=H)
+    poses = vo.synth.corridor_trajectory(9, step=0.5)
+    return scene, poses, [scene.render(T) for T in poses]
+
+
+def _start(vo, oracle, sequence):
+    scene, poses, frames = sequence
+    ab, _, _ = oracle.detect_corners(frames[0], min_quality=2e-4, border=16)
+    xy = (ab + 1.0).astype(np.float64)
+    return scene.backproject(poses[0], xy), xy
+
+
+def test_uniform_to_index_maps(vo):
+    """The two maps the device applies to the caller's uniforms, against brute-force definitions."""
+    rng = np.random.default_rng(0)
+    for n in (8, 9, 31, 500):
+        u = rng.random((300, 8))
+        got = vo.octets_from_uniforms(u, n)
+        for row_u, row in zip(u, got):
+            pool = list(range(n))
+            want = [pool.pop(min(int(x * len(pool)), len(pool) - 1)) for x in row_u]
+            assert list(row) == want
+    for n in (3, 4, 50):
+        u = rng.random((300, 3))
+        got = vo.triples_from_uniforms(u, n)
+        for row_u, row in zip(u, got):
+            pool = list(range(n))
+            want = [pool.pop(min(int(x * len(pool)), len(pool) - 1)) for x in row_u]
+            assert list(row) == want
+
+
+def test_device_loop_matches_stage_by_stage_loop(vo, ctx, oracle, sequence):
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    ref = vo.VOPipeline(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(1), ctx=ctx)
+    dev = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(1), ctx=ctx)
+    for i in range(1, len(frames)):
+        Tr = ref.process_frame(frames[i])
+        Td = dev.process_frame(frames[i])
+        assert dev.num_X[-1] == ref.S.num_X[-1] and dev.num_C[-1] == ref.S.num_C[-1], i
+        assert dev.num_new == ref.S.num_new, i
+        np.testing.assert_allclose(Td, Tr, rtol=0, atol=1e-8)
+        assert np.linalg.norm(Td[:3, 3] - poses[i][:3, 3]) < 0.25, i
+    S, R = dev.S, ref.S
+    np.testing.assert_array_equal(S.X[3], R.X[3])
+    np.testing.assert_allclose(S.X[:3], R.X[:3], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(S.P, R.P, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(S.C, R.C, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(S.F, R.F, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(S.T, R.T[:, :R.C.shape[1]], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(S.est_trans, R.est_trans, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(S.est_rot, R.est_rot, rtol=0, atol=1e-8)
+    # both generators consumed the same number of draws
+    assert dev.rng.bit_generator.state == ref.rng.bit_generator.state
+    ref.close()
+    dev.close()
+
+
+def test_device_loop_matches_cpu_restatement(vo, ctx, oracle, sequence):
+    from oracle import pipeline_oracle as po
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    ref = po.OraclePipeline(K, frames[0], X0, xy, poses[0], hp, 3, 2, np.random.default_rng(7), vo.draw_triples,
+                            vo.draw_octets)
+    dev = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(7), ctx=ctx)
+    for i in range(1, 7):
+        Tr = ref.process_frame(frames[i])
+        Td = dev.process_frame(frames[i])
+        assert dev.num_X[-1] == ref.S.num_X[-1] and dev.num_C[-1] == ref.S.num_C[-1], i
+        assert np.linalg.norm(Tr[:3, 3] - Td[:3, 3]) < 1e-5, i
+        dR = Tr[:3, :3].T @ Td[:3, :3]
+        assert np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)) < 1e-5, i
+    np.testing.assert_array_equal(dev.S.X[3], ref.S.X[3])
+    dev.close()
+
+
+def test_device_loop_accepts_device_images_and_reports_errors(vo, ctx, oracle, sequence):
+    import torch
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    a = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(3), ctx=ctx)
+    d0 = torch.from_numpy(frames[0]).cuda()
+    b = vo.VOPipelineDevice(K, d0, X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(3), ctx=ctx)
+    for i in range(1, 4):
+        Ta = a.process_frame(frames[i])
+        Tb = b.process_frame(torch.from_numpy(frames[i]).cuda())
+        np.testing.assert_array_equal(Ta, Tb)
+    a.close()
+    b.close()
+    # a blank image loses every track: the reference stops at main_demo.m:389-391, so does this
+    c = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(3), ctx=ctx)
+    with pytest.raises((RuntimeError, vo.VohipError)):
+        c.process_frame(np.full_like(frames[0], 127))
+    c.close()
+    hp_ba = vo.default_hyper_paras("kitti", is_BA=True)
+    with pytest.raises(NotImplementedError):
+        vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp_ba, ctx=ctx)
+    # capacity is checked
+    with pytest.raises(vo.VohipError):
+        vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, ctx=ctx, cap_landmarks=64)

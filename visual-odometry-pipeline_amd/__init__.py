@@ -10,12 +10,13 @@ from .bootstrap import (bootstrap, compProjMat, matching_init, pose_estimation_i
                         triangulation_init)
 from .evaluation import (alignError, alignEstimateToGroundTruth, experiment_name, load_results, quantitative_eval,
                          run_sequence, save_results)
-from .fmatrix import draw_octets, estimateFundamentalMatrix
+from .fmatrix import draw_octets, estimateFundamentalMatrix, octets_from_uniforms
+from .frame_pipeline import VOPipelineDevice
 from .keypoints import cornerPoints, genKeypoints
 from .klt import PointTracker, Pyramid
 from .pipeline import (VO_bundle_adjust, VOPipeline, default_hyper_paras, init_state, update_candidate,
                        update_landmarks)
-from .ransac import draw_triples, p3p, ransacLocalization
+from .ransac import draw_triples, p3p, ransacLocalization, triples_from_uniforms
 from .geometry import (Cross2Matrix, HomogMatrix2twist, Matrix2Cross, candidate_filter, candidate_triangulate,
                        linearTriangulation, linearTriangulation_refinement, twist2HomogMatrix)
 

@@ -29,8 +29,49 @@ c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 c_int_p = C.POINTER(C.c_int)
 
+
+
+class FrameParams(C.Structure):
+    """vohip_frame_params"""
+    _fields_ = [("klt_block", C.c_int), ("klt_levels", C.c_int), ("klt_max_iter", C.c_int),
+                ("klt_max_bidir_error", C.c_double), ("detector", C.c_int), ("min_quality", C.c_double),
+                ("filter_size", C.c_int), ("border", C.c_int), ("r_discard_redundant", C.c_double),
+                ("angle_threshold_deg", C.c_double), ("min_depth", C.c_double), ("max_depth", C.c_double),
+                ("refine_pose", C.c_int), ("refine_max_iter", C.c_int), ("fm_trials", C.c_int),
+                ("fm_threshold", C.c_double), ("fm_confidence", C.c_double), ("cap_landmarks", C.c_int),
+                ("cap_candidates", C.c_int), ("cap_corners", C.c_int), ("max_hypotheses", C.c_int),
+                ("slot_a", C.c_int), ("slot_b", C.c_int)]
+
+
+class FramePose(C.Structure):
+    """vohip_frame_pose"""
+    _fields_ = [("T_W_C", C.c_double * 16), ("Rt", C.c_double * 12), ("refine_stats", C.c_double * 3),
+                ("num_iterations", C.c_double), ("n_tracked", C.c_int), ("n_inliers", C.c_int),
+                ("max_num_inliers", C.c_int), ("n_iter", C.c_int), ("found", C.c_int), ("exhausted", C.c_int),
+                ("evaluated", C.c_int)]
+
+
+class FrameCounts(C.Structure):
+    """vohip_frame_counts"""
+    _fields_ = [("n_landmarks", C.c_int), ("n_candidates", C.c_int), ("num_new", C.c_int), ("n_detected", C.c_int),
+                ("n_kept", C.c_int), ("n_candidates_tracked", C.c_int), ("n_candidates_inliers", C.c_int),
+                ("fm_trials_run", C.c_int), ("overflow", C.c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/vohip.h one to one
 SIGNATURES = {
+    "vohip_frame_default_params": (None, [C.POINTER(FrameParams)]),
+    "vohip_frame_create": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams),
+                                      C.POINTER(C.c_void_p)]),
+    "vohip_frame_destroy": (C.c_int, [C.c_void_p]),
+    "vohip_frame_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int,
+                                     c_double_p]),
+    "vohip_frame_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "vohip_frame_localize": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.POINTER(FramePose)]),
+    "vohip_frame_map": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(FrameCounts)]),
+    "vohip_frame_sizes": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
+    "vohip_frame_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                     c_double_p]),
     "vohip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "vohip_destroy": (C.c_int, [C.c_void_p]),
     "vohip_last_error": (C.c_char_p, [C.c_void_p]),

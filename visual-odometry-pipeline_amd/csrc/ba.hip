@@ -565,7 +565,8 @@ struct pr_params {
     double ftol, xtol;
 };
 
-__global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, const double *__restrict__ kp_uv,
+__global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, const int *__restrict__ n_dev,
+                                                                 const double *__restrict__ kp_uv,
                                                                  const double *__restrict__ X,
                                                                  double *__restrict__ T_io /*16*/,
                                                                  double *__restrict__ stats /*3*/)
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
     __shared__ double sTw[6], sTwN[6], sH[36], sG[6], sD[6], sWave[16], sPart[27 * (PR_THREADS / 64)];
     __shared__ int sOk;
     const int tid = threadIdx.x;
+    if (n_dev) P.n = *n_dev;  // point count kept on the device (the frame pipeline)
     if (tid == 0) {
         const rigid T = rigid_from_cm44(T_io);
         double tw[6];
@@ -906,16 +908,29 @@ int vohip_pose_refine_dev(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, co
     VOHIP_REQUIRE(ctx, d_T && K && n >= 0, "bad argument");
     if (n == 0) return VOHIP_OK;
     VOHIP_REQUIRE(ctx, d_kp_uv && d_X, "NULL array");
+    return vohip_pose_refine_enqueue(ctx, d_T, d_kp_uv, d_X, n, nullptr, K, max_iter, ftol, xtol, d_stats);
+}
+
+}  // extern "C"
+
+// n, or *d_n when given (the frame pipeline keeps the count on the device).
+int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, const double *d_X, int n,
+                              const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
+                              double *d_stats)
+{
     pr_params P;
     std::memcpy(P.K, K, sizeof(P.K));
     P.n = n;
     P.max_iter = max_iter;
     P.ftol = ftol;
     P.xtol = xtol;
-    hipLaunchKernelGGL(pose_refine_kernel, dim3(1), dim3(PR_THREADS), 0, ctx->stream, P, d_kp_uv, d_X, d_T, d_stats);
+    hipLaunchKernelGGL(pose_refine_kernel, dim3(1), dim3(PR_THREADS), 0, ctx->stream, P, d_n, d_kp_uv, d_X, d_T,
+                       d_stats);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
+
+extern "C" {
 
 int vohip_pose_refine(vohip_ctx *ctx, double T[16], const double *kp_uv, const double *X, int n, const double K[9],
                       int max_iter, double ftol, double xtol, double *stats)

@@ -28,9 +28,11 @@ __device__ __forceinline__ double wsum(double v)
 // sums, wave butterfly, then waves in order), so the result is reproducible.
 __global__ __launch_bounds__(256) void fm_normalise_kernel(const double *__restrict__ p1,
                                                            const double *__restrict__ p2, int n,
+                                                           const int *__restrict__ n_dev,
                                                            double *__restrict__ nrm)
 {
     __shared__ double sW[4][4];
+    if (n_dev) n = *n_dev;  // point count kept on the device (the frame pipeline)
     __shared__ double sMean[4];
     const int tid = threadIdx.x;
     double s[4] = {0, 0, 0, 0};
@@ -165,11 +167,13 @@ __device__ void rank2(double F[3][3])
 
 // One thread per trial; F_out[t] row-major 3x3 (all zeros for a degenerate sample).
 __global__ __launch_bounds__(64) void fm_solve_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                      int n, const int32_t *__restrict__ samples, int trials,
+                                                      int n, const int *__restrict__ n_dev,
+                                                      const int32_t *__restrict__ samples, int trials,
                                                       const double *__restrict__ nrm, double *__restrict__ F_out)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= trials) return;
+    if (n_dev) n = *n_dev;
     const double s1 = nrm[0], cx1 = nrm[1], cy1 = nrm[2], s2 = nrm[3], cx2 = nrm[4], cy2 = nrm[5];
     double A[8][9];
     bool ok = true;
@@ -221,9 +225,11 @@ __device__ __forceinline__ bool sampson_inlier(const double F[9], double x1, dou
 
 // One wavefront per trial, 4 trials per workgroup.
 __global__ __launch_bounds__(256) void fm_count_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                       int n, const double *__restrict__ Fs, int trials, double thr,
+                                                       int n, const int *__restrict__ n_dev,
+                                                       const double *__restrict__ Fs, int trials, double thr,
                                                        int32_t *__restrict__ counts)
 {
+    if (n_dev) n = *n_dev;
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (t >= trials) return;
@@ -241,9 +247,11 @@ __global__ __launch_bounds__(256) void fm_count_kernel(const double *__restrict_
 }
 
 __global__ __launch_bounds__(256) void fm_mask_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
-                                                      int n, const double *__restrict__ F9, double thr,
+                                                      int n, const int *__restrict__ n_dev,
+                                                      const double *__restrict__ F9, double thr,
                                                       uint8_t *__restrict__ mask)
 {
+    if (n_dev) n = *n_dev;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double F[9];
@@ -262,6 +270,32 @@ double trial_budget(int inliers, int n, int num_trials, double confidence)
 }
 
 }  // namespace
+
+// Normalise + solve + count for `num_trials` trials; n sizes nothing here (one wavefront per
+// trial), the point count may live on the device.  d_nrm 6 doubles, d_F 9 x trials, d_counts trials.
+int vohip_fm_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int *d_n,
+                     const int32_t *d_samples, int num_trials, double threshold, double *d_nrm, double *d_F,
+                     int32_t *d_counts)
+{
+    hipStream_t s = ctx->stream;
+    hipLaunchKernelGGL(fm_normalise_kernel, dim3(1), dim3(256), 0, s, d_p1, d_p2, n, d_n, d_nrm);
+    hipLaunchKernelGGL(fm_solve_kernel, dim3((num_trials + 63) / 64), dim3(64), 0, s, d_p1, d_p2, n, d_n, d_samples,
+                       num_trials, (const double *)d_nrm, d_F);
+    hipLaunchKernelGGL(fm_count_kernel, dim3((num_trials + 3) / 4), dim3(256), 0, s, d_p1, d_p2, n, d_n,
+                       (const double *)d_F, num_trials, threshold, d_counts);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+// Inlier mask of the matrix at d_F9 (row-major 3x3, device memory).  n sizes the grid.
+int vohip_fm_mask_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int *d_n,
+                          const double *d_F9, double threshold, uint8_t *d_mask)
+{
+    hipLaunchKernelGGL(fm_mask_kernel, dim3((n + 255) / 256 < 1 ? 1 : (n + 255) / 256), dim3(256), 0, ctx->stream, d_p1,
+                       d_p2, n, d_n, d_F9, threshold, d_mask);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
 
 extern "C" {
 
@@ -285,12 +319,8 @@ int vohip_fmatrix_ransac_dev(vohip_ctx *ctx, const double *d_p1, const double *d
     VOHIP_TRY(vohip_reserve_pinned(ctx, ctx->bufs[H_FM_COUNTS], sizeof(int32_t) * (size_t)num_trials));
     h_counts = ctx->bufs[H_FM_COUNTS].ptr;
     hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(fm_normalise_kernel, dim3(1), dim3(256), 0, s, d_p1, d_p2, n, (double *)d_nrm);
-    hipLaunchKernelGGL(fm_solve_kernel, dim3((num_trials + 63) / 64), dim3(64), 0, s, d_p1, d_p2, n, d_samples,
-                       num_trials, (const double *)d_nrm, (double *)d_F);
-    hipLaunchKernelGGL(fm_count_kernel, dim3((num_trials + 3) / 4), dim3(256), 0, s, d_p1, d_p2, n, (const double *)d_F,
-                       num_trials, threshold, (int32_t *)d_counts);
-    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_TRY(vohip_fm_enqueue(ctx, d_p1, d_p2, n, nullptr, d_samples, num_trials, threshold, (double *)d_nrm,
+                               (double *)d_F, (int32_t *)d_counts));
     VOHIP_TRY(vohip_download(ctx, h_counts, d_counts, sizeof(int32_t) * (size_t)num_trials));
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
     const int32_t *c = (const int32_t *)h_counts;
@@ -310,9 +340,8 @@ int vohip_fmatrix_ransac_dev(vohip_ctx *ctx, const double *d_p1, const double *d
         VOHIP_HIP(ctx, hipMemsetAsync(d_mask, 0, (size_t)n, s));
         return vohip_fail(ctx, VOHIP_NO_MODEL, "no trial produced an inlier");
     }
-    hipLaunchKernelGGL(fm_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_p1, d_p2, n,
-                       (const double *)d_F + 9 * (size_t)best_t, threshold, d_mask);
-    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_TRY(vohip_fm_mask_enqueue(ctx, d_p1, d_p2, n, nullptr, (const double *)d_F + 9 * (size_t)best_t, threshold,
+                                    d_mask));
     if (F_best) {
         VOHIP_TRY(vohip_download(ctx, F_best, (const double *)d_F + 9 * (size_t)best_t, sizeof(double) * 9));
         VOHIP_HIP(ctx, hipStreamSynchronize(s));

@@ -1,0 +1,930 @@
+// The continuous-operation loop body with the state resident on the GPU (gfx950).
+//
+// Restates main_demo.m:377-427 with is_BA = false -- detection (genKeypoints.m), the landmark
+// tracker, ransacLocalization.m, T_refinement.m, update_landmarks.m, update_candidate.m and the
+// tracker re-initialisation -- as three enqueue-mostly calls per frame:
+//   vohip_frame_track     image pyramid, landmark tracking + ordered selection on the context's
+//                         stream; candidate tracking and corner detection on a second stream
+//   vohip_frame_localize  P3P hypotheses from the caller's uniform draws, scoring, the adaptive
+//                         stopping rule replayed by one device thread, inlier selection, pose
+//                         refinement; ONE synchronisation (the caller's RNG needs n_iter)
+//   vohip_frame_map       fundamental-matrix RANSAC over the candidate tracks, triangulation,
+//                         landmark append, redundancy filter, candidate append; ONE synchronisation
+// S.P, S.X, S.C, S.F, S.T never leave the device; every count between the stages stays in device
+// memory (kernels are launched over capacity-sized grids and read the count themselves), and
+// selections are ordered, so the state is element for element the one the stage-by-stage entry
+// points produce.
+#include "vohip_internal.h"
+
+#include <cmath>
+#include <new>
+
+namespace {
+
+// slots of the device counter array
+enum {
+    N_V = 0,      // landmarks tracked successfully
+    N_IN,         // ... that are inliers of the best pose (= landmarks kept)
+    N_CV,         // candidates tracked successfully
+    N_CI,         // ... that pass the epipolar filter
+    N_L_END,      // landmarks after new ones were appended
+    N_C_MID,      // candidates left after triangulation
+    NUM_NEW,      // candidates removed by update_landmarks (appended or dropped)
+    N_DET,        // corners detected (may exceed the capacity)
+    FILT0, FILT1, FILT2,  // {detections, candidates, landmarks} as the redundancy filter reads them
+    N_KEPT,       // detections kept
+    N_C_END,      // candidates at the end of the frame
+    OVERFLOW,     // bit 0: landmark capacity, bit 1: candidate capacity
+    R_ITER, R_FOUND, R_EXHAUSTED, R_BEST_H, R_BEST_S, R_MAX_INL,   // localisation
+    F_BEST_T, F_BEST_COUNT, F_TRIALS,                              // epipolar filter
+    N_COUNTERS = 32
+};
+// slots of the device double array
+enum {
+    D_T = 0,          // T_W_C, 4x4 column-major
+    D_M = 16,         // K [R | t] of the winning hypothesis, row-major 3x4
+    D_RT = 28,        // [R_C_W (column-major) | t_C_W] of the winning hypothesis
+    D_F = 40,         // winning fundamental matrix, row-major
+    D_IDX = 49,       // next landmark id
+    D_IDX_NEXT = 50,
+    D_NUM_ITER = 51,  // adaptive bound after the last replayed iteration
+    D_STATS = 52,     // pose refinement: iterations, initial cost, final cost
+    D_NRM = 56,       // Hartley normalisation (6)
+    N_DOUBLES = 64
+};
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Ordered selection inside a grid of 256-thread workgroups: returns the number of flagged
+// elements before element i = blockIdx.x * 256 + threadIdx.x and, in `total`, the number of
+// flagged elements in [0, n).  Every workgroup re-reads the flags before its range (at most a few
+// KB, from L2), so there is no inter-workgroup hand-off and the result is deterministic.
+// All 256 threads must call it.  `sh` needs 12 ints.
+template <class Pred>
+__device__ int ordered_rank(const uint8_t *__restrict__ flags, int n, Pred pred, int &total, int *sh)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int first = blockIdx.x * 256;
+    int before = 0, all = 0;
+    for (int j = tid; j < n; j += 256) {
+        const int f = pred(flags[j]) ? 1 : 0;
+        all += f;
+        before += j < first ? f : 0;
+    }
+    before = wave_sum_i(before);
+    all = wave_sum_i(all);
+    const int i = first + tid;
+    const bool mine = i < n && pred(flags[i]);
+    const unsigned long long b = __ballot(mine);
+    const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) {
+        sh[wave] = before;
+        sh[4 + wave] = all;
+        sh[8 + wave] = __popcll(b);
+    }
+    __syncthreads();
+    int r = sh[0] + sh[1] + sh[2] + sh[3] + in_wave;
+    for (int w = 0; w < wave; ++w) r += sh[8 + w];
+    total = sh[4] + sh[5] + sh[6] + sh[7];
+    return r;
+}
+
+struct is_set {
+    __device__ bool operator()(uint8_t f) const { return f != 0; }
+};
+struct is_one {
+    __device__ bool operator()(uint8_t f) const { return f == 1; }
+};
+struct is_zero {
+    __device__ bool operator()(uint8_t f) const { return f == 0; }
+};
+
+// main_demo.m:380-381 + the S.X(:, validity) of :387: tracked landmarks that are still valid.
+__global__ __launch_bounds__(256) void select_tracked_kernel(const double *__restrict__ out_xy, int ld,
+                                                             const uint8_t *__restrict__ valid,
+                                                             const double *__restrict__ L_X,
+                                                             const double *__restrict__ L_id, int n,
+                                                             double *__restrict__ mv_rc, double *__restrict__ Xv,
+                                                             double *__restrict__ idv, int *__restrict__ cnt)
+{
+    __shared__ int sh[12];
+    int total;
+    const int r = ordered_rank(valid, n, is_set(), total, sh);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && valid[i]) {
+        mv_rc[2 * r] = out_xy[ld + i];   // row = y
+        mv_rc[2 * r + 1] = out_xy[i];    // col = x
+        Xv[3 * r] = L_X[3 * i];
+        Xv[3 * r + 1] = L_X[3 * i + 1];
+        Xv[3 * r + 2] = L_X[3 * i + 2];
+        idv[r] = L_id[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[N_V] = total;
+}
+
+// uniform draws -> index triples (3 distinct indices in [0, n)), for hypotheses [first, first + h)
+__global__ __launch_bounds__(256) void triples_kernel(const double *__restrict__ u, int first, int h,
+                                                      const int *__restrict__ cnt, int32_t *__restrict__ samples)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= h) return;
+    const int n = cnt[N_V];
+    const double *r = u + 3 * (size_t)(first + k);
+    int a = min((int)(r[0] * (double)n), n - 1);
+    int b = min((int)(r[1] * (double)(n - 1)), n - 2);
+    int c = min((int)(r[2] * (double)(n - 2)), n - 3);
+    b += b >= a;
+    const int lo = min(a, b), hi = max(a, b);
+    c += c >= lo;
+    c += c >= hi;
+    int32_t *s = samples + 3 * (size_t)(first + k);
+    s[0] = a;
+    s[1] = b;
+    s[2] = c;
+}
+
+// ransacLocalization.m:118-129
+__device__ double adaptive_iterations_dev(int max_num_inliers, int n)
+{
+    const double confidence = 0.9999, upper = 0.95;
+    double outlier_ratio = 1.0 - (double)max_num_inliers / (double)n;
+    if (upper < outlier_ratio) outlier_ratio = upper;
+    double it = log(1.0 - confidence) / log(1.0 - pow(1.0 - outlier_ratio, 3.0));
+    if (it > 15000.0) it = 15000.0;
+    if (it < 100.0) it = 100.0;
+    return it;
+}
+
+// The sequential part of ransacLocalization.m:42-131 over the scored hypotheses, by one thread:
+// solution choice (:77-101, strict '>'), running maximum (:104-110), adaptive bound (:118-129).
+__global__ void localize_decide_kernel(const int32_t *__restrict__ counts, int evaluated,
+                                       const double *__restrict__ Rt_all, const double *__restrict__ M_all,
+                                       int *__restrict__ cnt, double *__restrict__ dv)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = cnt[N_V];
+    int max_num_inliers = 0, best_h = -1, best_s = 0, i = 1;
+    double num_iterations = INFINITY;
+    bool exhausted = false;
+    if (n >= 3) {
+        while (num_iterations > (double)i) {
+            if (i > evaluated) {
+                exhausted = true;
+                break;
+            }
+            const int32_t *c = counts + 4 * (size_t)(i - 1);
+            int s_best = 0;
+            for (int s = 1; s < 4; ++s)
+                if (c[s] > c[s_best]) s_best = s;
+            const int k = c[s_best];
+            if (k > max_num_inliers && k >= 30) {
+                max_num_inliers = k;
+                best_h = i - 1;
+                best_s = s_best;
+            }
+            num_iterations = adaptive_iterations_dev(max_num_inliers, n);
+            ++i;
+        }
+    }
+    cnt[R_ITER] = i - 1;
+    cnt[R_FOUND] = best_h >= 0 ? 1 : 0;
+    cnt[R_EXHAUSTED] = exhausted ? 1 : 0;
+    cnt[R_BEST_H] = best_h;
+    cnt[R_BEST_S] = best_s;
+    cnt[R_MAX_INL] = max_num_inliers;
+    dv[D_NUM_ITER] = num_iterations;
+    if (best_h >= 0) {
+        const double *Rt = Rt_all + (size_t)best_h * 48 + 12 * best_s;
+        const double *M = M_all + (size_t)best_h * 48 + 12 * best_s;
+        for (int q = 0; q < 12; ++q) {
+            dv[D_M + q] = M[q];
+            dv[D_RT + q] = Rt[q];
+        }
+        // T_W_C = inv([R_C_W t_C_W; 0 0 0 1]) (main_demo.m:391), column-major
+        double *T = dv + D_T;
+        for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) T[4 * c + r] = Rt[3 * r + c];   // R_W_C = R_C_W'
+            T[12 + r] = -(Rt[3 * r] * Rt[9] + Rt[3 * r + 1] * Rt[10] + Rt[3 * r + 2] * Rt[11]);
+            T[4 * r + 3] = 0.0;
+        }
+        T[15] = 1.0;
+    } else {
+        const double nan = __builtin_nan("");
+        for (int q = 0; q < 12; ++q) dv[D_M + q] = nan;   // no point is an inlier of a NaN pose
+    }
+}
+
+// main_demo.m:394-396: S.P, S.X restricted to the inliers; also the (u, v) copy the refinement reads.
+__global__ __launch_bounds__(256) void select_inliers_kernel(const double *__restrict__ mv_rc,
+                                                             const double *__restrict__ Xv,
+                                                             const double *__restrict__ idv,
+                                                             const uint8_t *__restrict__ mask,
+                                                             int *__restrict__ cnt, double *__restrict__ L_rc,
+                                                             double *__restrict__ L_X, double *__restrict__ L_id,
+                                                             double *__restrict__ kp_uv)
+{
+    __shared__ int sh[12];
+    const int n = cnt[N_V];
+    int total;
+    const int r = ordered_rank(mask, n, is_set(), total, sh);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && mask[i]) {
+        const double row = mv_rc[2 * i], col = mv_rc[2 * i + 1];
+        L_rc[2 * r] = row;
+        L_rc[2 * r + 1] = col;
+        kp_uv[2 * r] = col;
+        kp_uv[2 * r + 1] = row;
+        L_X[3 * r] = Xv[3 * i];
+        L_X[3 * r + 1] = Xv[3 * i + 1];
+        L_X[3 * r + 2] = Xv[3 * i + 2];
+        L_id[r] = idv[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cnt[N_IN] = total;
+        // what the mapping stage reads when it has nothing to do (no candidates yet)
+        cnt[N_L_END] = total;
+        cnt[N_C_MID] = 0;
+        cnt[NUM_NEW] = 0;
+    }
+}
+
+// update_landmarks.m:10-11,20-25: candidates whose track is valid, with their first observation.
+__global__ __launch_bounds__(256) void select_cand_tracked_kernel(const double *__restrict__ out_xy, int ld,
+                                                                  const uint8_t *__restrict__ valid,
+                                                                  const double *__restrict__ C_rc,
+                                                                  const double *__restrict__ F_rc,
+                                                                  const double *__restrict__ T12, int n,
+                                                                  double *__restrict__ p1_rc, double *__restrict__ m_rc,
+                                                                  double *__restrict__ F_t, double *__restrict__ T_t,
+                                                                  int *__restrict__ cnt)
+{
+    __shared__ int sh[12];
+    int total;
+    const int r = ordered_rank(valid, n, is_set(), total, sh);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && valid[i]) {
+        p1_rc[2 * r] = C_rc[2 * i];
+        p1_rc[2 * r + 1] = C_rc[2 * i + 1];
+        m_rc[2 * r] = out_xy[ld + i];
+        m_rc[2 * r + 1] = out_xy[i];
+        F_t[2 * r] = F_rc[2 * i];
+        F_t[2 * r + 1] = F_rc[2 * i + 1];
+        for (int q = 0; q < 12; ++q) T_t[12 * (size_t)r + q] = T12[12 * (size_t)i + q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[N_CV] = total;
+}
+
+// uniform draws -> sets of 8 distinct indices in [0, n): draw k picks the floor(u_k (n - k))-th
+// index not picked before.
+__global__ __launch_bounds__(64) void octets_kernel(const double *__restrict__ u, int trials,
+                                                    const int *__restrict__ cnt, int32_t *__restrict__ samples)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= trials) return;
+    const int n = cnt[N_CV];
+    int chosen[8];   // sorted
+    for (int k = 0; k < 8; ++k) {
+        int idx = min((int)(u[8 * (size_t)t + k] * (double)(n - k)), n - k - 1);
+        for (int m = 0; m < k; ++m) idx += idx >= chosen[m];
+        samples[8 * (size_t)t + k] = idx;
+        int pos = k;
+        while (pos > 0 && chosen[pos - 1] > idx) {
+            chosen[pos] = chosen[pos - 1];
+            --pos;
+        }
+        chosen[pos] = idx;
+    }
+}
+
+// The sequential part of the fundamental-matrix RANSAC: first trial with the largest count inside
+// the shrinking trial budget.
+__global__ void fm_decide_kernel(const int32_t *__restrict__ counts, int num_trials, double confidence,
+                                 const double *__restrict__ F_all, int *__restrict__ cnt, double *__restrict__ dv)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = cnt[N_CV];
+    double budget = (double)num_trials;
+    int t = 0, best = 0, best_t = -1;
+    if (n >= 8) {
+        while ((double)t < budget && t < num_trials) {
+            if (counts[t] > best) {
+                best = counts[t];
+                best_t = t;
+                const double r8 = pow((double)best / (double)n, 8.0);
+                double b;
+                if (r8 >= 1.0)
+                    b = 1.0;
+                else if (r8 <= 0.0)
+                    b = (double)num_trials;
+                else {
+                    b = ceil(log(1.0 - confidence / 100.0) / log(1.0 - r8));
+                    if (!(b < (double)num_trials)) b = (double)num_trials;
+                }
+                budget = b;
+            }
+            ++t;
+        }
+    }
+    cnt[F_BEST_T] = best_t;
+    cnt[F_BEST_COUNT] = best;
+    cnt[F_TRIALS] = t;
+    for (int q = 0; q < 9; ++q) dv[D_F + q] = best_t >= 0 ? F_all[9 * (size_t)best_t + q] : 0.0;
+}
+
+// update_landmarks.m:15,20-25: the epipolar inliers.  An all-zero matrix (no model) flags nothing.
+__global__ __launch_bounds__(256) void select_f_inliers_kernel(const double *__restrict__ m_rc,
+                                                               const double *__restrict__ F_t,
+                                                               const double *__restrict__ T_t,
+                                                               const uint8_t *__restrict__ fmask,
+                                                               int *__restrict__ cnt, double *__restrict__ m2_rc,
+                                                               double *__restrict__ F2, double *__restrict__ T2)
+{
+    __shared__ int sh[12];
+    const int n = cnt[F_BEST_T] >= 0 ? cnt[N_CV] : 0;
+    int total;
+    const int r = ordered_rank(fmask, n, is_set(), total, sh);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && fmask[i]) {
+        m2_rc[2 * r] = m_rc[2 * i];
+        m2_rc[2 * r + 1] = m_rc[2 * i + 1];
+        F2[2 * r] = F_t[2 * i];
+        F2[2 * r + 1] = F_t[2 * i + 1];
+        for (int q = 0; q < 12; ++q) T2[12 * (size_t)r + q] = T_t[12 * (size_t)i + q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[N_CI] = total;
+}
+
+// update_landmarks.m:83-97,120-123: status 1 -> new landmark (appended to S.X / S.P with a fresh
+// id), status 0 -> stays a candidate, status 2 -> dropped.
+__global__ __launch_bounds__(256) void split_candidates_kernel(const uint8_t *__restrict__ status,
+                                                               const double *__restrict__ m2_rc,
+                                                               const double *__restrict__ F2,
+                                                               const double *__restrict__ T2,
+                                                               const double *__restrict__ Xnew,
+                                                               int *__restrict__ cnt, double *__restrict__ dv,
+                                                               int capL, double *__restrict__ L_rc,
+                                                               double *__restrict__ L_X, double *__restrict__ L_id,
+                                                               double *__restrict__ C_rc, double *__restrict__ F_rc,
+                                                               double *__restrict__ T12)
+{
+    __shared__ int sh[12];
+    const int n = cnt[N_CI];
+    const int nL = cnt[N_IN];
+    const double idx0 = dv[D_IDX];
+    int k_new, k_stay;
+    const int r_new = ordered_rank(status, n, is_one(), k_new, sh);
+    __syncthreads();
+    const int r_stay = ordered_rank(status, n, is_zero(), k_stay, sh);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const uint8_t st = status[i];
+        if (st == 1 && nL + r_new < capL) {
+            const int d = nL + r_new;
+            L_rc[2 * d] = m2_rc[2 * i];
+            L_rc[2 * d + 1] = m2_rc[2 * i + 1];
+            L_X[3 * d] = Xnew[3 * i];
+            L_X[3 * d + 1] = Xnew[3 * i + 1];
+            L_X[3 * d + 2] = Xnew[3 * i + 2];
+            L_id[d] = idx0 + (double)r_new;
+        } else if (st == 0) {
+            C_rc[2 * r_stay] = m2_rc[2 * i];
+            C_rc[2 * r_stay + 1] = m2_rc[2 * i + 1];
+            F_rc[2 * r_stay] = F2[2 * i];
+            F_rc[2 * r_stay + 1] = F2[2 * i + 1];
+            for (int q = 0; q < 12; ++q) T12[12 * (size_t)r_stay + q] = T2[12 * (size_t)i + q];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int kept = k_new;
+        if (nL + kept > capL) {
+            kept = capL - nL;
+            cnt[OVERFLOW] |= 1;
+        }
+        cnt[N_L_END] = nL + kept;
+        cnt[N_C_MID] = k_stay;
+        cnt[NUM_NEW] = n - k_stay;
+        dv[D_IDX_NEXT] = idx0 + (double)k_new;
+    }
+}
+
+// Fills the three counts the redundancy filter reads (update_candidate.m:12-24).
+__global__ void filter_counts_kernel(int *__restrict__ cnt, int capK, int have_map, double *__restrict__ dv)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    cnt[FILT0] = min(cnt[N_DET], capK);
+    cnt[FILT1] = cnt[N_C_MID];
+    cnt[FILT2] = cnt[N_L_END];
+    if (!have_map) dv[D_IDX_NEXT] = dv[D_IDX];
+}
+
+// update_candidate.m:55-57: kept detections become candidates, first seen here, under this pose.
+__global__ __launch_bounds__(256) void append_candidates_kernel(const float *__restrict__ corner_xy, int ld,
+                                                                const uint8_t *__restrict__ keep,
+                                                                int *__restrict__ cnt, double *__restrict__ dv,
+                                                                int capC, double *__restrict__ C_rc,
+                                                                double *__restrict__ F_rc, double *__restrict__ T12)
+{
+    __shared__ int sh[12];
+    const int n = cnt[FILT0];
+    const int nC = cnt[N_C_MID];
+    int total;
+    const int r = ordered_rank(keep, n, is_set(), total, sh);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && keep[i] && nC + r < capC) {
+        const int d = nC + r;
+        const double row = (double)corner_xy[ld + i], col = (double)corner_xy[i];
+        C_rc[2 * d] = row;
+        C_rc[2 * d + 1] = col;
+        F_rc[2 * d] = row;
+        F_rc[2 * d + 1] = col;
+        const double *T = dv + D_T;   // [R_W_C(:); t_W_C]
+        double *o = T12 + 12 * (size_t)d;
+        for (int c = 0; c < 3; ++c)
+            for (int rr = 0; rr < 3; ++rr) o[3 * c + rr] = T[4 * c + rr];
+        for (int rr = 0; rr < 3; ++rr) o[9 + rr] = T[12 + rr];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int kept = total;
+        if (nC + kept > capC) {
+            kept = capC - nC;
+            cnt[OVERFLOW] |= 2;
+        }
+        cnt[N_KEPT] = kept;
+        cnt[N_C_END] = nC + kept;
+    }
+}
+
+// main_demo.m:417-424: the points both trackers start from in the next frame, as (x, y) columns;
+// also rolls the landmark id counter.
+__global__ __launch_bounds__(256) void next_tracks_kernel(const double *__restrict__ L_rc, int ldL,
+                                                          double *__restrict__ L_xy,
+                                                          const double *__restrict__ C_rc, int ldC,
+                                                          double *__restrict__ C_xy, const int *__restrict__ cnt,
+                                                          double *__restrict__ dv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < cnt[N_L_END]) {
+        L_xy[i] = L_rc[2 * i + 1];
+        L_xy[ldL + i] = L_rc[2 * i];
+    }
+    if (i < cnt[N_C_END]) {
+        C_xy[i] = C_rc[2 * i + 1];
+        C_xy[ldC + i] = C_rc[2 * i];
+    }
+    if (i == 0) dv[D_IDX] = dv[D_IDX_NEXT];
+}
+
+}  // namespace
+
+struct vohip_frame {
+    vohip_ctx *ctx = nullptr;
+    vohip_frame_params prm;
+    double K[9];
+    int rows = 0, cols = 0, colmajor = 0;
+    int capL = 0, capC = 0, capK = 0, hmax = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_side = nullptr;
+    void *block = nullptr;       // one device allocation, carved up below
+    void *pinned = nullptr;      // host mirror of the counters and doubles
+    uint8_t *img = nullptr;      // image staging (host images)
+    double *L_rc, *L_X, *L_id, *L_xy, *C_rc, *F_rc, *T12, *C_xy;
+    double *kL_out, *mv_rc, *Xv, *idv, *kp_uv;
+    double *kC_out, *p1_rc, *m_rc, *F_t, *T_t, *m2_rc, *F2, *T2, *Xnew;
+    double *u3, *u8, *fm_F, *dv;
+    float *corner_xy, *corner_metric;
+    int32_t *samples3, *counts4, *samples8, *fm_counts;
+    int *cnt;
+    uint8_t *kL_valid, *kC_valid, *mask, *fmask, *status, *keep;
+    int slot_prev = 0, slot_cur = 0;
+    int n_L = 0, n_C = 0;        // counts at the start of the frame (known to the host)
+    int evaluated = 0;           // hypotheses scored in the current frame
+    int stage = 0;               // 0 = ready for track, 1 = tracked, 2 = localised
+    const uint8_t *cur_img = nullptr;
+};
+
+namespace {
+
+template <class T>
+T *carve(char *&p, size_t count)
+{
+    T *r = reinterpret_cast<T *>(p);
+    p += (count * sizeof(T) + 255) / 256 * 256;
+    return r;
+}
+
+size_t layout(vohip_frame *f, char *base)
+{
+    char *p = base;
+    const size_t L = f->capL, C = f->capC, Kc = f->capK, H = f->hmax, T = f->prm.fm_trials;
+    f->L_rc = carve<double>(p, 2 * L);
+    f->L_X = carve<double>(p, 3 * L);
+    f->L_id = carve<double>(p, L);
+    f->L_xy = carve<double>(p, 2 * L);
+    f->C_rc = carve<double>(p, 2 * C);
+    f->F_rc = carve<double>(p, 2 * C);
+    f->T12 = carve<double>(p, 12 * C);
+    f->C_xy = carve<double>(p, 2 * C);
+    f->kL_out = carve<double>(p, 2 * L);
+    f->mv_rc = carve<double>(p, 2 * L);
+    f->Xv = carve<double>(p, 3 * L);
+    f->idv = carve<double>(p, L);
+    f->kp_uv = carve<double>(p, 2 * L);
+    f->kC_out = carve<double>(p, 2 * C);
+    f->p1_rc = carve<double>(p, 2 * C);
+    f->m_rc = carve<double>(p, 2 * C);
+    f->F_t = carve<double>(p, 2 * C);
+    f->T_t = carve<double>(p, 12 * C);
+    f->m2_rc = carve<double>(p, 2 * C);
+    f->F2 = carve<double>(p, 2 * C);
+    f->T2 = carve<double>(p, 12 * C);
+    f->Xnew = carve<double>(p, 3 * C);
+    f->u3 = carve<double>(p, 3 * H);
+    f->u8 = carve<double>(p, 8 * T);
+    f->fm_F = carve<double>(p, 9 * T);
+    f->dv = carve<double>(p, N_DOUBLES);
+    f->corner_xy = carve<float>(p, 2 * Kc);
+    f->corner_metric = carve<float>(p, Kc);
+    f->samples3 = carve<int32_t>(p, 3 * H);
+    f->counts4 = carve<int32_t>(p, 4 * H);
+    f->samples8 = carve<int32_t>(p, 8 * T);
+    f->fm_counts = carve<int32_t>(p, T);
+    f->cnt = carve<int>(p, N_COUNTERS);
+    f->kL_valid = carve<uint8_t>(p, L);
+    f->kC_valid = carve<uint8_t>(p, C);
+    f->mask = carve<uint8_t>(p, L);
+    f->fmask = carve<uint8_t>(p, C);
+    f->status = carve<uint8_t>(p, C);
+    f->keep = carve<uint8_t>(p, Kc);
+    f->img = carve<uint8_t>(p, (size_t)f->rows * f->cols);
+    return (size_t)(p - base);
+}
+
+inline int blocks256(int n) { return n < 1 ? 1 : (n + 255) / 256; }
+
+struct stream_swap {
+    vohip_ctx *ctx;
+    hipStream_t saved;
+    stream_swap(vohip_ctx *c, hipStream_t s) : ctx(c), saved(c->stream) { c->stream = s; }
+    ~stream_swap() { ctx->stream = saved; }
+};
+
+int fetch_summary(vohip_frame *f)
+{
+    vohip_ctx *ctx = f->ctx;
+    int *hc = (int *)f->pinned;
+    double *hd = (double *)((char *)f->pinned + 256);
+    VOHIP_HIP(ctx, hipMemcpyAsync(hc, f->cnt, sizeof(int) * N_COUNTERS, hipMemcpyDeviceToHost, ctx->stream));
+    VOHIP_HIP(ctx, hipMemcpyAsync(hd, f->dv, sizeof(double) * N_DOUBLES, hipMemcpyDeviceToHost, ctx->stream));
+    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VOHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vohip_frame_default_params(vohip_frame_params *p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->klt_block = 21;            // main_demo.m:342-343
+    p->klt_levels = 5;
+    p->klt_max_iter = 20;
+    p->klt_max_bidir_error = 6.0;
+    p->detector = 0;              // Harris
+    p->min_quality = 2e-4;
+    p->filter_size = 5;
+    p->border = 16;
+    p->r_discard_redundant = 10.0;   // main_demo.m:72-75 (kitti)
+    p->angle_threshold_deg = 1.0;
+    p->min_depth = 1.0;
+    p->max_depth = 80.0;
+    p->refine_pose = 1;
+    p->refine_max_iter = 100;
+    p->fm_trials = 500;           // update_landmarks.m:13-14
+    p->fm_threshold = 5e-2;
+    p->fm_confidence = 99.0;
+    p->cap_landmarks = 8192;
+    p->cap_candidates = 8192;
+    p->cap_corners = 16384;
+    p->max_hypotheses = 15000;    // ransacLocalization.m:128
+    p->slot_a = 6;
+    p->slot_b = 7;
+}
+
+int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor,
+                       const vohip_frame_params *params, vohip_frame **out)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, K && params && out, "NULL argument");
+    VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
+    const vohip_frame_params &p = *params;
+    VOHIP_REQUIRE(ctx, p.cap_landmarks >= 64 && p.cap_candidates >= 64 && p.cap_corners >= 64 && p.cap_corners <= 16384,
+                  "capacities out of range");
+    VOHIP_REQUIRE(ctx, p.fm_trials >= 1 && p.max_hypotheses >= 104, "bad RANSAC sizes");
+    VOHIP_REQUIRE(ctx, p.slot_a != p.slot_b && p.slot_a >= 0 && p.slot_a < VOHIP_PYR_SLOTS && p.slot_b >= 0 &&
+                           p.slot_b < VOHIP_PYR_SLOTS,
+                  "bad pyramid slots");
+    VOHIP_REQUIRE(ctx, p.klt_block == 21 || p.klt_block == 31, "BlockSize 21 or 31");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    vohip_frame *f = new (std::nothrow) vohip_frame;
+    if (!f) return vohip_fail(ctx, VOHIP_ERR_HIP, "out of host memory");
+    f->ctx = ctx;
+    f->prm = p;
+    std::memcpy(f->K, K, sizeof(f->K));
+    f->rows = rows;
+    f->cols = cols;
+    f->colmajor = colmajor ? 1 : 0;
+    f->capL = p.cap_landmarks;
+    f->capC = p.cap_candidates;
+    f->capK = p.cap_corners;
+    f->hmax = (p.max_hypotheses + 7) / 8 * 8;
+    f->slot_prev = p.slot_a;
+    f->slot_cur = p.slot_b;
+    const size_t bytes = layout(f, nullptr);
+    hipError_t e = hipMalloc(&f->block, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(f->block, 0, bytes, ctx->stream);
+    if (e == hipSuccess) e = hipHostMalloc(&f->pinned, 256 + sizeof(double) * N_DOUBLES, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_pyr, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_side, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        vohip_frame_destroy(f);
+        return vohip_fail(ctx, VOHIP_ERR_HIP, "frame state allocation failed: %s", hipGetErrorString(e));
+    }
+    layout(f, (char *)f->block);
+    // the pose buffers of the hypothesis solver must hold every hypothesis of a frame
+    int st = vohip_reserve(ctx, ctx->bufs[B_RANSAC_RT], (size_t)f->hmax * 48 * sizeof(double));
+    if (st == VOHIP_OK) st = vohip_reserve(ctx, ctx->bufs[B_RANSAC_M], (size_t)f->hmax * 48 * sizeof(double));
+    if (st != VOHIP_OK) {
+        vohip_frame_destroy(f);
+        return st;
+    }
+    *out = f;
+    return VOHIP_OK;
+}
+
+int vohip_frame_destroy(vohip_frame *f)
+{
+    if (!f) return VOHIP_OK;
+    if (f->ctx) (void)hipSetDevice(f->ctx->device);
+    if (f->side) {
+        (void)hipStreamSynchronize(f->side);
+        (void)hipStreamDestroy(f->side);
+    }
+    if (f->ctx) (void)hipStreamSynchronize(f->ctx->stream);
+    if (f->ev_pyr) (void)hipEventDestroy(f->ev_pyr);
+    if (f->ev_side) (void)hipEventDestroy(f->ev_side);
+    if (f->block) (void)hipFree(f->block);
+    if (f->pinned) (void)hipHostFree(f->pinned);
+    delete f;
+    return VOHIP_OK;
+}
+
+// main_demo.m:268-303 (the parts the no-BA loop uses) and :342-344.
+int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device, const double *X, const double *ids,
+                      const double *P_rc, int n, const double T_W_C[16])
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, image && X && P_rc && T_W_C, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 1 && n <= f->capL, "landmark count outside the capacity");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    VOHIP_HIP(ctx, hipStreamSynchronize(f->side));
+    const uint8_t *d_img = image;
+    if (!image_on_device) {
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->img, image, (size_t)f->rows * f->cols, hipMemcpyHostToDevice, s));
+        d_img = f->img;
+    }
+    VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_prev, d_img, f->rows, f->cols, f->colmajor, f->prm.klt_levels));
+    VOHIP_HIP(ctx, hipMemsetAsync(f->cnt, 0, sizeof(int) * N_COUNTERS, s));
+    VOHIP_HIP(ctx, hipMemsetAsync(f->dv, 0, sizeof(double) * N_DOUBLES, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->L_rc, P_rc, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->L_X, X, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+    double *hd = (double *)((char *)f->pinned + 256);
+    std::memcpy(hd, T_W_C, sizeof(double) * 16);
+    hd[16] = ids ? 0.0 : (double)(n + 1);
+    if (ids) {
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->L_id, ids, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        double mx = 0.0;
+        for (int i = 0; i < n; ++i) mx = ids[i] > mx ? ids[i] : mx;
+        hd[16] = mx + 1.0;
+    } else {
+        // 1..n, staged through the (still unused) tracker output buffer
+        double *tmp = (double *)std::malloc(sizeof(double) * n);
+        if (!tmp) return vohip_fail(ctx, VOHIP_ERR_HIP, "out of host memory");
+        for (int i = 0; i < n; ++i) tmp[i] = (double)(i + 1);
+        hipError_t e = hipMemcpyAsync(f->L_id, tmp, sizeof(double) * n, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        std::free(tmp);
+        VOHIP_HIP(ctx, e);
+    }
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->dv + D_T, hd, sizeof(double) * 16, hipMemcpyHostToDevice, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->dv + D_IDX, hd + 16, sizeof(double), hipMemcpyHostToDevice, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->dv + D_IDX_NEXT, hd + 16, sizeof(double), hipMemcpyHostToDevice, s));
+    int *hc = (int *)f->pinned;
+    hc[0] = n;
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->cnt + N_L_END, hc, sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(next_tracks_kernel, dim3(blocks256(n)), dim3(256), 0, s, f->L_rc, f->capL, f->L_xy, f->C_rc,
+                       f->capC, f->C_xy, f->cnt, f->dv);
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    f->n_L = n;
+    f->n_C = 0;
+    f->stage = 0;
+    return VOHIP_OK;
+}
+
+int vohip_frame_track(vohip_frame *f, const uint8_t *image, int image_on_device)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, image, "NULL image");
+    VOHIP_REQUIRE(ctx, f->stage == 0, "vohip_frame_track called out of order");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const vohip_frame_params &p = f->prm;
+    const uint8_t *d_img = image;
+    if (!image_on_device) {
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->img, image, (size_t)f->rows * f->cols, hipMemcpyHostToDevice, s));
+        d_img = f->img;
+    }
+    f->cur_img = d_img;
+    VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));
+    // second stream: corner detection (main_demo.m:377) and the candidate tracker
+    // (update_landmarks.m:10) need only the two pyramids and last frame's candidates
+    {
+        stream_swap sw(ctx, f->side);
+        VOHIP_HIP(ctx, hipStreamWaitEvent(f->side, f->ev_pyr, 0));
+        if (f->n_C > 0)
+            VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->C_xy, f->capC, f->n_C, nullptr, p.klt_block,
+                                        p.klt_max_iter, p.klt_max_bidir_error, f->kC_out, f->kC_valid, nullptr));
+        VOHIP_TRY(vohip_detect_corners_dev(ctx, d_img, f->rows, f->cols, f->colmajor, p.min_quality, p.filter_size,
+                                           p.border, p.detector, f->corner_xy, f->corner_metric, f->capK,
+                                           f->cnt + N_DET));
+        VOHIP_HIP(ctx, hipEventRecord(f->ev_side, f->side));
+    }
+    // landmark tracker (main_demo.m:380) and the selection of the valid tracks (:381, :387)
+    VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->L_xy, f->capL, f->n_L, nullptr, p.klt_block,
+                                p.klt_max_iter, p.klt_max_bidir_error, f->kL_out, f->kL_valid, nullptr));
+    hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->kL_out, f->capL, f->kL_valid,
+                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->cnt);
+    VOHIP_HIP(ctx, hipGetLastError());
+    f->evaluated = 0;
+    f->stage = 1;
+    return VOHIP_OK;
+}
+
+int vohip_frame_localize(vohip_frame *f, const double *uniforms, int h, vohip_frame_pose *out)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, uniforms && out, "NULL argument");
+    VOHIP_REQUIRE(ctx, f->stage == 1, "vohip_frame_localize called out of order");
+    VOHIP_REQUIRE(ctx, h > f->evaluated && h <= f->hmax, "hypothesis count must grow and stay within max_hypotheses");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const vohip_frame_params &p = f->prm;
+    const int first = f->evaluated, more = h - first;
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3 + 3 * (size_t)first, uniforms + 3 * (size_t)first, sizeof(double) * 3 * more,
+                                  hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more)), dim3(256), 0, s, f->u3, first, more, f->cnt, f->samples3);
+    VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
+                                   f->counts4));
+    f->evaluated = h;
+    hipLaunchKernelGGL(localize_decide_kernel, dim3(1), dim3(64), 0, s, f->counts4, h,
+                       (const double *)ctx->bufs[B_RANSAC_RT].ptr, (const double *)ctx->bufs[B_RANSAC_M].ptr, f->cnt,
+                       f->dv);
+    VOHIP_TRY(vohip_ransac_mask_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->dv + D_M, f->mask));
+    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->mv_rc, f->Xv, f->idv, f->mask,
+                       f->cnt, f->L_rc, f->L_X, f->L_id, f->kp_uv);
+    VOHIP_HIP(ctx, hipGetLastError());
+    if (p.refine_pose)   // main_demo.m:398-400
+        VOHIP_TRY(vohip_pose_refine_enqueue(ctx, f->dv + D_T, f->kp_uv, f->L_X, f->n_L, f->cnt + N_IN, f->K,
+                                            p.refine_max_iter, 1e-10, 1e-10, f->dv + D_STATS));
+    VOHIP_TRY(fetch_summary(f));
+    const int *hc = (const int *)f->pinned;
+    const double *hd = (const double *)((const char *)f->pinned + 256);
+    std::memset(out, 0, sizeof(*out));
+    out->n_tracked = hc[N_V];
+    out->n_iter = hc[R_ITER];
+    out->found = hc[R_FOUND];
+    out->exhausted = hc[R_EXHAUSTED];
+    out->n_inliers = hc[N_IN];
+    out->max_num_inliers = hc[R_MAX_INL];
+    out->evaluated = h;
+    out->num_iterations = hd[D_NUM_ITER];
+    std::memcpy(out->T_W_C, hd + D_T, sizeof(double) * 16);
+    std::memcpy(out->Rt, hd + D_RT, sizeof(double) * 12);
+    std::memcpy(out->refine_stats, hd + D_STATS, sizeof(double) * 3);
+    if (hc[N_V] < 3) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "only %d landmarks were tracked", hc[N_V]);
+    if (hc[R_EXHAUSTED] && h < f->hmax)
+        return vohip_fail(ctx, VOHIP_SAMPLES_EXHAUSTED, "the adaptive bound (%.0f) exceeds the %d hypotheses supplied",
+                          hd[D_NUM_ITER], h);
+    f->stage = 2;
+    if (!hc[R_FOUND]) return vohip_fail(ctx, VOHIP_NO_MODEL, "no hypothesis reached 30 inliers in %d iterations", hc[R_ITER]);
+    return VOHIP_OK;
+}
+
+int vohip_frame_map(vohip_frame *f, const double *uniforms, vohip_frame_counts *out)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, out, "NULL argument");
+    VOHIP_REQUIRE(ctx, f->stage == 2, "vohip_frame_map called out of order");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const vohip_frame_params &p = f->prm;
+    const int T = p.fm_trials;
+    const bool have_map = f->n_C > 0;   // main_demo.m:406
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_side, 0));
+    if (have_map) {
+        VOHIP_REQUIRE(ctx, uniforms, "NULL uniforms");
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, uniforms, sizeof(double) * 8 * (size_t)T, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->kC_out, f->capC,
+                           f->kC_valid, f->C_rc, f->F_rc, f->T12, f->n_C, f->p1_rc, f->m_rc, f->F_t, f->T_t, f->cnt);
+        hipLaunchKernelGGL(octets_kernel, dim3((T + 63) / 64), dim3(64), 0, s, f->u8, T, f->cnt, f->samples8);
+        VOHIP_TRY(vohip_fm_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->samples8, T, p.fm_threshold,
+                                   f->dv + D_NRM, f->fm_F, f->fm_counts));
+        hipLaunchKernelGGL(fm_decide_kernel, dim3(1), dim3(64), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
+                           f->dv);
+        VOHIP_TRY(vohip_fm_mask_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->dv + D_F, p.fm_threshold,
+                                        f->fmask));
+        hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->m_rc, f->F_t, f->T_t,
+                           f->fmask, f->cnt, f->m2_rc, f->F2, f->T2);
+        VOHIP_TRY(vohip_candidate_triangulate_enqueue(ctx, f->m2_rc, f->F2, f->T2, f->n_C, f->cnt + N_CI, f->dv + D_T,
+                                                      f->K, p.angle_threshold_deg, p.min_depth, p.max_depth, 0,
+                                                      f->status, f->Xnew));
+        hipLaunchKernelGGL(split_candidates_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->status, f->m2_rc, f->F2,
+                           f->T2, f->Xnew, f->cnt, f->dv, f->capL, f->L_rc, f->L_X, f->L_id, f->C_rc, f->F_rc, f->T12);
+    }
+    hipLaunchKernelGGL(filter_counts_kernel, dim3(1), dim3(64), 0, s, f->cnt, f->capK, have_map ? 1 : 0, f->dv);
+    VOHIP_TRY(vohip_candidate_filter_enqueue(ctx, f->corner_xy, f->capK, f->capK, f->C_rc, f->L_rc, f->cnt + FILT0,
+                                             p.r_discard_redundant, f->keep));
+    hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s, f->corner_xy, f->capK,
+                       f->keep, f->cnt, f->dv, f->capC, f->C_rc, f->F_rc, f->T12);
+    const int nmax = f->capL > f->capC ? f->capL : f->capC;
+    hipLaunchKernelGGL(next_tracks_kernel, dim3(blocks256(nmax)), dim3(256), 0, s, f->L_rc, f->capL, f->L_xy, f->C_rc,
+                       f->capC, f->C_xy, f->cnt, f->dv);
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_TRY(fetch_summary(f));
+    const int *hc = (const int *)f->pinned;
+    std::memset(out, 0, sizeof(*out));
+    out->n_landmarks = hc[N_L_END];
+    out->n_candidates = hc[N_C_END];
+    out->num_new = hc[NUM_NEW];
+    out->n_detected = hc[N_DET];
+    out->n_kept = hc[N_KEPT];
+    out->n_candidates_tracked = have_map ? hc[N_CV] : 0;
+    out->n_candidates_inliers = have_map ? hc[N_CI] : 0;
+    out->fm_trials_run = have_map ? hc[F_TRIALS] : 0;
+    out->overflow = hc[OVERFLOW];
+    const int t = f->slot_prev;   // main_demo.m:417-424: this frame's pyramid is the next "previous"
+    f->slot_prev = f->slot_cur;
+    f->slot_cur = t;
+    f->n_L = hc[N_L_END];
+    f->n_C = hc[N_C_END];
+    f->stage = 0;
+    if (have_map && hc[N_CV] < 8)
+        return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "the 8-point algorithm needs 8 candidate tracks, got %d", hc[N_CV]);
+    if (hc[N_DET] > f->capK)
+        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "%d corners found, capacity %d", hc[N_DET], f->capK);
+    if (hc[OVERFLOW])
+        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "landmark or candidate capacity exceeded (flags %d)", hc[OVERFLOW]);
+    return VOHIP_OK;
+}
+
+int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    if (n_landmarks) *n_landmarks = f->n_L;
+    if (n_candidates) *n_candidates = f->n_C;
+    return VOHIP_OK;
+}
+
+int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc, double *T12)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, f->stage == 0, "the state is complete only between frames");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nL = f->n_L, nC = f->n_C;
+    if (P_rc) VOHIP_TRY(vohip_download(ctx, P_rc, f->L_rc, sizeof(double) * 2 * nL));
+    if (X) VOHIP_TRY(vohip_download(ctx, X, f->L_X, sizeof(double) * 3 * nL));
+    if (ids) VOHIP_TRY(vohip_download(ctx, ids, f->L_id, sizeof(double) * nL));
+    if (C_rc) VOHIP_TRY(vohip_download(ctx, C_rc, f->C_rc, sizeof(double) * 2 * nC));
+    if (F_rc) VOHIP_TRY(vohip_download(ctx, F_rc, f->F_rc, sizeof(double) * 2 * nC));
+    if (T12) VOHIP_TRY(vohip_download(ctx, T12, f->T12, sizeof(double) * 12 * nC));
+    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VOHIP_OK;
+}
+
+}  // extern "C"

@@ -83,16 +83,22 @@ __global__ __launch_bounds__(128) void triangulate_refine_kernel(const double *_
 // update_candidate.m:14-24.  One wavefront per new detection; its lanes stride over the existing
 // points (S.C then S.P, rounded to single exactly as MATLAB's single/double comparison does) and a
 // ballot ends the search at the first hit.
-__global__ __launch_bounds__(256) void candidate_filter_kernel(const float *__restrict__ new_xy, int n_new,
+__global__ __launch_bounds__(256) void candidate_filter_kernel(const float *__restrict__ new_xy, int ld, int n_new,
                                                                const double *__restrict__ C_rc, int nC,
                                                                const double *__restrict__ P_rc, int nP,
-                                                               float r, uint8_t *__restrict__ keep)
+                                                               const int *__restrict__ counts_dev, float r,
+                                                               uint8_t *__restrict__ keep)
 {
+    if (counts_dev) {  // {n_new, nC, nP} kept on the device (the frame pipeline); n_new is clamped
+        n_new = min(counts_dev[0], n_new);
+        nC = counts_dev[1];
+        nP = counts_dev[2];
+    }
     // one wavefront per new point: the lanes stride over C and then P, 4 loads in flight each
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (i >= n_new) return;
-    const float x = new_xy[i], y = new_xy[n_new + i];
+    const float x = new_xy[i], y = new_xy[ld + i];
     const float u0 = x - r, u1 = x + r, v0 = y - r, v1 = y + r;
     bool near = false;
     const int total = nC + nP;
@@ -127,12 +133,17 @@ struct cand_params {
 __global__ __launch_bounds__(128) void candidate_triangulate_kernel(const double *__restrict__ cur_rc,
                                                                     const double *__restrict__ first_rc,
                                                                     const double *__restrict__ T_first, int n,
+                                                                    const int *__restrict__ n_dev,
+                                                                    const double *__restrict__ T_dev,
                                                                     cand_params prm, uint8_t *__restrict__ status,
                                                                     double *__restrict__ X_out,
                                                                     double *__restrict__ angles)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = *n_dev;  // count and pose kept on the device (the frame pipeline)
     if (i >= n) return;
+    if (T_dev)
+        for (int q = 0; q < 16; ++q) prm.T_W_C[q] = T_dev[q];
     double Tf[12];
     for (int k = 0; k < 12; ++k) Tf[k] = T_first[12 * (size_t)i + k];
     const double cur[2] = {cur_rc[2 * (size_t)i], cur_rc[2 * (size_t)i + 1]};
@@ -241,11 +252,47 @@ int vohip_candidate_filter_dev(vohip_ctx *ctx, const float *d_new_xy, int n_new,
     VOHIP_REQUIRE(ctx, n_new >= 0 && nC >= 0 && nP >= 0 && d_keep, "bad argument");
     VOHIP_REQUIRE(ctx, (n_new == 0 || d_new_xy) && (nC == 0 || d_C_rc) && (nP == 0 || d_P_rc), "NULL array");
     if (n_new == 0) return VOHIP_OK;
-    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new + 3) / 4), dim3(256), 0, ctx->stream, d_new_xy,
-                       n_new, d_C_rc, nC, d_P_rc, nP, (float)r, d_keep);
+    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new + 3) / 4), dim3(256), 0, ctx->stream, d_new_xy, n_new,
+                       n_new, d_C_rc, nC, d_P_rc, nP, (const int *)nullptr, (float)r, d_keep);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
+
+}  // extern "C"
+
+// Frame-pipeline form: x and y columns `ld` apart, at most n_new_cap detections, the three counts
+// {n_new, nC, nP} in device memory.
+int vohip_candidate_filter_enqueue(vohip_ctx *ctx, const float *d_new_xy, int ld, int n_new_cap, const double *d_C_rc,
+                                   const double *d_P_rc, const int *d_counts3, double r, uint8_t *d_keep)
+{
+    if (n_new_cap <= 0) return VOHIP_OK;
+    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new_cap + 3) / 4), dim3(256), 0, ctx->stream, d_new_xy, ld,
+                       n_new_cap, d_C_rc, 0, d_P_rc, 0, d_counts3, (float)r, d_keep);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+// Frame-pipeline form of the candidate triangulation: count and current pose in device memory.
+int vohip_candidate_triangulate_enqueue(vohip_ctx *ctx, const double *d_cur_rc, const double *d_first_rc,
+                                        const double *d_T_first, int n_cap, const int *d_n, const double *d_T_W_C,
+                                        const double K[9], double angle_threshold_deg, double min_depth,
+                                        double max_depth, int is_BA, uint8_t *d_status, double *d_X)
+{
+    if (n_cap <= 0) return VOHIP_OK;
+    cand_params prm;
+    std::memset(prm.T_W_C, 0, sizeof(prm.T_W_C));
+    std::memcpy(prm.K, K, sizeof(prm.K));
+    prm.angle_threshold_deg = angle_threshold_deg;
+    prm.min_depth = min_depth;
+    prm.max_depth = max_depth;
+    prm.is_BA = is_BA;
+    hipLaunchKernelGGL(candidate_triangulate_kernel, dim3((n_cap + 127) / 128), dim3(128), 0, ctx->stream, d_cur_rc,
+                       d_first_rc, d_T_first, n_cap, d_n, d_T_W_C, prm, d_status, d_X, (double *)nullptr);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+extern "C" {
 
 int vohip_candidate_filter(vohip_ctx *ctx, const float *new_xy, int n_new, const double *C_rc, int nC,
                            const double *P_rc, int nP, double r, uint8_t *keep)
@@ -282,7 +329,8 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
     prm.max_depth = max_depth;
     prm.is_BA = is_BA;
     hipLaunchKernelGGL(candidate_triangulate_kernel, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, d_cur_rc,
-                       d_first_rc, d_T_first, n, prm, d_status, d_X, d_angles);
+                       d_first_rc, d_T_first, n, (const int *)nullptr, (const double *)nullptr, prm, d_status, d_X,
+                       d_angles);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }

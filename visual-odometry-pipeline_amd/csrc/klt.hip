@@ -248,11 +248,13 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
     return ok0;
 }
 
-// pts_xy / out_xy: n x 2 column-major, MATLAB's (x, y), 1-based.  swap_xy: the image is a
-// column-major MATLAB image, so a = y - 1, b = x - 1; otherwise a = x - 1, b = y - 1.
+// pts_xy / out_xy: x column then y column with leading dimension ld, MATLAB's (x, y), 1-based.
+// swap_xy: the image is a column-major MATLAB image, so a = y - 1, b = x - 1; otherwise a = x - 1,
+// b = y - 1.  The point count is n, or *n_dev when n_dev is given (n then only sizes the grid).
 template <int W>
 __global__ __launch_bounds__(64) void klt_track_kernel(pyr_desc P, pyr_desc Q, const double *__restrict__ pts_xy,
-                                                       int n, int swap_xy, int max_iter, double max_bidir,
+                                                       int n, const int *__restrict__ n_dev, int ld, int swap_xy,
+                                                       int max_iter, double max_bidir,
                                                        double *__restrict__ out_xy, uint8_t *__restrict__ valid,
                                                        double *__restrict__ fb_err)
 {
@@ -260,8 +262,9 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_desc P, pyr_desc Q, c
     __shared__ float sI[C::SI * C::SI];
     __shared__ float sJ[C::SJ * C::SJ];
     const int i = blockIdx.x;
+    if (n_dev) n = *n_dev;
     if (i >= n) return;
-    const double x = pts_xy[i] - 1.0, y = pts_xy[n + i] - 1.0;
+    const double x = pts_xy[i] - 1.0, y = pts_xy[ld + i] - 1.0;
     const double pa = swap_xy ? y : x, pb = swap_xy ? x : y;
     double qa, qb, ra, rb;
     const bool ok_f = track_dir<W>(P, Q, max_iter, pa, pb, qa, qb, sI, sJ);
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_desc P, pyr_desc Q, c
     const bool inside = qa >= 0.0 && qa <= (double)(P.A[0] - 1) && qb >= 0.0 && qb <= (double)(P.B[0] - 1);
     if (threadIdx.x == 0) {
         out_xy[i] = (swap_xy ? qb : qa) + 1.0;
-        out_xy[n + i] = (swap_xy ? qa : qb) + 1.0;
+        out_xy[ld + i] = (swap_xy ? qa : qb) + 1.0;
         valid[i] = (ok_f && ok_b && inside && err <= max_bidir) ? 1 : 0;
         if (fb_err) fb_err[i] = err;
     }
@@ -359,8 +362,18 @@ int vohip_pyramid_level(vohip_ctx *ctx, int slot, int level, float *out, int *A,
 int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int n, int block_size,
                         int max_iter, double max_bidir_error, double *d_out_xy, uint8_t *d_valid, double *d_fb_err)
 {
+    return vohip_klt_enqueue(ctx, slot_prev, slot_cur, d_pts_xy, n, n, nullptr, block_size, max_iter, max_bidir_error,
+                             d_out_xy, d_valid, d_fb_err);
+}
+
+}  // extern "C"
+
+int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int ld, int n,
+                      const int *d_n, int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
+                      uint8_t *d_valid, double *d_fb_err)
+{
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
-    VOHIP_REQUIRE(ctx, n >= 0 && max_iter >= 1, "bad argument");
+    VOHIP_REQUIRE(ctx, n >= 0 && max_iter >= 1 && ld >= n, "bad argument");
     if (n == 0) return VOHIP_OK;
     VOHIP_REQUIRE(ctx, d_pts_xy && d_out_xy && d_valid, "NULL array");
     pyr_desc P, Q;
@@ -371,16 +384,18 @@ int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const doubl
                   "previous and current pyramids differ in shape");
     const int swap_xy = pp.colmajor;
     if (block_size == 21)
-        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, swap_xy,
-                           max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err);
+        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, d_n, ld,
+                           swap_xy, max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err);
     else if (block_size == 31)
-        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, swap_xy,
-                           max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err);
+        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, d_n, ld,
+                           swap_xy, max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err);
     else
         return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "BlockSize %d not built (21 and 31 are)", block_size);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
+
+extern "C" {
 
 int vohip_klt_track(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *pts_xy, int n, int block_size,
                     int max_iter, double max_bidir_error, double *out_xy, uint8_t *valid, double *fb_err)

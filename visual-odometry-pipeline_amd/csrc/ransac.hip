@@ -301,13 +301,15 @@ __device__ __forceinline__ void decode_pose(const vohip_K &K, const double pose[
 }
 
 __global__ __launch_bounds__(64) void p3p_solve_kernel(const double *__restrict__ kp_rc,
-                                                       const double *__restrict__ X, int n, vohip_K K,
+                                                       const double *__restrict__ X, int n,
+                                                       const int *__restrict__ n_dev, vohip_K K,
                                                        const int32_t *__restrict__ samples, int h,
                                                        double *__restrict__ Rt_out,
                                                        double *__restrict__ M_out)
 {
     const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
     if (hyp >= h) return;
+    if (n_dev) n = *n_dev;  // point count kept on the device (the frame pipeline)
     v3 W[3], bearing[3];
     bool ok = true;
     for (int c = 0; c < 3; ++c) {
@@ -392,10 +394,11 @@ constexpr int SCORE_WAVES = 8;  // default hypotheses per workgroup (chunk granu
 // tile t+1 are issued before the arithmetic on tile t and written to the other LDS buffer after it.
 template <int WAVES, int TILE>
 __global__ __launch_bounds__(WAVES * 64) void p3p_score_kernel(
-    const double *__restrict__ kp_rc, const double *__restrict__ X, int n,
+    const double *__restrict__ kp_rc, const double *__restrict__ X, int n, const int *__restrict__ n_dev,
     const double *__restrict__ M, int h, int32_t *__restrict__ counts)
 {
     constexpr int NT = WAVES * 64;
+    if (n_dev) n = *n_dev;
     constexpr int PER_X = (3 * TILE + NT - 1) / NT;
     constexpr int PER_K = (2 * TILE + NT - 1) / NT;
     __shared__ double lds[2][5 * TILE];
@@ -496,6 +499,23 @@ __global__ __launch_bounds__(256) void inlier_mask_kernel(const double *__restri
     }
 }
 
+// The same mask for a pose that lives in device memory (m = K [R | t], row-major 3x4) and a
+// point count that may live there too.
+__global__ __launch_bounds__(256) void inlier_mask_dev_kernel(const double *__restrict__ kp_rc,
+                                                              const double *__restrict__ X, int n,
+                                                              const int *__restrict__ n_dev,
+                                                              const double *__restrict__ m12,
+                                                              uint8_t *__restrict__ mask)
+{
+    if (n_dev) n = *n_dev;
+    double m[12];
+    for (int q = 0; q < 12; ++q) m[q] = m12[q];
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        const bool in = is_inlier(m, X[3 * j], X[3 * j + 1], X[3 * j + 2], kp_rc[2 * j + 1], kp_rc[2 * j]);
+        mask[j] = in ? 1 : 0;
+    }
+}
+
 // K [R | t] on the host with the same statements as decode_pose (no contraction on the host
 // build either: the expression is a plain sum of products evaluated left to right).
 void host_fused_projection(const double K[9], const double Rt[12], double M[12])
@@ -530,22 +550,22 @@ int launch_solve(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n
     ctx->ransac_h = h;
     const vohip_K Kv = vohip_make_K(K);
     hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n,
-                       Kv, d_samples, h, (double *)ctx->bufs[B_RANSAC_RT].ptr,
+                       (const int *)nullptr, Kv, d_samples, h, (double *)ctx->bufs[B_RANSAC_RT].ptr,
                        (double *)ctx->bufs[B_RANSAC_M].ptr);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
 
 template <int WAVES, int TILE>
-void launch_score_t(hipStream_t st, const double *d_kp_rc, const double *d_X, int n, const double *d_M, int h,
-                    int32_t *d_counts)
+void launch_score_t(hipStream_t st, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
+                    const double *d_M, int h, int32_t *d_counts)
 {
     hipLaunchKernelGGL((p3p_score_kernel<WAVES, TILE>), dim3((h + WAVES - 1) / WAVES), dim3(WAVES * 64), 0, st,
-                       d_kp_rc, d_X, n, d_M, h, d_counts);
+                       d_kp_rc, d_X, n, d_n, d_M, h, d_counts);
 }
 
 int launch_score_variant(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const double *d_M,
-                         int h, int32_t *d_counts)
+                         int h, int32_t *d_counts, const int *d_n = nullptr)
 {
     // Geometry: many hypotheses -> 16 per workgroup share each staged tile (fewest L2->LDS bytes);
     // few hypotheses -> small workgroups so that more CUs take part.  Measured on MI355X:
@@ -553,12 +573,12 @@ int launch_score_variant(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
     int variant = ctx->opt_ransac_variant;
     if (variant < 0) variant = h >= 2048 ? 2 : (h < 512 ? 3 : 0);
     switch (variant) {
-    case 1: launch_score_t<8, 512>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
-    case 2: launch_score_t<16, 1024>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
-    case 3: launch_score_t<4, 512>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
-    case 4: launch_score_t<16, 512>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
-    case 5: launch_score_t<4, 256>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
-    default: launch_score_t<8, 1024>(ctx->stream, d_kp_rc, d_X, n, d_M, h, d_counts); break;
+    case 1: launch_score_t<8, 512>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
+    case 2: launch_score_t<16, 1024>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
+    case 3: launch_score_t<4, 512>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
+    case 4: launch_score_t<16, 512>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
+    case 5: launch_score_t<4, 256>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
+    default: launch_score_t<8, 1024>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
     }
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
@@ -570,6 +590,36 @@ int launch_count(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n
 }
 
 }  // namespace
+
+// Solve + score hypotheses [first, first + h) of the context's pose buffers (which must already be
+// reserved for first + h hypotheses) for points whose count may live on the device.
+int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
+                         const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts)
+{
+    VOHIP_REQUIRE(ctx, (size_t)(first + h) * 48 * sizeof(double) <= ctx->bufs[B_RANSAC_RT].cap &&
+                           (size_t)(first + h) * 48 * sizeof(double) <= ctx->bufs[B_RANSAC_M].cap,
+                  "pose buffers not reserved for this many hypotheses");
+    double *d_Rt = (double *)ctx->bufs[B_RANSAC_RT].ptr + (size_t)first * 48;
+    double *d_M = (double *)ctx->bufs[B_RANSAC_M].ptr + (size_t)first * 48;
+    const vohip_K Kv = vohip_make_K(K);
+    hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n, d_n, Kv,
+                       d_samples + 3 * (size_t)first, h, d_Rt, d_M);
+    VOHIP_TRY(launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, h, d_counts + 4 * (size_t)first, d_n));
+    if (ctx->ransac_h < first + h) ctx->ransac_h = first + h;
+    return VOHIP_OK;
+}
+
+int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
+                              const double *d_M12, uint8_t *d_mask)
+{
+    const int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(inlier_mask_dev_kernel, dim3(blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks)), dim3(256), 0,
+                       ctx->stream, d_kp_rc, d_X, n, d_n, d_M12, d_mask);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+double vohip_ransac_adaptive_iterations(int max_num_inliers, int n) { return adaptive_num_iterations(max_num_inliers, n); }
 
 extern "C" {
 
@@ -686,8 +736,8 @@ int vohip_ransac_p3p(vohip_ctx *ctx, const double *kp_rc, const double *X, int n
             if (want < 64) want = 64;
             want = (want + SCORE_WAVES - 1) / SCORE_WAVES * SCORE_WAVES;
             if (want > hcap - evaluated) want = hcap - evaluated;
-            hipLaunchKernelGGL(p3p_solve_kernel, dim3((want + 63) / 64), dim3(64), 0, st, d_kp, d_X, n, Kv,
-                               d_samples + 3 * (size_t)evaluated, want, d_Rt + (size_t)evaluated * 48,
+            hipLaunchKernelGGL(p3p_solve_kernel, dim3((want + 63) / 64), dim3(64), 0, st, d_kp, d_X, n,
+                               (const int *)nullptr, Kv, d_samples + 3 * (size_t)evaluated, want, d_Rt + (size_t)evaluated * 48,
                                d_M + (size_t)evaluated * 48);
             VOHIP_TRY(launch_score_variant(ctx, d_kp, d_X, n, d_M + (size_t)evaluated * 48, want,
                                            d_counts + 4 * (size_t)evaluated));

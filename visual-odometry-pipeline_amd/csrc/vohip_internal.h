@@ -97,6 +97,32 @@ static inline int vohip_download(vohip_ctx *ctx, void *dst, const void *dsrc, si
     return VOHIP_OK;
 }
 
+// Launchers shared between translation units.  They enqueue on ctx->stream and never synchronise;
+// a count argument `n` sizes the grid (an upper bound) and `d_n`, when not NULL, points to the
+// actual count in device memory.
+int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int ld, int n,
+                      const int *d_n, int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
+                      uint8_t *d_valid, double *d_fb_err);
+int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
+                         const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts);
+int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
+                              const double *d_M12, uint8_t *d_mask);
+double vohip_ransac_adaptive_iterations(int max_num_inliers, int n);
+int vohip_fm_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int *d_n,
+                     const int32_t *d_samples, int num_trials, double threshold, double *d_nrm, double *d_F,
+                     int32_t *d_counts);
+int vohip_fm_mask_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int *d_n,
+                          const double *d_F9, double threshold, uint8_t *d_mask);
+int vohip_candidate_filter_enqueue(vohip_ctx *ctx, const float *d_new_xy, int ld, int n_new_cap, const double *d_C_rc,
+                                   const double *d_P_rc, const int *d_counts3, double r, uint8_t *d_keep);
+int vohip_candidate_triangulate_enqueue(vohip_ctx *ctx, const double *d_cur_rc, const double *d_first_rc,
+                                        const double *d_T_first, int n_cap, const int *d_n, const double *d_T_W_C,
+                                        const double K[9], double angle_threshold_deg, double min_depth,
+                                        double max_depth, int is_BA, uint8_t *d_status, double *d_X);
+int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, const double *d_X, int n,
+                              const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
+                              double *d_stats);
+
 // Camera matrix passed to kernels by value (column-major, as MATLAB stores it).
 struct vohip_K {
     double k[9];

@@ -8,18 +8,29 @@ from . import _lib
 from ._lib import VOHIP_NO_MODEL, dptr
 
 
+def octets_from_uniforms(r, n):
+    """Maps a (count, 8) array of uniforms in [0, 1) to `count` sets of 8 distinct indices in
+    [0, n): draw k picks the floor(r_k (n - k))-th index not picked before (a partial Fisher-Yates
+    shuffle written without the array), so exactly 8 uniforms are consumed per set."""
+    r = np.asarray(r, dtype=np.float64)
+    count = r.shape[0]
+    chosen = np.zeros((count, 0), dtype=np.int64)      # kept sorted along axis 1
+    out = np.zeros((count, 8), dtype=np.int64)
+    for k in range(8):
+        idx = np.minimum((r[:, k] * (n - k)).astype(np.int64), n - k - 1)
+        for m in range(k):
+            idx = idx + (idx >= chosen[:, m])
+        out[:, k] = idx
+        chosen = np.sort(np.concatenate([chosen, idx[:, None]], axis=1), axis=1)
+    return out.astype(np.int32)
+
+
 def draw_octets(rng, n, count):
     """`count` sets of 8 distinct indices in [0, n): the stand-in for the toolbox's internal
-    sampling.  Rows with a repeated index are redrawn (whole row) until all are distinct."""
+    sampling.  Consumes exactly 8 * count draws of `rng`."""
     if n < 8:
         raise ValueError("need at least 8 points")
-    out = np.minimum((rng.random((count, 8)) * n).astype(np.int64), n - 1)
-    while True:
-        srt = np.sort(out, axis=1)
-        bad = np.flatnonzero((np.diff(srt, axis=1) == 0).any(axis=1))
-        if bad.size == 0:
-            return out.astype(np.int32)
-        out[bad] = np.minimum((rng.random((bad.size, 8)) * n).astype(np.int64), n - 1)
+    return octets_from_uniforms(rng.random((count, 8)), n)
 
 
 def estimateFundamentalMatrix(matchedPoints1, matchedPoints2, NumTrials=500, DistanceThreshold=0.01,

@@ -1,0 +1,160 @@
+"""The continuous-operation loop (main_demo.m:377-427, is_BA = false) with its state resident on the
+GPU: a thin driver over the vohip_frame_* entry points of libvohip.so.  Same constructor and
+methods as pipeline.VOPipeline; the state S is downloaded only when asked for.
+
+Per frame the host does three library calls and draws the random numbers the two RANSAC stages
+consume, from the same generator and in the same order as VOPipeline: 3 uniforms per P3P hypothesis
+(the generator ends up advanced by exactly n_iter triples, as ransacLocalization would leave it),
+then 8 per fundamental-matrix trial.
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib
+from ._lib import VOHIP_NO_MODEL, VOHIP_SAMPLES_EXHAUSTED, colmajor, dptr
+from .pipeline import default_hyper_paras
+from .ransac import MAX_ITERATIONS
+
+
+class VOPipelineDevice:
+    def __init__(self, K, first_image, p_W_landmarks, keypoints_xy, T_init_WC, hyper_paras=None, rng=None, ctx=None,
+                 tracker_options=None, cap_landmarks=8192, cap_candidates=8192, cap_corners=16384):
+        self.ctx = ctx or _lib.default_context()
+        self.K = np.asarray(K, dtype=np.float64)
+        self.hp = hyper_paras or default_hyper_paras()
+        if self.hp.is_BA:
+            raise NotImplementedError("the device-resident loop has no bundle adjustment; use VOPipeline")
+        if self.hp.feature_extract not in ("Harris", "MinEigen"):
+            raise NotImplementedError("detector '%s' is not built" % self.hp.feature_extract)
+        self.rng = rng or np.random.default_rng()
+        lib = _lib.load()
+        prm = _lib.FrameParams()
+        lib.vohip_frame_default_params(C.byref(prm))
+        opts = dict(BlockSize=[21, 21], NumPyramidLevels=5, MaxIterations=20, MaxBidirectionalError=6)  # main_demo.m:342-349
+        opts.update(tracker_options or {})
+        prm.klt_block = int(np.atleast_1d(opts["BlockSize"])[0])
+        prm.klt_levels = int(opts["NumPyramidLevels"])
+        prm.klt_max_iter = int(opts["MaxIterations"])
+        e = float(opts["MaxBidirectionalError"])
+        prm.klt_max_bidir_error = e if np.isfinite(e) else 1e300
+        fo = dict(zip(self.hp.feature_extract_options[::2], self.hp.feature_extract_options[1::2]))
+        prm.detector = 0 if self.hp.feature_extract == "Harris" else 1
+        prm.min_quality = float(fo.get("MinQuality", 0.01))
+        prm.filter_size = int(fo.get("FilterSize", 5))
+        prm.r_discard_redundant = float(self.hp.r_discard_redundant)
+        prm.angle_threshold_deg = float(self.hp.angle_threshold)
+        prm.min_depth = float(self.hp.min_depth)
+        prm.max_depth = float(self.hp.max_depth)
+        prm.refine_pose = int(bool(self.hp.is_refine_pose))
+        prm.cap_landmarks, prm.cap_candidates, prm.cap_corners = int(cap_landmarks), int(cap_candidates), int(cap_corners)
+        free = self.ctx.__dict__.setdefault("_free_pyr_slots", list(range(8)))
+        if len(free) < 2:
+            raise RuntimeError("the context has fewer than 2 free pyramid slots")
+        self._slots = [free.pop(), free.pop()]
+        prm.slot_a, prm.slot_b = self._slots
+        self.params = prm
+        shape = tuple(first_image.shape)
+        self._colmajor = 0
+        if not hasattr(first_image, "data_ptr"):
+            first_image = np.asarray(first_image)
+            self._colmajor = int(first_image.flags.f_contiguous and not first_image.flags.c_contiguous)
+        self._shape = shape
+        h = C.c_void_p()
+        self.ctx.check(lib.vohip_frame_create(self.ctx.handle, dptr(colmajor(self.K)), shape[0], shape[1], self._colmajor,
+                                              C.byref(prm), C.byref(h)))
+        self._h = h
+        X = np.ascontiguousarray(np.asarray(p_W_landmarks, dtype=np.float64).reshape(-1, 3))
+        P_rc = np.ascontiguousarray(np.asarray(keypoints_xy, dtype=np.float64).reshape(-1, 2)[:, ::-1])
+        T = np.asarray(T_init_WC, dtype=np.float64)
+        ptr, on_dev, keep = self._image_ptr(first_image)
+        self.ctx.check(lib.vohip_frame_reset(self._h, ptr, on_dev, dptr(X), None, dptr(P_rc), X.shape[0],
+                                             dptr(colmajor(T))))
+        del keep
+        self.est_trans = [T[:3, 3].copy()]
+        self.est_rot = [T[:3, :3].reshape(-1, order="F").copy()]
+        self.num_X, self.num_C, self.num_new = [X.shape[0]], [0], [0]
+        self.frames = 0
+        self.last_pose = None
+        self.last_counts = None
+
+    def _image_ptr(self, image):
+        if hasattr(image, "data_ptr"):                      # uint8 image already on the GPU (torch tensor)
+            if tuple(image.shape) != self._shape:
+                raise ValueError("image shape changed")
+            return C.c_void_p(image.data_ptr()), 1, image
+        img = np.asarray(image)
+        if img.dtype != np.uint8 or img.shape != self._shape:
+            raise TypeError("image must be a uint8 array of shape %s" % (self._shape,))
+        cm = int(img.flags.f_contiguous and not img.flags.c_contiguous)
+        if cm != self._colmajor:
+            img = np.asfortranarray(img) if self._colmajor else np.ascontiguousarray(img)
+        return C.c_void_p(img.ctypes.data), 0, img
+
+    def process_frame(self, image):
+        lib = _lib.load()
+        ptr, on_dev, keep = self._image_ptr(image)
+        self.ctx.check(lib.vohip_frame_track(self._h, ptr, on_dev))                        # :377, :380
+        pose = _lib.FramePose()
+        state = self.rng.bit_generator.state
+        have = 104
+        while True:                                                                         # :387-388
+            self.rng.bit_generator.state = state
+            u = self.rng.random((have, 3))
+            st = lib.vohip_frame_localize(self._h, dptr(u), have, C.byref(pose))
+            if st == VOHIP_SAMPLES_EXHAUSTED and have < MAX_ITERATIONS:
+                have = min(max(8 * have, int(np.ceil(pose.num_iterations)) + 8), MAX_ITERATIONS)
+                continue
+            break
+        self.rng.bit_generator.state = state
+        if pose.n_iter > 0:
+            self.rng.random((pose.n_iter, 3))       # the generator as n_iter executed iterations leave it
+        if st == VOHIP_NO_MODEL:
+            raise RuntimeError("ransacLocalization found no pose (the reference fails here too, main_demo.m:389-391)")
+        self.ctx.check(st)
+        counts = _lib.FrameCounts()
+        u8 = self.rng.random((self.params.fm_trials, 8)) if self.num_C[-1] > 0 else None    # update_landmarks.m:13
+        self.ctx.check(lib.vohip_frame_map(self._h, dptr(u8) if u8 is not None else None, C.byref(counts)))
+        del keep
+        T_W_C = np.array(pose.T_W_C).reshape(4, 4).T.copy()
+        self.est_trans.append(T_W_C[:3, 3].copy())                                          # :401-403
+        self.est_rot.append(T_W_C[:3, :3].reshape(-1, order="F").copy())
+        if self.num_C[-1] > 0:
+            self.num_new.append(counts.num_new)                                             # update_landmarks.m:124
+        self.num_X.append(counts.n_landmarks)                                               # :426-427
+        self.num_C.append(counts.n_candidates)
+        self.frames += 1
+        self.last_pose, self.last_counts = pose, counts
+        return T_W_C
+
+    def trajectory(self):
+        """est_trans (3 x T) and est_rot (9 x T), as saved by main_demo.m:473-476."""
+        return np.array(self.est_trans).T.copy(), np.array(self.est_rot).T.copy()
+
+    @property
+    def S(self):
+        """The state struct of main_demo.m:272-286, downloaded from the GPU."""
+        lib = _lib.load()
+        nL, nC = C.c_int(0), C.c_int(0)
+        self.ctx.check(lib.vohip_frame_sizes(self._h, C.byref(nL), C.byref(nC)))
+        nL, nC = nL.value, nC.value
+        P, X, ids = np.zeros((max(nL, 1), 2)), np.zeros((max(nL, 1), 3)), np.zeros(max(nL, 1))
+        Cc, F, T = np.zeros((max(nC, 1), 2)), np.zeros((max(nC, 1), 2)), np.zeros((max(nC, 1), 12))
+        self.ctx.check(lib.vohip_frame_state(self._h, dptr(P), dptr(X), dptr(ids), dptr(Cc), dptr(F), dptr(T)))
+        et, er = self.trajectory()
+        return SimpleNamespace(P=P[:nL].T.copy(), X=np.vstack([X[:nL].T, ids[:nL]]), C=Cc[:nC].T.copy(), F=F[:nC].T.copy(),
+                               T=T[:nC].T.copy(), est_trans=et, est_rot=er, num_X=list(self.num_X), num_C=list(self.num_C),
+                               num_new=list(self.num_new))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _lib.load().vohip_frame_destroy(self._h)
+            self._h = None
+            self.ctx.__dict__.setdefault("_free_pyr_slots", []).extend(self._slots)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -15,12 +15,10 @@ from ._lib import VOHIP_NO_MODEL, VOHIP_OK, VOHIP_SAMPLES_EXHAUSTED, as_f64, col
 MAX_ITERATIONS = 15000  # cap of ransacLocalization.m:128
 
 
-def draw_triples(rng, n, count):
-    """`count` index triples, each 3 distinct indices in [0, n) -- the stand-in for
-    datasample(landmarks, 3, 2, 'Replace', false) at ransacLocalization.m:46-47.
-    One call consumes exactly 3*count draws of `rng` in triple order, so drawing m triples and
-    then k more equals drawing m+k at once."""
-    r = rng.random((count, 3))
+def triples_from_uniforms(r, n):
+    """Maps a (count, 3) array of uniforms in [0, 1) to index triples, 3 distinct indices in [0, n)
+    each."""
+    r = np.asarray(r, dtype=np.float64)
     a = np.minimum((r[:, 0] * n).astype(np.int64), n - 1)
     b = np.minimum((r[:, 1] * (n - 1)).astype(np.int64), n - 2)
     c = np.minimum((r[:, 2] * (n - 2)).astype(np.int64), n - 3)
@@ -30,6 +28,14 @@ def draw_triples(rng, n, count):
     c = c + (c >= lo)
     c = c + (c >= hi)
     return np.stack([a, b, c], axis=1).astype(np.int32)
+
+
+def draw_triples(rng, n, count):
+    """`count` index triples, each 3 distinct indices in [0, n) -- the stand-in for
+    datasample(landmarks, 3, 2, 'Replace', false) at ransacLocalization.m:46-47.
+    One call consumes exactly 3*count draws of `rng` in triple order, so drawing m triples and
+    then k more equals drawing m+k at once."""
+    return triples_from_uniforms(rng.random((count, 3)), n)
 
 
 def ransacLocalization(matched_query_keypoints, corresponding_landmarks, K, samples=None, rng=None,
