@@ -178,7 +178,7 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
                                     double *d_angles);
 
 /* ---- the frame loop with device-resident state -------------------------------------------------
- * The loop body main_demo.m:377-427 (is_BA = false) as three calls per frame.  S.P, S.X, S.C, S.F
+ * The loop body main_demo.m:377-427 (is_BA = false) as one call per frame.  S.P, S.X, S.C, S.F
  * and S.T (main_demo.m:272-279) stay in GPU memory between frames; the stages are the kernels behind
  * the entry points above, chained through device-side counts, so the state after each frame is the
  * one the stage-by-stage calls produce (genKeypoints.m, ransacLocalization.m, T_refinement.m,
@@ -190,10 +190,9 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
  * both) and 8 per fundamental-matrix trial (draw k picks the floor(u_k (n-k))-th index not picked
  * before).
  *
- * Per frame: vohip_frame_track (enqueue only), vohip_frame_localize (returns the pose and n_iter,
- * the number of hypotheses the adaptive rule of ransacLocalization.m:118-131 consumed; when it
- * returns VOHIP_SAMPLES_EXHAUSTED call it again with more uniforms, the first `evaluated` of
- * which must be the ones already passed), vohip_frame_map.
+ * The two sets of draws are independent of each other (the trial draws do not wait for the number
+ * of hypotheses the localisation consumes), which lets the epipolar filter run beside the
+ * localisation on a second stream.
  */
 typedef struct vohip_frame vohip_frame;
 
@@ -238,11 +237,14 @@ int vohip_frame_destroy(vohip_frame *f);
  * col) in `image`, T_W_C 4x4 column-major.  image on the host, or on the device when the flag is set. */
 int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device, const double *X, const double *ids,
                       const double *P_rc, int n, const double T_W_C[16]);
-int vohip_frame_track(vohip_frame *f, const uint8_t *image, int image_on_device);
-/* uniforms 3 x h.  VOHIP_NO_MODEL: no hypothesis reached 30 inliers (the reference stops there too). */
-int vohip_frame_localize(vohip_frame *f, const double *uniforms, int h, vohip_frame_pose *out);
-/* uniforms 8 x fm_trials (may be NULL while there are no candidates yet). */
-int vohip_frame_map(vohip_frame *f, const double *uniforms, vohip_frame_counts *out);
+/* One frame: u3 = 3 x h uniforms for the P3P hypotheses, u8 = 8 x fm_trials uniforms for the
+ * fundamental-matrix trials (may be NULL while there are no candidates yet).  One synchronisation.
+ * VOHIP_SAMPLES_EXHAUSTED: the adaptive rule wants more than h hypotheses (pose->num_iterations tells
+ * how many); call vohip_frame_retry with a longer u3 whose first h triples are the ones already
+ * passed.  VOHIP_NO_MODEL: no hypothesis reached 30 inliers (the reference stops there too). */
+int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, const double *u3, int h,
+                     const double *u8, vohip_frame_pose *pose, vohip_frame_counts *counts);
+int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *counts);
 int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates);
 /* Copies of S.P (2xn), S.X(1:3,:) (3xn), S.X(4,:), S.C, S.F (2xm), S.T (12xm); any pointer may be NULL. */
 int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc, double *T12);

@@ -175,8 +175,9 @@ def VO_bundle_adjust(S, B, T_W_C, K, hp):
 
 class OraclePipeline:
     def __init__(self, K, first_image, p_W_landmarks, keypoints_xy, T_init_WC, hp, window_size, keyframe_d, rng,
-                 draw_triples, draw_octets):
+                 draw_triples, draw_octets, rng_map=None):
         self.K, self.hp, self.rng = np.asarray(K, dtype=np.float64), hp, rng
+        self.rng_map = rng_map or rng.spawn(1)[0]    # the epipolar filter draws from its own stream
         self.draw_triples, self.draw_octets = draw_triples, draw_octets
         self.S, self.B = init_state(p_W_landmarks, keypoints_xy, np.asarray(T_init_WC, dtype=np.float64), window_size,
                                     keyframe_d)
@@ -214,7 +215,7 @@ class OraclePipeline:
         S.est_trans = np.hstack([S.est_trans, T_W_C[:3, 3:4]])                              # :401-403
         S.est_rot = np.hstack([S.est_rot, T_W_C[:3, :3].reshape(9, 1, order="F")])
         if S.C.shape[1] > 0:                                                                # :406-408
-            S, B = update_landmarks(S, B, self.prev_img, image, K, hp, self.draw_octets, self.rng)
+            S, B = update_landmarks(S, B, self.prev_img, image, K, hp, self.draw_octets, self.rng_map)
         if hp.is_BA:                                                                        # :409-411
             S, B = VO_bundle_adjust(S, B, T_W_C, K, hp)
         S = update_candidate(S, location, hp)                                               # :413

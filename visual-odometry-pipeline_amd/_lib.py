@@ -66,9 +66,9 @@ SIGNATURES = {
     "vohip_frame_destroy": (C.c_int, [C.c_void_p]),
     "vohip_frame_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int,
                                      c_double_p]),
-    "vohip_frame_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
-    "vohip_frame_localize": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.POINTER(FramePose)]),
-    "vohip_frame_map": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(FrameCounts)]),
+    "vohip_frame_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_double_p, C.c_int, c_double_p,
+                                    C.POINTER(FramePose), C.POINTER(FrameCounts)]),
+    "vohip_frame_retry": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.POINTER(FramePose), C.POINTER(FrameCounts)]),
     "vohip_frame_sizes": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
     "vohip_frame_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]),

@@ -2,18 +2,20 @@
 //
 // Restates main_demo.m:377-427 with is_BA = false -- detection (genKeypoints.m), the landmark
 // tracker, ransacLocalization.m, T_refinement.m, update_landmarks.m, update_candidate.m and the
-// tracker re-initialisation -- as three enqueue-mostly calls per frame:
-//   vohip_frame_track     image pyramid, landmark tracking + ordered selection on the context's
-//                         stream; candidate tracking and corner detection on a second stream
-//   vohip_frame_localize  P3P hypotheses from the caller's uniform draws, scoring, the adaptive
-//                         stopping rule replayed by one device thread, inlier selection, pose
-//                         refinement; ONE synchronisation (the caller's RNG needs n_iter)
-//   vohip_frame_map       fundamental-matrix RANSAC over the candidate tracks, triangulation,
-//                         landmark append, redundancy filter, candidate append; ONE synchronisation
+// tracker re-initialisation -- as ONE call and ONE synchronisation per frame (vohip_frame_step):
+//   context stream  image pyramid -> landmark tracking -> ordered selection -> P3P hypotheses from
+//                   the caller's uniform draws -> scoring -> the adaptive stopping rule replayed by
+//                   one wavefront -> inlier selection -> pose refinement -> [join] -> triangulation
+//                   of the filtered candidates -> landmark append -> redundancy filter ->
+//                   candidate append -> next frame's track points
+//   second stream   (after the pyramid) candidate tracking -> ordered selection -> fundamental-matrix
+//                   RANSAC from the caller's second set of draws -> inlier selection; corner
+//                   detection
 // S.P, S.X, S.C, S.F, S.T never leave the device; every count between the stages stays in device
 // memory (kernels are launched over capacity-sized grids and read the count themselves), and
 // selections are ordered, so the state is element for element the one the stage-by-stage entry
-// points produce.
+// points produce.  When the adaptive bound of the localisation asks for more hypotheses than were
+// supplied, vohip_frame_retry re-runs the context-stream part from the hypotheses onwards.
 #include "vohip_internal.h"
 
 #include <cmath>
@@ -111,10 +113,13 @@ __global__ __launch_bounds__(256) void select_tracked_kernel(const double *__res
                                                              const double *__restrict__ L_X,
                                                              const double *__restrict__ L_id, int n,
                                                              double *__restrict__ mv_rc, double *__restrict__ Xv,
-                                                             double *__restrict__ idv, int *__restrict__ cnt)
+                                                             double *__restrict__ idv, int *__restrict__ cnt,
+                                                             double *__restrict__ dv)
 {
     __shared__ int sh[12];
     int total;
+    // the ids handed out in the previous frame are final now
+    if (blockIdx.x == 0 && threadIdx.x == 0) dv[D_IDX] = dv[D_IDX_NEXT];
     const int r = ordered_rank(valid, n, is_set(), total, sh);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n && valid[i]) {
@@ -161,43 +166,82 @@ __device__ double adaptive_iterations_dev(int max_num_inliers, int n)
     return it;
 }
 
-// The sequential part of ransacLocalization.m:42-131 over the scored hypotheses, by one thread:
-// solution choice (:77-101, strict '>'), running maximum (:104-110), adaptive bound (:118-129).
-__global__ void localize_decide_kernel(const int32_t *__restrict__ counts, int evaluated,
-                                       const double *__restrict__ Rt_all, const double *__restrict__ M_all,
-                                       int *__restrict__ cnt, double *__restrict__ dv)
+__device__ __forceinline__ int wave_prefix_max(int v, int lane)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v = max(v, t);
+    }
+    return v;
+}
+
+// The sequential part of ransacLocalization.m:42-131 over the scored hypotheses: solution choice
+// (:77-101, strict '>'), running maximum (:104-110), adaptive bound (:118-129).  The bound is a
+// function of the running maximum only, so one wavefront replays 64 iterations at a time: prefix
+// maximum, bound per lane, first lane at which the loop condition fails.
+__global__ __launch_bounds__(64) void localize_decide_kernel(const int32_t *__restrict__ counts, int evaluated,
+                                                             const double *__restrict__ Rt_all,
+                                                             const double *__restrict__ M_all,
+                                                             int *__restrict__ cnt, double *__restrict__ dv)
+{
+    const int lane = threadIdx.x;
     const int n = cnt[N_V];
-    int max_num_inliers = 0, best_h = -1, best_s = 0, i = 1;
+    int run_max = 0, best_h = -1, best_s = 0, n_iter = 0;
     double num_iterations = INFINITY;
-    bool exhausted = false;
+    bool exhausted = false, stopped = false;
     if (n >= 3) {
-        while (num_iterations > (double)i) {
-            if (i > evaluated) {
+        for (int base = 0; !stopped; base += 64) {
+            if (base >= evaluated) {
+                exhausted = true;   // the loop wants iteration base + 1, which was not scored
+                n_iter = evaluated;
+                break;
+            }
+            const int j = base + lane;          // iteration j + 1 of the reference loop
+            const bool live = j < evaluated;
+            int k = 0, s_best = 0;
+            if (live) {
+                const int4 c = *reinterpret_cast<const int4 *>(counts + 4 * (size_t)j);
+                k = c.x;
+                if (c.y > k) { k = c.y; s_best = 1; }
+                if (c.z > k) { k = c.z; s_best = 2; }
+                if (c.w > k) { k = c.w; s_best = 3; }
+            }
+            const int e = k >= 30 ? k : 0;      // :104 min_inlier_count
+            const int m = max(wave_prefix_max(e, lane), run_max);
+            const double bound = adaptive_iterations_dev(m, n);
+            // after iteration j + 1 the loop goes on iff bound > j + 2
+            const unsigned long long stop = __ballot(live && !(bound > (double)(j + 2)));
+            int last = 63;                       // last lane of this chunk that is executed
+            if (stop) {
+                last = __ffsll((long long)stop) - 1;
+                stopped = true;
+            } else if (base + 64 >= evaluated) {
+                last = evaluated - 1 - base;
+            }
+            const int m_last = __shfl(m, last, 64);
+            if (m_last > run_max) {
+                const unsigned long long hit = __ballot(lane <= last && e == m_last);
+                const int w = __ffsll((long long)hit) - 1;
+                best_h = base + w;
+                best_s = __shfl(s_best, w, 64);
+                run_max = m_last;
+            }
+            num_iterations = __shfl(bound, last, 64);
+            n_iter = base + last + 1;
+            if (!stopped && base + 64 >= evaluated) {
                 exhausted = true;
                 break;
             }
-            const int32_t *c = counts + 4 * (size_t)(i - 1);
-            int s_best = 0;
-            for (int s = 1; s < 4; ++s)
-                if (c[s] > c[s_best]) s_best = s;
-            const int k = c[s_best];
-            if (k > max_num_inliers && k >= 30) {
-                max_num_inliers = k;
-                best_h = i - 1;
-                best_s = s_best;
-            }
-            num_iterations = adaptive_iterations_dev(max_num_inliers, n);
-            ++i;
         }
     }
-    cnt[R_ITER] = i - 1;
+    if (lane != 0) return;
+    cnt[R_ITER] = n_iter;
     cnt[R_FOUND] = best_h >= 0 ? 1 : 0;
     cnt[R_EXHAUSTED] = exhausted ? 1 : 0;
     cnt[R_BEST_H] = best_h;
     cnt[R_BEST_S] = best_s;
-    cnt[R_MAX_INL] = max_num_inliers;
+    cnt[R_MAX_INL] = run_max;
     dv[D_NUM_ITER] = num_iterations;
     if (best_h >= 0) {
         const double *Rt = Rt_all + (size_t)best_h * 48 + 12 * best_s;
@@ -302,39 +346,55 @@ __global__ __launch_bounds__(64) void octets_kernel(const double *__restrict__ u
     }
 }
 
-// The sequential part of the fundamental-matrix RANSAC: first trial with the largest count inside
-// the shrinking trial budget.
-__global__ void fm_decide_kernel(const int32_t *__restrict__ counts, int num_trials, double confidence,
-                                 const double *__restrict__ F_all, int *__restrict__ cnt, double *__restrict__ dv)
+__device__ double fm_trial_budget_dev(int inliers, int n, int num_trials, double confidence)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double r8 = pow((double)inliers / (double)n, 8.0);
+    if (r8 >= 1.0) return 1.0;
+    if (r8 <= 0.0) return (double)num_trials;
+    const double b = ceil(log(1.0 - confidence / 100.0) / log(1.0 - r8));
+    return b < (double)num_trials ? b : (double)num_trials;
+}
+
+// The sequential part of the fundamental-matrix RANSAC: first trial with the largest count inside
+// the shrinking trial budget.  The budget is a function of the running maximum only, so one
+// wavefront replays 64 trials at a time (prefix maximum, budget per lane, first lane at which the
+// loop ends).
+__global__ __launch_bounds__(64) void fm_decide_kernel(const int32_t *__restrict__ counts, int num_trials,
+                                                       double confidence, const double *__restrict__ F_all,
+                                                       int *__restrict__ cnt, double *__restrict__ dv)
+{
+    const int lane = threadIdx.x;
     const int n = cnt[N_CV];
-    double budget = (double)num_trials;
-    int t = 0, best = 0, best_t = -1;
+    int run_max = 0, best_t = -1, trials = 0;
     if (n >= 8) {
-        while ((double)t < budget && t < num_trials) {
-            if (counts[t] > best) {
-                best = counts[t];
-                best_t = t;
-                const double r8 = pow((double)best / (double)n, 8.0);
-                double b;
-                if (r8 >= 1.0)
-                    b = 1.0;
-                else if (r8 <= 0.0)
-                    b = (double)num_trials;
-                else {
-                    b = ceil(log(1.0 - confidence / 100.0) / log(1.0 - r8));
-                    if (!(b < (double)num_trials)) b = (double)num_trials;
-                }
-                budget = b;
+        bool stopped = false;
+        for (int base = 0; base < num_trials && !stopped; base += 64) {
+            const int t = base + lane;
+            const bool live = t < num_trials;
+            const int c = live ? counts[t] : 0;
+            const int m = max(wave_prefix_max(c, lane), run_max);
+            const double budget = fm_trial_budget_dev(m, n, num_trials, confidence);
+            // after trial t the loop goes on iff t + 1 < budget (and t + 1 < num_trials)
+            const unsigned long long stop = __ballot(live && !((double)(t + 1) < budget));
+            int last = min(63, num_trials - 1 - base);
+            if (stop) {
+                last = __ffsll((long long)stop) - 1;
+                stopped = true;
             }
-            ++t;
+            const int m_last = __shfl(m, last, 64);
+            if (m_last > run_max) {
+                const unsigned long long hit = __ballot(lane <= last && c == m_last);
+                best_t = base + __ffsll((long long)hit) - 1;
+                run_max = m_last;
+            }
+            trials = base + last + 1;
         }
     }
+    if (lane < 9) dv[D_F + lane] = best_t >= 0 ? F_all[9 * (size_t)best_t + lane] : 0.0;
+    if (lane != 0) return;
     cnt[F_BEST_T] = best_t;
-    cnt[F_BEST_COUNT] = best;
-    cnt[F_TRIALS] = t;
-    for (int q = 0; q < 9; ++q) dv[D_F + q] = best_t >= 0 ? F_all[9 * (size_t)best_t + q] : 0.0;
+    cnt[F_BEST_COUNT] = run_max;
+    cnt[F_TRIALS] = trials;
 }
 
 // update_landmarks.m:15,20-25: the epipolar inliers.  An all-zero matrix (no model) flags nothing.
@@ -460,13 +520,11 @@ __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__r
     }
 }
 
-// main_demo.m:417-424: the points both trackers start from in the next frame, as (x, y) columns;
-// also rolls the landmark id counter.
+// main_demo.m:417-424: the points both trackers start from in the next frame, as (x, y) columns.
 __global__ __launch_bounds__(256) void next_tracks_kernel(const double *__restrict__ L_rc, int ldL,
                                                           double *__restrict__ L_xy,
                                                           const double *__restrict__ C_rc, int ldC,
-                                                          double *__restrict__ C_xy, const int *__restrict__ cnt,
-                                                          double *__restrict__ dv)
+                                                          double *__restrict__ C_xy, const int *__restrict__ cnt)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < cnt[N_L_END]) {
@@ -477,7 +535,6 @@ __global__ __launch_bounds__(256) void next_tracks_kernel(const double *__restri
         C_xy[i] = C_rc[2 * i + 1];
         C_xy[ldC + i] = C_rc[2 * i];
     }
-    if (i == 0) dv[D_IDX] = dv[D_IDX_NEXT];
 }
 
 }  // namespace
@@ -504,8 +561,8 @@ struct vohip_frame {
     int slot_prev = 0, slot_cur = 0;
     int n_L = 0, n_C = 0;        // counts at the start of the frame (known to the host)
     int evaluated = 0;           // hypotheses scored in the current frame
-    int stage = 0;               // 0 = ready for track, 1 = tracked, 2 = localised
-    const uint8_t *cur_img = nullptr;
+    int stage = 0;               // 0 = between frames, 1 = a frame waits for more hypotheses
+    bool have_map = false;       // the frame started with candidates (update_landmarks runs)
 };
 
 namespace {
@@ -582,6 +639,129 @@ int fetch_summary(vohip_frame *f)
     VOHIP_HIP(ctx, hipMemcpyAsync(hc, f->cnt, sizeof(int) * N_COUNTERS, hipMemcpyDeviceToHost, ctx->stream));
     VOHIP_HIP(ctx, hipMemcpyAsync(hd, f->dv, sizeof(double) * N_DOUBLES, hipMemcpyDeviceToHost, ctx->stream));
     VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VOHIP_OK;
+}
+
+// Second stream: everything that needs neither the new pose nor the localisation draws --
+// corner detection (main_demo.m:377), the candidate tracker and the epipolar filter
+// (update_landmarks.m:10-25).
+int enqueue_side(vohip_frame *f, const uint8_t *d_img)
+{
+    vohip_ctx *ctx = f->ctx;
+    const vohip_frame_params &p = f->prm;
+    const int T = p.fm_trials;
+    stream_swap sw(ctx, f->side);
+    hipStream_t s = f->side;
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_pyr, 0));
+    if (f->have_map) {
+        VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->C_xy, f->capC, f->n_C, nullptr, p.klt_block,
+                                    p.klt_max_iter, p.klt_max_bidir_error, f->kC_out, f->kC_valid, nullptr));
+        hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->kC_out, f->capC,
+                           f->kC_valid, f->C_rc, f->F_rc, f->T12, f->n_C, f->p1_rc, f->m_rc, f->F_t, f->T_t, f->cnt);
+        hipLaunchKernelGGL(octets_kernel, dim3((T + 63) / 64), dim3(64), 0, s, f->u8, T, f->cnt, f->samples8);
+        VOHIP_TRY(vohip_fm_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->samples8, T, p.fm_threshold,
+                                   f->dv + D_NRM, f->fm_F, f->fm_counts));
+        hipLaunchKernelGGL(fm_decide_kernel, dim3(1), dim3(64), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
+                           f->dv);
+        VOHIP_TRY(vohip_fm_mask_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->dv + D_F, p.fm_threshold,
+                                        f->fmask));
+        hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->m_rc, f->F_t, f->T_t,
+                           f->fmask, f->cnt, f->m2_rc, f->F2, f->T2);
+    }
+    VOHIP_TRY(vohip_detect_corners_dev(ctx, d_img, f->rows, f->cols, f->colmajor, p.min_quality, p.filter_size, p.border,
+                                       p.detector, f->corner_xy, f->corner_metric, f->capK, f->cnt + N_DET));
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_side, s));
+    return VOHIP_OK;
+}
+
+// Localisation over hypotheses [f->evaluated, h), the rest of the frame, and the frame's single
+// synchronisation.  Every kernel here reads only buffers that an earlier run of the same sequence
+// leaves intact, so it can run again with more hypotheses when the adaptive bound asks for them.
+int finish_frame(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *out)
+{
+    vohip_ctx *ctx = f->ctx;
+    hipStream_t s = ctx->stream;
+    const vohip_frame_params &p = f->prm;
+    const int first = f->evaluated, more = h - first;
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3 + 3 * (size_t)first, u3 + 3 * (size_t)first, sizeof(double) * 3 * more,
+                                  hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more)), dim3(256), 0, s, f->u3, first, more, f->cnt, f->samples3);
+    VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
+                                   f->counts4));
+    f->evaluated = h;
+    hipLaunchKernelGGL(localize_decide_kernel, dim3(1), dim3(64), 0, s, f->counts4, h,
+                       (const double *)ctx->bufs[B_RANSAC_RT].ptr, (const double *)ctx->bufs[B_RANSAC_M].ptr, f->cnt,
+                       f->dv);
+    VOHIP_TRY(vohip_ransac_mask_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->dv + D_M, f->mask));
+    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->mv_rc, f->Xv, f->idv, f->mask,
+                       f->cnt, f->L_rc, f->L_X, f->L_id, f->kp_uv);
+    VOHIP_HIP(ctx, hipGetLastError());
+    if (p.refine_pose)   // main_demo.m:398-400
+        VOHIP_TRY(vohip_pose_refine_enqueue(ctx, f->dv + D_T, f->kp_uv, f->L_X, f->n_L, f->cnt + N_IN, f->K,
+                                            p.refine_max_iter, 1e-10, 1e-10, f->dv + D_STATS));
+    // update_landmarks.m:27-125 and update_candidate.m with the new pose
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_side, 0));
+    if (f->have_map) {
+        VOHIP_TRY(vohip_candidate_triangulate_enqueue(ctx, f->m2_rc, f->F2, f->T2, f->n_C, f->cnt + N_CI, f->dv + D_T,
+                                                      f->K, p.angle_threshold_deg, p.min_depth, p.max_depth, 0,
+                                                      f->status, f->Xnew));
+        hipLaunchKernelGGL(split_candidates_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->status, f->m2_rc, f->F2,
+                           f->T2, f->Xnew, f->cnt, f->dv, f->capL, f->L_rc, f->L_X, f->L_id, f->C_rc, f->F_rc, f->T12);
+    }
+    hipLaunchKernelGGL(filter_counts_kernel, dim3(1), dim3(64), 0, s, f->cnt, f->capK, f->have_map ? 1 : 0, f->dv);
+    VOHIP_TRY(vohip_candidate_filter_enqueue(ctx, f->corner_xy, f->capK, f->capK, f->C_rc, f->L_rc, f->cnt + FILT0,
+                                             p.r_discard_redundant, f->keep));
+    hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s, f->corner_xy, f->capK,
+                       f->keep, f->cnt, f->dv, f->capC, f->C_rc, f->F_rc, f->T12);
+    const int nmax = f->capL > f->capC ? f->capL : f->capC;
+    hipLaunchKernelGGL(next_tracks_kernel, dim3(blocks256(nmax)), dim3(256), 0, s, f->L_rc, f->capL, f->L_xy, f->C_rc,
+                       f->capC, f->C_xy, f->cnt);
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_TRY(fetch_summary(f));
+
+    const int *hc = (const int *)f->pinned;
+    const double *hd = (const double *)((const char *)f->pinned + 256);
+    std::memset(pose, 0, sizeof(*pose));
+    std::memset(out, 0, sizeof(*out));
+    pose->n_tracked = hc[N_V];
+    pose->n_iter = hc[R_ITER];
+    pose->found = hc[R_FOUND];
+    pose->exhausted = hc[R_EXHAUSTED];
+    pose->n_inliers = hc[N_IN];
+    pose->max_num_inliers = hc[R_MAX_INL];
+    pose->evaluated = h;
+    pose->num_iterations = hd[D_NUM_ITER];
+    std::memcpy(pose->T_W_C, hd + D_T, sizeof(double) * 16);
+    std::memcpy(pose->Rt, hd + D_RT, sizeof(double) * 12);
+    std::memcpy(pose->refine_stats, hd + D_STATS, sizeof(double) * 3);
+    if (hc[N_V] >= 3 && hc[R_EXHAUSTED] && h < f->hmax)   // stage stays 1: vohip_frame_retry goes on from here
+        return vohip_fail(ctx, VOHIP_SAMPLES_EXHAUSTED, "the adaptive bound (%.0f) exceeds the %d hypotheses supplied",
+                          hd[D_NUM_ITER], h);
+    out->n_landmarks = hc[N_L_END];
+    out->n_candidates = hc[N_C_END];
+    out->num_new = hc[NUM_NEW];
+    out->n_detected = hc[N_DET];
+    out->n_kept = hc[N_KEPT];
+    out->n_candidates_tracked = f->have_map ? hc[N_CV] : 0;
+    out->n_candidates_inliers = f->have_map ? hc[N_CI] : 0;
+    out->fm_trials_run = f->have_map ? hc[F_TRIALS] : 0;
+    out->overflow = hc[OVERFLOW];
+    const int t = f->slot_prev;   // main_demo.m:417-424: this frame's pyramid is the next "previous"
+    f->slot_prev = f->slot_cur;
+    f->slot_cur = t;
+    f->n_L = hc[N_L_END];
+    f->n_C = hc[N_C_END];
+    f->stage = 0;
+    if (hc[N_V] < 3) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "only %d landmarks were tracked", hc[N_V]);
+    if (!hc[R_FOUND])
+        return vohip_fail(ctx, VOHIP_NO_MODEL, "no hypothesis reached 30 inliers in %d iterations", hc[R_ITER]);
+    if (f->have_map && hc[N_CV] < 8)
+        return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "the 8-point algorithm needs 8 candidate tracks, got %d", hc[N_CV]);
+    if (hc[N_DET] > f->capK)
+        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "%d corners found, capacity %d", hc[N_DET], f->capK);
+    if (hc[OVERFLOW])
+        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "landmark or candidate capacity exceeded (flags %d)", hc[OVERFLOW]);
     return VOHIP_OK;
 }
 
@@ -733,7 +913,7 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     hc[0] = n;
     VOHIP_HIP(ctx, hipMemcpyAsync(f->cnt + N_L_END, hc, sizeof(int), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(next_tracks_kernel, dim3(blocks256(n)), dim3(256), 0, s, f->L_rc, f->capL, f->L_xy, f->C_rc,
-                       f->capC, f->C_xy, f->cnt, f->dv);
+                       f->capC, f->C_xy, f->cnt);
     VOHIP_HIP(ctx, hipGetLastError());
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
     f->n_L = n;
@@ -742,12 +922,15 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     return VOHIP_OK;
 }
 
-int vohip_frame_track(vohip_frame *f, const uint8_t *image, int image_on_device)
+int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, const double *u3, int h,
+                     const double *u8, vohip_frame_pose *pose, vohip_frame_counts *counts)
 {
     if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
     vohip_ctx *ctx = f->ctx;
-    VOHIP_REQUIRE(ctx, image, "NULL image");
-    VOHIP_REQUIRE(ctx, f->stage == 0, "vohip_frame_track called out of order");
+    VOHIP_REQUIRE(ctx, image && u3 && pose && counts, "NULL argument");
+    VOHIP_REQUIRE(ctx, f->stage == 0, "a frame is still waiting for vohip_frame_retry");
+    VOHIP_REQUIRE(ctx, h >= 1 && h <= f->hmax, "hypothesis count outside 1..max_hypotheses");
+    VOHIP_REQUIRE(ctx, f->n_C == 0 || u8, "candidates exist: the fundamental-matrix draws are needed");
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
@@ -756,150 +939,32 @@ int vohip_frame_track(vohip_frame *f, const uint8_t *image, int image_on_device)
         VOHIP_HIP(ctx, hipMemcpyAsync(f->img, image, (size_t)f->rows * f->cols, hipMemcpyHostToDevice, s));
         d_img = f->img;
     }
-    f->cur_img = d_img;
     VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
+    f->have_map = f->n_C > 0;   // main_demo.m:406
+    if (f->have_map)
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, u8, sizeof(double) * 8 * (size_t)p.fm_trials, hipMemcpyHostToDevice, s));
     VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));
-    // second stream: corner detection (main_demo.m:377) and the candidate tracker
-    // (update_landmarks.m:10) need only the two pyramids and last frame's candidates
-    {
-        stream_swap sw(ctx, f->side);
-        VOHIP_HIP(ctx, hipStreamWaitEvent(f->side, f->ev_pyr, 0));
-        if (f->n_C > 0)
-            VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->C_xy, f->capC, f->n_C, nullptr, p.klt_block,
-                                        p.klt_max_iter, p.klt_max_bidir_error, f->kC_out, f->kC_valid, nullptr));
-        VOHIP_TRY(vohip_detect_corners_dev(ctx, d_img, f->rows, f->cols, f->colmajor, p.min_quality, p.filter_size,
-                                           p.border, p.detector, f->corner_xy, f->corner_metric, f->capK,
-                                           f->cnt + N_DET));
-        VOHIP_HIP(ctx, hipEventRecord(f->ev_side, f->side));
-    }
+    VOHIP_TRY(enqueue_side(f, d_img));
     // landmark tracker (main_demo.m:380) and the selection of the valid tracks (:381, :387)
     VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->L_xy, f->capL, f->n_L, nullptr, p.klt_block,
                                 p.klt_max_iter, p.klt_max_bidir_error, f->kL_out, f->kL_valid, nullptr));
     hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->kL_out, f->capL, f->kL_valid,
-                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->cnt);
+                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->cnt, f->dv);
     VOHIP_HIP(ctx, hipGetLastError());
     f->evaluated = 0;
     f->stage = 1;
-    return VOHIP_OK;
+    return finish_frame(f, u3, h, pose, counts);
 }
 
-int vohip_frame_localize(vohip_frame *f, const double *uniforms, int h, vohip_frame_pose *out)
+int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *counts)
 {
     if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
     vohip_ctx *ctx = f->ctx;
-    VOHIP_REQUIRE(ctx, uniforms && out, "NULL argument");
-    VOHIP_REQUIRE(ctx, f->stage == 1, "vohip_frame_localize called out of order");
+    VOHIP_REQUIRE(ctx, u3 && pose && counts, "NULL argument");
+    VOHIP_REQUIRE(ctx, f->stage == 1, "no frame is waiting for more hypotheses");
     VOHIP_REQUIRE(ctx, h > f->evaluated && h <= f->hmax, "hypothesis count must grow and stay within max_hypotheses");
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const vohip_frame_params &p = f->prm;
-    const int first = f->evaluated, more = h - first;
-    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3 + 3 * (size_t)first, uniforms + 3 * (size_t)first, sizeof(double) * 3 * more,
-                                  hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more)), dim3(256), 0, s, f->u3, first, more, f->cnt, f->samples3);
-    VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
-                                   f->counts4));
-    f->evaluated = h;
-    hipLaunchKernelGGL(localize_decide_kernel, dim3(1), dim3(64), 0, s, f->counts4, h,
-                       (const double *)ctx->bufs[B_RANSAC_RT].ptr, (const double *)ctx->bufs[B_RANSAC_M].ptr, f->cnt,
-                       f->dv);
-    VOHIP_TRY(vohip_ransac_mask_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->dv + D_M, f->mask));
-    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->mv_rc, f->Xv, f->idv, f->mask,
-                       f->cnt, f->L_rc, f->L_X, f->L_id, f->kp_uv);
-    VOHIP_HIP(ctx, hipGetLastError());
-    if (p.refine_pose)   // main_demo.m:398-400
-        VOHIP_TRY(vohip_pose_refine_enqueue(ctx, f->dv + D_T, f->kp_uv, f->L_X, f->n_L, f->cnt + N_IN, f->K,
-                                            p.refine_max_iter, 1e-10, 1e-10, f->dv + D_STATS));
-    VOHIP_TRY(fetch_summary(f));
-    const int *hc = (const int *)f->pinned;
-    const double *hd = (const double *)((const char *)f->pinned + 256);
-    std::memset(out, 0, sizeof(*out));
-    out->n_tracked = hc[N_V];
-    out->n_iter = hc[R_ITER];
-    out->found = hc[R_FOUND];
-    out->exhausted = hc[R_EXHAUSTED];
-    out->n_inliers = hc[N_IN];
-    out->max_num_inliers = hc[R_MAX_INL];
-    out->evaluated = h;
-    out->num_iterations = hd[D_NUM_ITER];
-    std::memcpy(out->T_W_C, hd + D_T, sizeof(double) * 16);
-    std::memcpy(out->Rt, hd + D_RT, sizeof(double) * 12);
-    std::memcpy(out->refine_stats, hd + D_STATS, sizeof(double) * 3);
-    if (hc[N_V] < 3) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "only %d landmarks were tracked", hc[N_V]);
-    if (hc[R_EXHAUSTED] && h < f->hmax)
-        return vohip_fail(ctx, VOHIP_SAMPLES_EXHAUSTED, "the adaptive bound (%.0f) exceeds the %d hypotheses supplied",
-                          hd[D_NUM_ITER], h);
-    f->stage = 2;
-    if (!hc[R_FOUND]) return vohip_fail(ctx, VOHIP_NO_MODEL, "no hypothesis reached 30 inliers in %d iterations", hc[R_ITER]);
-    return VOHIP_OK;
-}
-
-int vohip_frame_map(vohip_frame *f, const double *uniforms, vohip_frame_counts *out)
-{
-    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
-    vohip_ctx *ctx = f->ctx;
-    VOHIP_REQUIRE(ctx, out, "NULL argument");
-    VOHIP_REQUIRE(ctx, f->stage == 2, "vohip_frame_map called out of order");
-    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    const vohip_frame_params &p = f->prm;
-    const int T = p.fm_trials;
-    const bool have_map = f->n_C > 0;   // main_demo.m:406
-    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_side, 0));
-    if (have_map) {
-        VOHIP_REQUIRE(ctx, uniforms, "NULL uniforms");
-        VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, uniforms, sizeof(double) * 8 * (size_t)T, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->kC_out, f->capC,
-                           f->kC_valid, f->C_rc, f->F_rc, f->T12, f->n_C, f->p1_rc, f->m_rc, f->F_t, f->T_t, f->cnt);
-        hipLaunchKernelGGL(octets_kernel, dim3((T + 63) / 64), dim3(64), 0, s, f->u8, T, f->cnt, f->samples8);
-        VOHIP_TRY(vohip_fm_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->samples8, T, p.fm_threshold,
-                                   f->dv + D_NRM, f->fm_F, f->fm_counts));
-        hipLaunchKernelGGL(fm_decide_kernel, dim3(1), dim3(64), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
-                           f->dv);
-        VOHIP_TRY(vohip_fm_mask_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->dv + D_F, p.fm_threshold,
-                                        f->fmask));
-        hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->m_rc, f->F_t, f->T_t,
-                           f->fmask, f->cnt, f->m2_rc, f->F2, f->T2);
-        VOHIP_TRY(vohip_candidate_triangulate_enqueue(ctx, f->m2_rc, f->F2, f->T2, f->n_C, f->cnt + N_CI, f->dv + D_T,
-                                                      f->K, p.angle_threshold_deg, p.min_depth, p.max_depth, 0,
-                                                      f->status, f->Xnew));
-        hipLaunchKernelGGL(split_candidates_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->status, f->m2_rc, f->F2,
-                           f->T2, f->Xnew, f->cnt, f->dv, f->capL, f->L_rc, f->L_X, f->L_id, f->C_rc, f->F_rc, f->T12);
-    }
-    hipLaunchKernelGGL(filter_counts_kernel, dim3(1), dim3(64), 0, s, f->cnt, f->capK, have_map ? 1 : 0, f->dv);
-    VOHIP_TRY(vohip_candidate_filter_enqueue(ctx, f->corner_xy, f->capK, f->capK, f->C_rc, f->L_rc, f->cnt + FILT0,
-                                             p.r_discard_redundant, f->keep));
-    hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s, f->corner_xy, f->capK,
-                       f->keep, f->cnt, f->dv, f->capC, f->C_rc, f->F_rc, f->T12);
-    const int nmax = f->capL > f->capC ? f->capL : f->capC;
-    hipLaunchKernelGGL(next_tracks_kernel, dim3(blocks256(nmax)), dim3(256), 0, s, f->L_rc, f->capL, f->L_xy, f->C_rc,
-                       f->capC, f->C_xy, f->cnt, f->dv);
-    VOHIP_HIP(ctx, hipGetLastError());
-    VOHIP_TRY(fetch_summary(f));
-    const int *hc = (const int *)f->pinned;
-    std::memset(out, 0, sizeof(*out));
-    out->n_landmarks = hc[N_L_END];
-    out->n_candidates = hc[N_C_END];
-    out->num_new = hc[NUM_NEW];
-    out->n_detected = hc[N_DET];
-    out->n_kept = hc[N_KEPT];
-    out->n_candidates_tracked = have_map ? hc[N_CV] : 0;
-    out->n_candidates_inliers = have_map ? hc[N_CI] : 0;
-    out->fm_trials_run = have_map ? hc[F_TRIALS] : 0;
-    out->overflow = hc[OVERFLOW];
-    const int t = f->slot_prev;   // main_demo.m:417-424: this frame's pyramid is the next "previous"
-    f->slot_prev = f->slot_cur;
-    f->slot_cur = t;
-    f->n_L = hc[N_L_END];
-    f->n_C = hc[N_C_END];
-    f->stage = 0;
-    if (have_map && hc[N_CV] < 8)
-        return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "the 8-point algorithm needs 8 candidate tracks, got %d", hc[N_CV]);
-    if (hc[N_DET] > f->capK)
-        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "%d corners found, capacity %d", hc[N_DET], f->capK);
-    if (hc[OVERFLOW])
-        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "landmark or candidate capacity exceeded (flags %d)", hc[OVERFLOW]);
-    return VOHIP_OK;
+    return finish_frame(f, u3, h, pose, counts);
 }
 
 int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates)

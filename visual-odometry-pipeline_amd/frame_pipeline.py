@@ -2,10 +2,10 @@
 GPU: a thin driver over the vohip_frame_* entry points of libvohip.so.  Same constructor and
 methods as pipeline.VOPipeline; the state S is downloaded only when asked for.
 
-Per frame the host does three library calls and draws the random numbers the two RANSAC stages
-consume, from the same generator and in the same order as VOPipeline: 3 uniforms per P3P hypothesis
-(the generator ends up advanced by exactly n_iter triples, as ransacLocalization would leave it),
-then 8 per fundamental-matrix trial.
+Per frame the host does one library call (one synchronisation) and draws the random numbers the two
+RANSAC stages consume, from the same two generators as VOPipeline: `rng` gives 3 uniforms per P3P
+hypothesis (it ends up advanced by exactly n_iter triples, as ransacLocalization would leave it),
+`rng_map` 8 per fundamental-matrix trial.
 """
 import ctypes as C
 from types import SimpleNamespace
@@ -20,7 +20,7 @@ from .ransac import MAX_ITERATIONS
 
 class VOPipelineDevice:
     def __init__(self, K, first_image, p_W_landmarks, keypoints_xy, T_init_WC, hyper_paras=None, rng=None, ctx=None,
-                 tracker_options=None, cap_landmarks=8192, cap_candidates=8192, cap_corners=16384):
+                 tracker_options=None, rng_map=None, cap_landmarks=8192, cap_candidates=8192, cap_corners=16384):
         self.ctx = ctx or _lib.default_context()
         self.K = np.asarray(K, dtype=np.float64)
         self.hp = hyper_paras or default_hyper_paras()
@@ -29,6 +29,7 @@ class VOPipelineDevice:
         if self.hp.feature_extract not in ("Harris", "MinEigen"):
             raise NotImplementedError("detector '%s' is not built" % self.hp.feature_extract)
         self.rng = rng or np.random.default_rng()
+        self.rng_map = rng_map or self.rng.spawn(1)[0]
         lib = _lib.load()
         prm = _lib.FrameParams()
         lib.vohip_frame_default_params(C.byref(prm))
@@ -95,32 +96,30 @@ class VOPipelineDevice:
     def process_frame(self, image):
         lib = _lib.load()
         ptr, on_dev, keep = self._image_ptr(image)
-        self.ctx.check(lib.vohip_frame_track(self._h, ptr, on_dev))                        # :377, :380
-        pose = _lib.FramePose()
+        pose, counts = _lib.FramePose(), _lib.FrameCounts()
+        have_map = self.num_C[-1] > 0                                                       # :406
+        u8 = self.rng_map.random((self.params.fm_trials, 8)) if have_map else None          # update_landmarks.m:13
         state = self.rng.bit_generator.state
         have = 104
-        while True:                                                                         # :387-388
+        u3 = self.rng.random((have, 3))                                                     # :387-388
+        st = lib.vohip_frame_step(self._h, ptr, on_dev, dptr(u3), have, dptr(u8) if have_map else None,
+                                  C.byref(pose), C.byref(counts))
+        while st == VOHIP_SAMPLES_EXHAUSTED and have < MAX_ITERATIONS:
+            have = min(max(8 * have, int(np.ceil(pose.num_iterations)) + 8), MAX_ITERATIONS)
             self.rng.bit_generator.state = state
-            u = self.rng.random((have, 3))
-            st = lib.vohip_frame_localize(self._h, dptr(u), have, C.byref(pose))
-            if st == VOHIP_SAMPLES_EXHAUSTED and have < MAX_ITERATIONS:
-                have = min(max(8 * have, int(np.ceil(pose.num_iterations)) + 8), MAX_ITERATIONS)
-                continue
-            break
+            u3 = self.rng.random((have, 3))         # the same leading draws, then more
+            st = lib.vohip_frame_retry(self._h, dptr(u3), have, C.byref(pose), C.byref(counts))
+        del keep
         self.rng.bit_generator.state = state
         if pose.n_iter > 0:
             self.rng.random((pose.n_iter, 3))       # the generator as n_iter executed iterations leave it
         if st == VOHIP_NO_MODEL:
             raise RuntimeError("ransacLocalization found no pose (the reference fails here too, main_demo.m:389-391)")
         self.ctx.check(st)
-        counts = _lib.FrameCounts()
-        u8 = self.rng.random((self.params.fm_trials, 8)) if self.num_C[-1] > 0 else None    # update_landmarks.m:13
-        self.ctx.check(lib.vohip_frame_map(self._h, dptr(u8) if u8 is not None else None, C.byref(counts)))
-        del keep
         T_W_C = np.array(pose.T_W_C).reshape(4, 4).T.copy()
         self.est_trans.append(T_W_C[:3, 3].copy())                                          # :401-403
         self.est_rot.append(T_W_C[:3, :3].reshape(-1, order="F").copy())
-        if self.num_C[-1] > 0:
+        if have_map:
             self.num_new.append(counts.num_new)                                             # update_landmarks.m:124
         self.num_X.append(counts.n_landmarks)                                               # :426-427
         self.num_C.append(counts.n_candidates)

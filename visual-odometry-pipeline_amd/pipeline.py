@@ -209,11 +209,12 @@ class VOPipeline:
     trackers and by the next frame."""
 
     def __init__(self, K, first_image, p_W_landmarks, keypoints_xy, T_init_WC, hyper_paras=None, window_size=3,
-                 keyframe_d=2, rng=None, ctx=None, tracker_options=None):
+                 keyframe_d=2, rng=None, ctx=None, tracker_options=None, rng_map=None):
         self.ctx = ctx or _lib.default_context()
         self.K = np.asarray(K, dtype=np.float64)
         self.hp = hyper_paras or default_hyper_paras()
-        self.rng = rng or np.random.default_rng()
+        self.rng = rng or np.random.default_rng()      # sample triples of the localisation
+        self.rng_map = rng_map or self.rng.spawn(1)[0]  # trials of the epipolar filter: an independent stream
         self.S, self.B = init_state(p_W_landmarks, keypoints_xy, T_init_WC, window_size, keyframe_d, ctx=self.ctx)
         opts = dict(BlockSize=[21, 21], NumPyramidLevels=5, MaxIterations=20, MaxBidirectionalError=6)  # :342-349
         opts.update(tracker_options or {})
@@ -246,7 +247,7 @@ class VOPipeline:
         S.est_trans = np.hstack([S.est_trans, T_W_C[:3, 3:4]])  # :401-403
         S.est_rot = np.hstack([S.est_rot, T_W_C[:3, :3].reshape(9, 1, order="F")])
         if S.C.shape[1] > 0:                                    # :406-408
-            S, B = update_landmarks(S, B, self.KLT_tracker_C, pyr, K, hp, rng=self.rng, ctx=ctx)
+            S, B = update_landmarks(S, B, self.KLT_tracker_C, pyr, K, hp, rng=self.rng_map, ctx=ctx)
         if hp.is_BA:                                            # :409-411
             S, B = VO_bundle_adjust(S, B, T_W_C, K, hp, ctx=ctx)
         S = update_candidate(S, valid_key_candidates, image, K, hp, ctx=ctx)    # :413
