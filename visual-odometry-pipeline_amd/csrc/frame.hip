@@ -545,8 +545,8 @@ struct vohip_frame {
     double K[9];
     int rows = 0, cols = 0, colmajor = 0;
     int capL = 0, capC = 0, capK = 0, hmax = 0;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_pyr = nullptr, ev_side = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_side = nullptr, ev_det = nullptr, ev_img = nullptr;
     void *block = nullptr;       // one device allocation, carved up below
     void *pinned = nullptr;      // host mirror of the counters and doubles
     uint8_t *img = nullptr;      // image staging (host images)
@@ -579,6 +579,8 @@ size_t layout(vohip_frame *f, char *base)
 {
     char *p = base;
     const size_t L = f->capL, C = f->capC, Kc = f->capK, H = f->hmax, T = f->prm.fm_trials;
+    f->dv = carve<double>(p, N_DOUBLES);   // dv and cnt are adjacent: one copy brings both to the host
+    f->cnt = carve<int>(p, N_COUNTERS);
     f->L_rc = carve<double>(p, 2 * L);
     f->L_X = carve<double>(p, 3 * L);
     f->L_id = carve<double>(p, L);
@@ -604,14 +606,12 @@ size_t layout(vohip_frame *f, char *base)
     f->u3 = carve<double>(p, 3 * H);
     f->u8 = carve<double>(p, 8 * T);
     f->fm_F = carve<double>(p, 9 * T);
-    f->dv = carve<double>(p, N_DOUBLES);
     f->corner_xy = carve<float>(p, 2 * Kc);
     f->corner_metric = carve<float>(p, Kc);
     f->samples3 = carve<int32_t>(p, 3 * H);
     f->counts4 = carve<int32_t>(p, 4 * H);
     f->samples8 = carve<int32_t>(p, 8 * T);
     f->fm_counts = carve<int32_t>(p, T);
-    f->cnt = carve<int>(p, N_COUNTERS);
     f->kL_valid = carve<uint8_t>(p, L);
     f->kC_valid = carve<uint8_t>(p, C);
     f->mask = carve<uint8_t>(p, L);
@@ -631,31 +631,48 @@ struct stream_swap {
     ~stream_swap() { ctx->stream = saved; }
 };
 
+// pinned host block: [dv mirror | cnt mirror | staging of the P3P uniforms | staging of the trial uniforms]
+constexpr size_t PIN_CNT = sizeof(double) * N_DOUBLES;
+constexpr size_t PIN_U3 = PIN_CNT + sizeof(int) * N_COUNTERS;
+inline double *pin_dv(vohip_frame *f) { return (double *)f->pinned; }
+inline int *pin_cnt(vohip_frame *f) { return (int *)((char *)f->pinned + PIN_CNT); }
+inline double *pin_u3(vohip_frame *f) { return (double *)((char *)f->pinned + PIN_U3); }
+inline double *pin_u8(vohip_frame *f) { return pin_u3(f) + 3 * (size_t)f->hmax; }
+
 int fetch_summary(vohip_frame *f)
 {
     vohip_ctx *ctx = f->ctx;
-    int *hc = (int *)f->pinned;
-    double *hd = (double *)((char *)f->pinned + 256);
-    VOHIP_HIP(ctx, hipMemcpyAsync(hc, f->cnt, sizeof(int) * N_COUNTERS, hipMemcpyDeviceToHost, ctx->stream));
-    VOHIP_HIP(ctx, hipMemcpyAsync(hd, f->dv, sizeof(double) * N_DOUBLES, hipMemcpyDeviceToHost, ctx->stream));
+    static_assert(sizeof(double) * N_DOUBLES % 256 == 0, "cnt must follow dv directly");
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->pinned, f->dv, PIN_U3, hipMemcpyDeviceToHost, ctx->stream));
     VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VOHIP_OK;
 }
 
-// Second stream: everything that needs neither the new pose nor the localisation draws --
-// corner detection (main_demo.m:377), the candidate tracker and the epipolar filter
-// (update_landmarks.m:10-25).
-int enqueue_side(vohip_frame *f, const uint8_t *d_img)
+// Second stream, part 1: the candidate tracker (update_landmarks.m:10), the long pole of that stream.
+int enqueue_side_track(vohip_frame *f)
+{
+    vohip_ctx *ctx = f->ctx;
+    const vohip_frame_params &p = f->prm;
+    stream_swap sw(ctx, f->side);
+    VOHIP_HIP(ctx, hipStreamWaitEvent(f->side, f->ev_pyr, 0));
+    if (f->have_map)
+        VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->C_xy, f->capC, f->n_C, nullptr, p.klt_block,
+                                    p.klt_max_iter, p.klt_max_bidir_error, f->kC_out, f->kC_valid, nullptr));
+    return VOHIP_OK;
+}
+
+// Second stream, part 2: the epipolar filter over the candidate tracks (update_landmarks.m:11-25),
+// which needs neither the new pose nor the localisation draws.
+int enqueue_side_filter(vohip_frame *f, const double *u8)
 {
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
     const int T = p.fm_trials;
     stream_swap sw(ctx, f->side);
     hipStream_t s = f->side;
-    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_pyr, 0));
     if (f->have_map) {
-        VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->C_xy, f->capC, f->n_C, nullptr, p.klt_block,
-                                    p.klt_max_iter, p.klt_max_bidir_error, f->kC_out, f->kC_valid, nullptr));
+        std::memcpy(pin_u8(f), u8, sizeof(double) * 8 * (size_t)T);
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, pin_u8(f), sizeof(double) * 8 * (size_t)T, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->kC_out, f->capC,
                            f->kC_valid, f->C_rc, f->F_rc, f->T12, f->n_C, f->p1_rc, f->m_rc, f->F_t, f->T_t, f->cnt);
         hipLaunchKernelGGL(octets_kernel, dim3((T + 63) / 64), dim3(64), 0, s, f->u8, T, f->cnt, f->samples8);
@@ -667,25 +684,37 @@ int enqueue_side(vohip_frame *f, const uint8_t *d_img)
                                         f->fmask));
         hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->m_rc, f->F_t, f->T_t,
                            f->fmask, f->cnt, f->m2_rc, f->F2, f->T2);
+        VOHIP_HIP(ctx, hipGetLastError());
     }
-    VOHIP_TRY(vohip_detect_corners_dev(ctx, d_img, f->rows, f->cols, f->colmajor, p.min_quality, p.filter_size, p.border,
-                                       p.detector, f->corner_xy, f->corner_metric, f->capK, f->cnt + N_DET));
-    VOHIP_HIP(ctx, hipGetLastError());
     VOHIP_HIP(ctx, hipEventRecord(f->ev_side, s));
     return VOHIP_OK;
 }
 
-// Localisation over hypotheses [f->evaluated, h), the rest of the frame, and the frame's single
-// synchronisation.  Every kernel here reads only buffers that an earlier run of the same sequence
-// leaves intact, so it can run again with more hypotheses when the adaptive bound asks for them.
-int finish_frame(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *out)
+// Third stream: corner detection (main_demo.m:377) needs only the image.
+int enqueue_detection(vohip_frame *f, const uint8_t *d_img)
+{
+    vohip_ctx *ctx = f->ctx;
+    const vohip_frame_params &p = f->prm;
+    stream_swap sw(ctx, f->side2);
+    VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, f->ev_img, 0));
+    VOHIP_TRY(vohip_detect_corners_dev(ctx, d_img, f->rows, f->cols, f->colmajor, p.min_quality, p.filter_size, p.border,
+                                       p.detector, f->corner_xy, f->corner_metric, f->capK, f->cnt + N_DET));
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_det, f->side2));
+    return VOHIP_OK;
+}
+
+// Localisation over hypotheses [f->evaluated, h) (ransacLocalization.m, T_refinement.m) on the
+// context's stream.  Every kernel reads only buffers an earlier run leaves intact, so it can run
+// again with more hypotheses when the adaptive bound asks for them.
+int enqueue_localize(vohip_frame *f, const double *u3, int h)
 {
     vohip_ctx *ctx = f->ctx;
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
     const int first = f->evaluated, more = h - first;
-    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3 + 3 * (size_t)first, u3 + 3 * (size_t)first, sizeof(double) * 3 * more,
-                                  hipMemcpyHostToDevice, s));
+    std::memcpy(pin_u3(f) + 3 * (size_t)first, u3 + 3 * (size_t)first, sizeof(double) * 3 * (size_t)more);
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3 + 3 * (size_t)first, pin_u3(f) + 3 * (size_t)first,
+                                  sizeof(double) * 3 * (size_t)more, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more)), dim3(256), 0, s, f->u3, first, more, f->cnt, f->samples3);
     VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
                                    f->counts4));
@@ -700,8 +729,17 @@ int finish_frame(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose
     if (p.refine_pose)   // main_demo.m:398-400
         VOHIP_TRY(vohip_pose_refine_enqueue(ctx, f->dv + D_T, f->kp_uv, f->L_X, f->n_L, f->cnt + N_IN, f->K,
                                             p.refine_max_iter, 1e-10, 1e-10, f->dv + D_STATS));
-    // update_landmarks.m:27-125 and update_candidate.m with the new pose
+    return VOHIP_OK;
+}
+
+// update_landmarks.m:27-125 and update_candidate.m with the new pose, once the other streams are done.
+int enqueue_tail(vohip_frame *f)
+{
+    vohip_ctx *ctx = f->ctx;
+    hipStream_t s = ctx->stream;
+    const vohip_frame_params &p = f->prm;
     VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_side, 0));
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_det, 0));
     if (f->have_map) {
         VOHIP_TRY(vohip_candidate_triangulate_enqueue(ctx, f->m2_rc, f->F2, f->T2, f->n_C, f->cnt + N_CI, f->dv + D_T,
                                                       f->K, p.angle_threshold_deg, p.min_depth, p.max_depth, 0,
@@ -718,10 +756,16 @@ int finish_frame(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose
     hipLaunchKernelGGL(next_tracks_kernel, dim3(blocks256(nmax)), dim3(256), 0, s, f->L_rc, f->capL, f->L_xy, f->C_rc,
                        f->capC, f->C_xy, f->cnt);
     VOHIP_HIP(ctx, hipGetLastError());
-    VOHIP_TRY(fetch_summary(f));
+    return VOHIP_OK;
+}
 
-    const int *hc = (const int *)f->pinned;
-    const double *hd = (const double *)((const char *)f->pinned + 256);
+// The frame's single synchronisation and its results.
+int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_counts *out)
+{
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_TRY(fetch_summary(f));
+    const int *hc = pin_cnt(f);
+    const double *hd = pin_dv(f);
     std::memset(pose, 0, sizeof(*pose));
     std::memset(out, 0, sizeof(*out));
     pose->n_tracked = hc[N_V];
@@ -830,10 +874,15 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     const size_t bytes = layout(f, nullptr);
     hipError_t e = hipMalloc(&f->block, bytes);
     if (e == hipSuccess) e = hipMemsetAsync(f->block, 0, bytes, ctx->stream);
-    if (e == hipSuccess) e = hipHostMalloc(&f->pinned, 256 + sizeof(double) * N_DOUBLES, hipHostMallocDefault);
+    if (e == hipSuccess)
+        e = hipHostMalloc(&f->pinned, PIN_U3 + sizeof(double) * (3 * (size_t)f->hmax + 8 * (size_t)p.fm_trials),
+                          hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_pyr, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_side, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_img, hipEventDisableTiming);
     if (e != hipSuccess) {
         vohip_frame_destroy(f);
         return vohip_fail(ctx, VOHIP_ERR_HIP, "frame state allocation failed: %s", hipGetErrorString(e));
@@ -858,9 +907,15 @@ int vohip_frame_destroy(vohip_frame *f)
         (void)hipStreamSynchronize(f->side);
         (void)hipStreamDestroy(f->side);
     }
+    if (f->side2) {
+        (void)hipStreamSynchronize(f->side2);
+        (void)hipStreamDestroy(f->side2);
+    }
+    if (f->ev_det) (void)hipEventDestroy(f->ev_det);
     if (f->ctx) (void)hipStreamSynchronize(f->ctx->stream);
     if (f->ev_pyr) (void)hipEventDestroy(f->ev_pyr);
     if (f->ev_side) (void)hipEventDestroy(f->ev_side);
+    if (f->ev_img) (void)hipEventDestroy(f->ev_img);
     if (f->block) (void)hipFree(f->block);
     if (f->pinned) (void)hipHostFree(f->pinned);
     delete f;
@@ -878,6 +933,7 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     VOHIP_HIP(ctx, hipStreamSynchronize(f->side));
+    VOHIP_HIP(ctx, hipStreamSynchronize(f->side2));
     const uint8_t *d_img = image;
     if (!image_on_device) {
         VOHIP_HIP(ctx, hipMemcpyAsync(f->img, image, (size_t)f->rows * f->cols, hipMemcpyHostToDevice, s));
@@ -888,7 +944,7 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     VOHIP_HIP(ctx, hipMemsetAsync(f->dv, 0, sizeof(double) * N_DOUBLES, s));
     VOHIP_HIP(ctx, hipMemcpyAsync(f->L_rc, P_rc, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
     VOHIP_HIP(ctx, hipMemcpyAsync(f->L_X, X, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
-    double *hd = (double *)((char *)f->pinned + 256);
+    double *hd = pin_u3(f);   // staging
     std::memcpy(hd, T_W_C, sizeof(double) * 16);
     hd[16] = ids ? 0.0 : (double)(n + 1);
     if (ids) {
@@ -909,7 +965,7 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     VOHIP_HIP(ctx, hipMemcpyAsync(f->dv + D_T, hd, sizeof(double) * 16, hipMemcpyHostToDevice, s));
     VOHIP_HIP(ctx, hipMemcpyAsync(f->dv + D_IDX, hd + 16, sizeof(double), hipMemcpyHostToDevice, s));
     VOHIP_HIP(ctx, hipMemcpyAsync(f->dv + D_IDX_NEXT, hd + 16, sizeof(double), hipMemcpyHostToDevice, s));
-    int *hc = (int *)f->pinned;
+    int *hc = pin_cnt(f);
     hc[0] = n;
     VOHIP_HIP(ctx, hipMemcpyAsync(f->cnt + N_L_END, hc, sizeof(int), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(next_tracks_kernel, dim3(blocks256(n)), dim3(256), 0, s, f->L_rc, f->capL, f->L_xy, f->C_rc,
@@ -939,21 +995,27 @@ int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, 
         VOHIP_HIP(ctx, hipMemcpyAsync(f->img, image, (size_t)f->rows * f->cols, hipMemcpyHostToDevice, s));
         d_img = f->img;
     }
-    VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
     f->have_map = f->n_C > 0;   // main_demo.m:406
-    if (f->have_map)
-        VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, u8, sizeof(double) * 8 * (size_t)p.fm_trials, hipMemcpyHostToDevice, s));
+    f->evaluated = 0;
+    f->stage = 1;
+    // The order of the enqueues follows the critical path: the context's stream (pyramid ->
+    // landmark tracker -> localisation) is fed first at every step, the two long trackers start
+    // as early as possible, the short kernels of the other streams are enqueued while they run.
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_img, s));
+    VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
     VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));
-    VOHIP_TRY(enqueue_side(f, d_img));
     // landmark tracker (main_demo.m:380) and the selection of the valid tracks (:381, :387)
     VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->L_xy, f->capL, f->n_L, nullptr, p.klt_block,
                                 p.klt_max_iter, p.klt_max_bidir_error, f->kL_out, f->kL_valid, nullptr));
+    VOHIP_TRY(enqueue_side_track(f));
     hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->kL_out, f->capL, f->kL_valid,
                        f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->cnt, f->dv);
     VOHIP_HIP(ctx, hipGetLastError());
-    f->evaluated = 0;
-    f->stage = 1;
-    return finish_frame(f, u3, h, pose, counts);
+    VOHIP_TRY(enqueue_localize(f, u3, h));
+    VOHIP_TRY(enqueue_detection(f, d_img));
+    VOHIP_TRY(enqueue_side_filter(f, u8));
+    VOHIP_TRY(enqueue_tail(f));
+    return complete_frame(f, h, pose, counts);
 }
 
 int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *counts)
@@ -964,7 +1026,9 @@ int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose 
     VOHIP_REQUIRE(ctx, f->stage == 1, "no frame is waiting for more hypotheses");
     VOHIP_REQUIRE(ctx, h > f->evaluated && h <= f->hmax, "hypothesis count must grow and stay within max_hypotheses");
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
-    return finish_frame(f, u3, h, pose, counts);
+    VOHIP_TRY(enqueue_localize(f, u3, h));
+    VOHIP_TRY(enqueue_tail(f));
+    return complete_frame(f, h, pose, counts);
 }
 
 int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates)
