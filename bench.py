@@ -30,6 +30,8 @@ if ROOT not in sys.path:
 
 METRIC = "VO frames/sec (KITTI 1241x376, 2k kpts) + RANSAC hypotheses/sec per GPU"
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector fp64: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector fp32
+LDS_PEAK_TBS = 78.6            # 256 CU x 128 B/clk x 2.4 GHz
 MATLAB_KITTI_HARRIS_FPS = 3.817  # the reference's published figure (Ryzen 7 5800H, MATLAB, real KITTI 05)
 CACHE = os.environ.get("VOHIP_CACHE", "/tmp/vohip_cache")
 
@@ -121,6 +123,48 @@ def bench_ransac(vo, torch, ctx, n, h, steps, warmup, seed):
     return hyps_per_s, score_ms
 
 
+def bench_klt(vo, torch, ctx, d_frames, xy, n_points, reps=20):
+    """The tracker kernel alone (21x21, 5 levels, 20 iterations, forward-backward) on two consecutive
+    frames: kernel time from HIP events on its stream, work from the library's own counters."""
+    import ctypes as C
+    lib = vo._lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    reps_xy = int(np.ceil(n_points / len(xy)))
+    pts = np.concatenate([xy + 0.37 * k for k in range(reps_xy)])[:n_points]
+    p0, p1 = vo.Pyramid(d_frames[0], 5, ctx=ctx), vo.Pyramid(d_frames[1], 5, ctx=ctx)
+    d_pts = torch.from_numpy(np.ascontiguousarray(pts.T)).to(dev)
+    d_out = torch.zeros_like(d_pts)
+    d_valid = torch.zeros(n_points, dtype=torch.uint8, device=dev)
+
+    def run():
+        ctx.check(lib.vohip_klt_track_dev(ctx.handle, p0.slot, p1.slot, d_pts.data_ptr(), n_points, 21, 20, 6.0,
+                                          d_out.data_ptr(), d_valid.data_ptr(), None))
+
+    run()
+    torch.cuda.synchronize()
+    tr, it = C.c_longlong(0), C.c_longlong(0)
+    ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        run()
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
+    p0.release()
+    p1.release()
+    passes = tr.value * 5 * 2 / reps                   # (track, level, direction) triples per launch
+    iters = it.value / reps
+    flop = 11907.0 * passes + 5292.0 * iters          # 441 px x (27 set-up + 12 per iteration) fp32 flop
+    lds = 441.0 * 4 * 4 * iters                       # 4 bilinear taps x 4 B per window pixel per iteration
+    return dict(kernel="klt_track_kernel<21>", tracks=n_points, kernel_ms=ms, mean_iterations_per_pass=iters / passes,
+                valid_fraction=float(d_valid.float().mean().item()), achieved_tflops=flop / (ms * 1e-3) / 1e12,
+                peak_tflops=FP32_VALU_PEAK_TFLOPS, frac_valu=flop / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                achieved_lds_tbs=lds / (ms * 1e-3) / 1e12, peak_lds_tbs=LDS_PEAK_TBS,
+                frac_lds=lds / (ms * 1e-3) / 1e12 / LDS_PEAK_TBS)
+
+
 def cpu_baseline_frames(vo, scene, frames, poses, X0, xy0, budget_s=20.0):
     """The CPU restatement of the same loop on the first frames of the same sequence."""
     from oracle import pipeline_oracle as po
@@ -186,6 +230,11 @@ def main():
             elapsed = float(t.item())
         fps = world * args.steps / elapsed
 
+        d2 = [torch.from_numpy(f).to(torch.device("cuda", local_rank)) for f in frames[:2]]
+        _, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
+        klt_frame = bench_klt(vo, torch, ctx, d2, xy0, len(xy0))
+        klt_stress = bench_klt(vo, torch, ctx, d2, xy0, 8192)
+
         n, h = args.points, args.hypotheses
         hyps_per_s, score_ms = bench_ransac(vo, torch, ctx, n, h, max(args.steps, 20), args.warmup, 100 + rank)
         achieved = 116.0 * n * h / (score_ms * 1e-3) / 1e12
@@ -217,6 +266,10 @@ def main():
             "roofline": {"bound": "valu_fp64", "kernel": "p3p_score_kernel (RANSAC stress)", "achieved": achieved,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS,
                          "traffic": None, "kernel_ms": score_ms},
+            "roofline_klt": {"note": "dominant kernel of the frame loop; one wavefront per track, so at ~2k tracks "
+                                     "the launch is bound by the dependent-iteration latency of the slowest track, "
+                                     "not by LDS or VALU throughput; the 8192-track launch is the stress configuration",
+                             "frame_config": klt_frame, "stress_config": klt_stress},
         }
         if not args.no_cpu_baseline and world == 1:
             X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])

@@ -302,6 +302,11 @@ int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const doubl
                         int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
                         uint8_t *d_valid, double *d_fb_err);
 
+/* Work counters of the tracker since the last reset (no reference counterpart; measurement only):
+ * tracks processed and Gauss-Newton iterations executed over all levels and both directions.
+ * Synchronises the device. */
+int vohip_klt_stats(vohip_ctx *ctx, long long *tracks, long long *iterations, int reset);
+
 /* ---- fundamental-matrix RANSAC -----------------------------------------------------------
  * Stands in for [F, inliersIndex] = estimateFundamentalMatrix(p1, p2, 'NumTrials', 500, 'Method',
  * 'RANSAC', 'DistanceThreshold', 5e-2) at update_landmarks.m:13-14 (Sampson distance; the toolbox

@@ -60,6 +60,7 @@ class FrameCounts(C.Structure):
 
 # name -> (restype, argtypes); mirrors include/vohip.h one to one
 SIGNATURES = {
+    "vohip_klt_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
     "vohip_frame_default_params": (None, [C.POINTER(FrameParams)]),
     "vohip_frame_create": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams),
                                       C.POINTER(C.c_void_p)]),

@@ -97,7 +97,7 @@ struct klt_cfg {
 // Tracks (pa, pb) from pyramid P to pyramid Q.  sI / sJ: this wavefront's LDS.
 template <int W>
 __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, double pa, double pb,
-                          double &qa, double &qb, float *sI, float *sJ)
+                          double &qa, double &qb, float *sI, float *sJ, int &iters)
 {
     using C = klt_cfg<W>;
     const int lane = threadIdx.x;
@@ -225,6 +225,7 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                 const double sb = (gxx * bb - gxy * ba) * inv_det;
                 da += sa;
                 db += sb;
+                ++iters;
                 if (sa * sa + sb * sb < KLT_EPS_STEP * KLT_EPS_STEP) break;
                 // a step that undoes the previous one: the estimate oscillates around the minimum;
                 // settle half-way and stop
@@ -256,7 +257,8 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_desc P, pyr_desc Q, c
                                                        int n, const int *__restrict__ n_dev, int ld, int swap_xy,
                                                        int max_iter, double max_bidir,
                                                        double *__restrict__ out_xy, uint8_t *__restrict__ valid,
-                                                       double *__restrict__ fb_err)
+                                                       double *__restrict__ fb_err,
+                                                       unsigned long long *__restrict__ stats)
 {
     using C = klt_cfg<W>;
     __shared__ float sI[C::SI * C::SI];
@@ -267,8 +269,9 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_desc P, pyr_desc Q, c
     const double x = pts_xy[i] - 1.0, y = pts_xy[ld + i] - 1.0;
     const double pa = swap_xy ? y : x, pb = swap_xy ? x : y;
     double qa, qb, ra, rb;
-    const bool ok_f = track_dir<W>(P, Q, max_iter, pa, pb, qa, qb, sI, sJ);
-    const bool ok_b = track_dir<W>(Q, P, max_iter, qa, qb, ra, rb, sI, sJ);
+    int iters = 0;
+    const bool ok_f = track_dir<W>(P, Q, max_iter, pa, pb, qa, qb, sI, sJ, iters);
+    const bool ok_b = track_dir<W>(Q, P, max_iter, qa, qb, ra, rb, sI, sJ, iters);
     const double ea = ra - pa, eb = rb - pb;
     const double err = sqrt(ea * ea + eb * eb);
     const bool inside = qa >= 0.0 && qa <= (double)(P.A[0] - 1) && qb >= 0.0 && qb <= (double)(P.B[0] - 1);
@@ -277,6 +280,10 @@ __global__ __launch_bounds__(64) void klt_track_kernel(pyr_desc P, pyr_desc Q, c
         out_xy[ld + i] = (swap_xy ? qa : qb) + 1.0;
         valid[i] = (ok_f && ok_b && inside && err <= max_bidir) ? 1 : 0;
         if (fb_err) fb_err[i] = err;
+        if (stats) {   // work counters: tracks, Gauss-Newton iterations (both directions, all levels)
+            atomicAdd(stats, 1ull);
+            atomicAdd(stats + 1, (unsigned long long)iters);
+        }
     }
 }
 
@@ -383,12 +390,18 @@ int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double 
     VOHIP_REQUIRE(ctx, pp.rows == pq.rows && pp.cols == pq.cols && pp.colmajor == pq.colmajor && pp.levels == pq.levels,
                   "previous and current pyramids differ in shape");
     const int swap_xy = pp.colmajor;
+    if (!ctx->bufs[B_KLT_STATS].ptr) {
+        VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_KLT_STATS], 64));
+        VOHIP_HIP(ctx, hipMemsetAsync(ctx->bufs[B_KLT_STATS].ptr, 0, 64, ctx->stream));
+        VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    unsigned long long *d_stats = (unsigned long long *)ctx->bufs[B_KLT_STATS].ptr;
     if (block_size == 21)
         hipLaunchKernelGGL(klt_track_kernel<21>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, d_n, ld,
-                           swap_xy, max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err);
+                           swap_xy, max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err, d_stats);
     else if (block_size == 31)
         hipLaunchKernelGGL(klt_track_kernel<31>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, d_n, ld,
-                           swap_xy, max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err);
+                           swap_xy, max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err, d_stats);
     else
         return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "BlockSize %d not built (21 and 31 are)", block_size);
     VOHIP_HIP(ctx, hipGetLastError());
@@ -396,6 +409,21 @@ int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double 
 }
 
 extern "C" {
+
+int vohip_klt_stats(vohip_ctx *ctx, long long *tracks, long long *iterations, int reset)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    unsigned long long h[2] = {0, 0};
+    if (ctx->bufs[B_KLT_STATS].ptr) {
+        VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VOHIP_HIP(ctx, hipDeviceSynchronize());   // trackers may run on other streams of this context's owner
+        VOHIP_HIP(ctx, hipMemcpy(h, ctx->bufs[B_KLT_STATS].ptr, sizeof(h), hipMemcpyDeviceToHost));
+        if (reset) VOHIP_HIP(ctx, hipMemset(ctx->bufs[B_KLT_STATS].ptr, 0, 64));
+    }
+    if (tracks) *tracks = (long long)h[0];
+    if (iterations) *iterations = (long long)h[1];
+    return VOHIP_OK;
+}
 
 int vohip_klt_track(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *pts_xy, int n, int block_size,
                     int max_iter, double max_bidir_error, double *out_xy, uint8_t *valid, double *fb_err)

@@ -35,6 +35,7 @@ enum vohip_buf_id {
     B_FM_NRM, B_FM_F, B_FM_COUNTS, H_FM_COUNTS,
     B_BA_INDEX, B_BA_FRAME, B_BA_LM, B_BA_UV, B_BA_COUNT, B_BA_STATE, B_BA_TRIAL, B_BA_SPART, B_BA_GPART,
     B_BA_E, B_BA_GL, B_BA_W, B_BA_DP, B_BA_PART, B_BA_STATUS, H_BA_STATUS,
+    B_KLT_STATS,
     B_PYR0, B_PYR1, B_PYR2, B_PYR3, B_PYR4, B_PYR5, B_PYR6, B_PYR7,
     VOHIP_NBUF = 96
 };
