@@ -58,9 +58,12 @@ def init_points(vo, ctx, scene, frame0, pose0):
     return scene.backproject(pose0, xy), xy
 
 
-def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barrier, gather):
+def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barrier, gather, resident=True):
     dev = torch.device("cuda", torch.cuda.current_device())
-    d_frames = [torch.from_numpy(f).to(dev) for f in frames[:warmup + steps + 1]]
+    if resident:
+        d_frames = [torch.from_numpy(f).to(dev) for f in frames[:warmup + steps + 1]]
+    else:   # frames stay in host memory; every step uploads its 466 KB image
+        d_frames = list(frames[:warmup + steps + 1])
     X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
     hp = vo.default_hyper_paras("kitti", is_BA=False)
     pipe = vo.VOPipelineDevice(vo.synth.K_KITTI, d_frames[0], X0, xy0, poses[0], hyper_paras=hp,
@@ -165,7 +168,7 @@ def bench_klt(vo, torch, ctx, d_frames, xy, n_points, reps=20):
                 frac_lds=lds / (ms * 1e-3) / 1e12 / LDS_PEAK_TBS)
 
 
-def cpu_baseline_frames(vo, scene, frames, poses, X0, xy0, budget_s=20.0):
+def cpu_baseline_frames(vo, scene, frames, poses, X0, xy0, budget_s=12.0):
     """The CPU restatement of the same loop on the first frames of the same sequence."""
     from oracle import pipeline_oracle as po
     from oracle import vo_oracle
@@ -221,9 +224,14 @@ def main():
             return vo.batch.gather_records([rec], world, device=torch.device("cuda", local_rank) if world > 1 else None)
 
         n_frames = args.warmup + args.steps + 1
-        scene, frames, poses = make_sequence(vo, n_frames)
+        # with the CPU baseline leg the sequence is longer, so that its sample is about 10 s of CPU work
+        n_seq = n_frames if (args.no_cpu_baseline or world > 1) else max(n_frames, 200)
+        scene, frames_all, poses_all = make_sequence(vo, n_seq)
+        frames, poses = frames_all[:n_frames], poses_all[:n_frames]
         elapsed, info = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
                                      gather)
+        elapsed_h2d, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
+                                      gather, resident=False)
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -261,6 +269,7 @@ def main():
                        "final_position_error_m": info["final_position_error_m"],
                        "baseline_note": "vs_baseline divides by the reference's published 3.817 frames/s "
                                         "(MATLAB, Ryzen 7 5800H, real KITTI 05, Harris)"},
+            "frames_per_s_pcie_inclusive": args.steps / elapsed_h2d,
             "ransac_hypotheses_per_s": hyps_per_s,
             "ransac_config": {"workload": "RANSAC stress: %d P3P hypotheses x %d correspondences per step" % (h, n)},
             "roofline": {"bound": "valu_fp64", "kernel": "p3p_score_kernel (RANSAC stress)", "achieved": achieved,
@@ -272,8 +281,8 @@ def main():
                              "frame_config": klt_frame, "stress_config": klt_stress},
         }
         if not args.no_cpu_baseline and world == 1:
-            X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
-            v, done, dt = cpu_baseline_frames(vo, scene, frames, poses, X0, xy0)
+            X0, xy0 = init_points(vo, ctx, scene, frames_all[0], poses_all[0])
+            v, done, dt = cpu_baseline_frames(vo, scene, frames_all, poses_all, X0, xy0)
             out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "kind": "port",
                                    "sample": "%d frames of the same sequence through the CPU restatement of the loop "
                                              "(OpenMP in the tracker, scalar elsewhere), %.1f s" % (done, dt)}
