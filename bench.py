@@ -72,15 +72,19 @@ def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barr
         pipe.process_frame(d_frames[i])
     barrier()
     t0 = time.perf_counter()
+    enq = wait = 0.0
     for i in range(warmup + 1, warmup + steps + 1):
         pipe.process_frame(d_frames[i])
+        enq += pipe.last_counts.host_enqueue_us
+        wait += pipe.last_counts.host_wait_us
     records = gather(pipe, time.perf_counter() - t0)
     barrier()
     elapsed = time.perf_counter() - t0
     last = warmup + steps
     T = pipe.est_trans[-1]
     info = dict(n_landmarks=int(np.mean(pipe.num_X[-steps:])), n_candidates=int(np.mean(pipe.num_C[-steps:])),
-                final_position_error_m=float(np.linalg.norm(T - poses[last][:3, 3])), records=len(records))
+                final_position_error_m=float(np.linalg.norm(T - poses[last][:3, 3])), records=len(records),
+                host_enqueue_us_per_frame=enq / steps, host_wait_us_per_frame=wait / steps)
     pipe.close()
     return elapsed, info
 
@@ -145,8 +149,6 @@ def bench_klt(vo, torch, ctx, d_frames, xy, n_points, reps=20):
 
     run()
     torch.cuda.synchronize()
-    tr, it = C.c_longlong(0), C.c_longlong(0)
-    ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(reps):
@@ -154,11 +156,17 @@ def bench_klt(vo, torch, ctx, d_frames, xy, n_points, reps=20):
     ev1.record()
     torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / reps
+    # one more launch with the work counters on (they cost two atomics per track, so not while timing)
+    tr, it = C.c_longlong(0), C.c_longlong(0)
+    ctx.set_option("klt_stats", 1)
     ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
+    run()
+    ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
+    ctx.set_option("klt_stats", 0)
     p0.release()
     p1.release()
-    passes = tr.value * 5 * 2 / reps                   # (track, level, direction) triples per launch
-    iters = it.value / reps
+    passes = tr.value * 5 * 2                          # (track, level, direction) triples per launch
+    iters = it.value
     flop = 11907.0 * passes + 5292.0 * iters          # 441 px x (27 set-up + 12 per iteration) fp32 flop
     lds = 441.0 * 4 * 4 * iters                       # 4 bilinear taps x 4 B per window pixel per iteration
     return dict(kernel="klt_track_kernel<21>", tracks=n_points, kernel_ms=ms, mean_iterations_per_pass=iters / passes,
@@ -267,6 +275,8 @@ def main():
                                    "per rank one independent replica (batch mode)",
                        "tracked_landmarks": info["n_landmarks"], "candidates": info["n_candidates"],
                        "final_position_error_m": info["final_position_error_m"],
+                       "host_enqueue_us_per_frame": info["host_enqueue_us_per_frame"],
+                       "host_wait_us_per_frame": info["host_wait_us_per_frame"],
                        "baseline_note": "vs_baseline divides by the reference's published 3.817 frames/s "
                                         "(MATLAB, Ryzen 7 5800H, real KITTI 05, Harris)"},
             "frames_per_s_pcie_inclusive": args.steps / elapsed_h2d,

@@ -60,7 +60,8 @@ void *vohip_stream(vohip_ctx *ctx);
 int vohip_synchronize(vohip_ctx *ctx);
 /* Tuning knobs (no reference counterpart).  "ransac_score_variant" 0..5 (-1 = automatic, the default) selects the workgroup
  * geometry (hypotheses per workgroup x points per LDS tile) of the RANSAC scoring kernel; results
- * do not depend on it. */
+ * do not depend on it.  "klt_stats" 1 makes the tracker count its work (see vohip_klt_stats; two
+ * atomics per track, off by default). */
 int vohip_set_option(vohip_ctx *ctx, const char *name, int value);
 /* Library version, "major.minor". */
 const char *vohip_version(void);
@@ -226,6 +227,7 @@ typedef struct vohip_frame_counts {
     int n_detected, n_kept;          /* corners found / kept as new candidates */
     int n_candidates_tracked, n_candidates_inliers, fm_trials_run;
     int overflow;
+    double host_enqueue_us, host_wait_us;   /* host time spent enqueuing / waiting in this call */
 } vohip_frame_counts;
 
 void vohip_frame_default_params(vohip_frame_params *p);

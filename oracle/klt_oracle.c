@@ -27,7 +27,8 @@
  *    stopping after a step shorter than 0.01 px, or when a step cancels the previous one to
  *    within 0.01 px (oscillation: half of the last step is taken back).  G is summed in double; the right-hand side is
  *    summed in float within each of 64 pixel groups (pixel q in group q mod 64, increasing q,
- *    fmaf) and in double across the groups.
+ *    fmaf) and across the groups by a fixed float tree: fours ((g0+g1)+(g2+g3)), pairs of fours,
+ *    pairs of eights, then the four sixteens as ((r0+r1)+r2)+r3.
  *    The displacement doubles between levels.
  *  - A point is valid iff at level 0 G is well conditioned in both directions
  *    (lambda_min(G) / W^2 >= 1e-3), the forward result lies inside the image, and the
@@ -41,6 +42,23 @@
 
 #define KLT_EPS_STEP 0.01
 #define KLT_MIN_EIG 1e-3
+
+/* Sum of 64 floats in the fixed order of the tracker's wavefront reduction. */
+static float tree64(const float *g)
+{
+    float r[4];
+    for (int n = 0; n < 4; ++n) {
+        float h[2];
+        for (int m = 0; m < 2; ++m) {
+            const float *p = g + 16 * n + 8 * m;
+            const float q0 = (p[0] + p[1]) + (p[2] + p[3]);
+            const float q1 = (p[4] + p[5]) + (p[6] + p[7]);
+            h[m] = q0 + q1;
+        }
+        r[n] = h[0] + h[1];
+    }
+    return ((r[0] + r[1]) + r[2]) + r[3];
+}
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -158,8 +176,8 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
                 const float ga = (float)(ta - ja), gb = (float)(tb - jb);
                 /* right-hand side: window pixel q = (wb + half) W + (wa + half) belongs to group
                  * q mod 64; each group is summed in float with fmaf in increasing q, the 64 group
-                 * sums are added in double */
-                double ba = 0, bb = 0;
+                 * sums are added in float by the fixed tree of tree64() */
+                float pa_[64], pb_[64];
                 for (int grp = 0; grp < 64; ++grp) {
                     float baf = 0.f, bbf = 0.f;
                     for (int k = grp; k < W * W; k += 64) {
@@ -169,9 +187,10 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
                         baf = fmaf(e, GX[k], baf);
                         bbf = fmaf(e, GY[k], bbf);
                     }
-                    ba += (double)baf;
-                    bb += (double)bbf;
+                    pa_[grp] = baf;
+                    pb_[grp] = bbf;
                 }
+                const double ba = (double)tree64(pa_), bb = (double)tree64(pb_);
                 const double sa = (gyy * ba - gxy * bb) * inv_det;
                 const double sb = (gxx * bb - gxy * ba) * inv_det;
                 da += sa;

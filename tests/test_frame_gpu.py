@@ -61,7 +61,7 @@ def test_device_loop_matches_stage_by_stage_loop(vo, ctx, oracle, sequence):
         assert np.linalg.norm(Td[:3, 3] - poses[i][:3, 3]) < 0.25, i
     S, R = dev.S, ref.S
     np.testing.assert_array_equal(S.X[3], R.X[3])
-    np.testing.assert_allclose(S.X[:3], R.X[:3], rtol=1e-7, atol=1e-7)   # triangulation amplifies the 1e-10 pose difference
+    np.testing.assert_allclose(S.X[:3], R.X[:3], rtol=1e-6, atol=1e-6)   # low-parallax triangulation amplifies the 1e-10 pose difference
     np.testing.assert_allclose(S.P, R.P, rtol=0, atol=1e-9)
     np.testing.assert_allclose(S.C, R.C, rtol=0, atol=1e-9)
     np.testing.assert_allclose(S.F, R.F, rtol=0, atol=1e-9)

@@ -55,7 +55,8 @@ class FrameCounts(C.Structure):
     """vohip_frame_counts"""
     _fields_ = [("n_landmarks", C.c_int), ("n_candidates", C.c_int), ("num_new", C.c_int), ("n_detected", C.c_int),
                 ("n_kept", C.c_int), ("n_candidates_tracked", C.c_int), ("n_candidates_inliers", C.c_int),
-                ("fm_trials_run", C.c_int), ("overflow", C.c_int)]
+                ("fm_trials_run", C.c_int), ("overflow", C.c_int), ("host_enqueue_us", C.c_double),
+                ("host_wait_us", C.c_double)]
 
 
 # name -> (restype, argtypes); mirrors include/vohip.h one to one

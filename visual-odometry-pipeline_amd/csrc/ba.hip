@@ -548,8 +548,7 @@ constexpr int PR_THREADS = 512;
 
 __device__ __forceinline__ double block_sum(double v, double *sWave /*16*/)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    v = wave_sum_f64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) sWave[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -572,7 +571,7 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
                                                                  double *__restrict__ stats /*3*/)
 {
     __shared__ frame_lin sF, sFn;
-    __shared__ double sTw[6], sTwN[6], sH[36], sG[6], sD[6], sWave[16], sPart[27 * (PR_THREADS / 64)];
+    __shared__ double sTw[6], sTwN[6], sH[36], sG[6], sD[6], sWave[16], sPart[27 * (PR_THREADS / 8)];
     __shared__ int sOk;
     const int tid = threadIdx.x;
     if (n_dev) P.n = *n_dev;  // point count kept on the device (the frame pipeline)
@@ -615,35 +614,40 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
                 for (int b = a; b < 6; ++b) h[q++] += Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b];
             }
         }
-        // all 27 sums at once: DPP wave sums, one row of partials per wave, one barrier
+        // all 27 sums at once: three DPP steps leave every group of 8 lanes with its sum, the 64
+        // group sums of each quantity go through LDS, one thread per quantity adds them in order
         {
 #pragma unroll
-            for (int q = 0; q < 21; ++q) h[q] = wave_sum_f64(h[q]);
+            for (int q = 0; q < 21; ++q) h[q] = group8_sum_f64(h[q]);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) g[q] = wave_sum_f64(g[q]);
+            for (int q = 0; q < 6; ++q) g[q] = group8_sum_f64(g[q]);
             __syncthreads();
-            if ((tid & 63) == 0) {
-                double *row = sPart + 27 * (tid >> 6);
+            if ((tid & 7) == 0) {
+                double *col = sPart + (tid >> 3);
 #pragma unroll
-                for (int q = 0; q < 21; ++q) row[q] = h[q];
+                for (int q = 0; q < 21; ++q) col[64 * q] = h[q];
 #pragma unroll
-                for (int q = 0; q < 6; ++q) row[21 + q] = g[q];
+                for (int q = 0; q < 6; ++q) col[64 * (21 + q)] = g[q];
             }
             __syncthreads();
-            if (tid < 27) {
-                double s = 0.0;
-                for (int w = 0; w < PR_THREADS / 64; ++w) s += sPart[27 * w + tid];
-                if (tid < 21) {
-                    // upper-triangle index -> (a, b)
-                    int a = 0, rem = tid;
-                    while (rem >= 6 - a) {
-                        rem -= 6 - a;
-                        ++a;
+            if (tid < 27 * 8) {   // 8 threads per quantity: 8 partials each, then one more group sum
+                const int q = tid >> 3;
+                const double *row = sPart + 64 * q + 8 * (tid & 7);
+                double s = ((row[0] + row[1]) + (row[2] + row[3])) + ((row[4] + row[5]) + (row[6] + row[7]));
+                s = group8_sum_f64(s);
+                if ((tid & 7) == 0) {
+                    if (q < 21) {
+                        // upper-triangle index -> (a, b)
+                        int a = 0, rem = q;
+                        while (rem >= 6 - a) {
+                            rem -= 6 - a;
+                            ++a;
+                        }
+                        const int b = a + rem;
+                        sH[6 * a + b] = sH[6 * b + a] = s;
+                    } else {
+                        sG[q - 21] = s;
                     }
-                    const int b = a + rem;
-                    sH[6 * a + b] = sH[6 * b + a] = s;
-                } else {
-                    sG[tid - 21] = s;
                 }
             }
         }
@@ -652,36 +656,45 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
         while (!accepted && !stop) {
             __syncthreads();
             if (tid == 0) {
+                // 6x6 Cholesky with every loop unrolled, so that A and d stay in registers
                 double A[36], d[6];
+#pragma unroll
                 for (int q = 0; q < 36; ++q) A[q] = sH[q];
+#pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     A[7 * a] *= 1.0 + lambda;
                     d[a] = -sG[a];
                 }
                 int ok = 1;
-                for (int j = 0; j < 6 && ok; ++j) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
                     double dd = A[j * 6 + j];
+#pragma unroll
                     for (int k = 0; k < j; ++k) dd -= A[j * 6 + k] * A[j * 6 + k];
-                    if (!(dd > 0.0)) {
-                        ok = 0;
-                        break;
-                    }
+                    if (!(dd > 0.0)) ok = 0;
                     dd = sqrt(dd);
+                    const double inv = 1.0 / dd;
                     A[j * 6 + j] = dd;
+#pragma unroll
                     for (int i = j + 1; i < 6; ++i) {
                         double s = A[i * 6 + j];
+#pragma unroll
                         for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
-                        A[i * 6 + j] = s / dd;
+                        A[i * 6 + j] = s * inv;
                     }
                 }
                 if (ok) {
+#pragma unroll
                     for (int i = 0; i < 6; ++i) {
                         double s = d[i];
+#pragma unroll
                         for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * d[k];
                         d[i] = s / A[i * 6 + i];
                     }
+#pragma unroll
                     for (int i = 5; i >= 0; --i) {
                         double s = d[i];
+#pragma unroll
                         for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * d[k];
                         d[i] = s / A[i * 6 + i];
                     }

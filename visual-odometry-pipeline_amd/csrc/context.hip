@@ -118,6 +118,10 @@ int vohip_set_option(vohip_ctx *ctx, const char *name, int value)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, name, "NULL option name");
+    if (std::strcmp(name, "klt_stats") == 0) {
+        ctx->opt_klt_stats = value ? 1 : 0;
+        return VOHIP_OK;
+    }
     if (std::strcmp(name, "ransac_score_variant") == 0) {
         VOHIP_REQUIRE(ctx, value >= -1 && value <= 5, "ransac_score_variant must be -1 (auto) or 0..5");
         ctx->opt_ransac_variant = value;

@@ -17,7 +17,9 @@
 // points produce.  When the adaptive bound of the localisation asks for more hypotheses than were
 // supplied, vohip_frame_retry re-runs the context-stream part from the hypotheses onwards.
 #include "vohip_internal.h"
+#include "inlier_test.h"
 
+#include <chrono>
 #include <cmath>
 #include <new>
 
@@ -64,24 +66,24 @@ __device__ __forceinline__ int wave_sum_i(int v)
 
 // Ordered selection inside a grid of 256-thread workgroups: returns the number of flagged
 // elements before element i = blockIdx.x * 256 + threadIdx.x and, in `total`, the number of
-// flagged elements in [0, n).  Every workgroup re-reads the flags before its range (at most a few
+// flagged elements in [0, n).  Every workgroup re-evaluates the flags before its range (at most a few
 // KB, from L2), so there is no inter-workgroup hand-off and the result is deterministic.
 // All 256 threads must call it.  `sh` needs 12 ints.
 template <class Pred>
-__device__ int ordered_rank(const uint8_t *__restrict__ flags, int n, Pred pred, int &total, int *sh)
+__device__ int ordered_rank_if(int n, Pred pred, int &total, int *sh)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int first = blockIdx.x * 256;
     int before = 0, all = 0;
     for (int j = tid; j < n; j += 256) {
-        const int f = pred(flags[j]) ? 1 : 0;
+        const int f = pred(j) ? 1 : 0;
         all += f;
         before += j < first ? f : 0;
     }
     before = wave_sum_i(before);
     all = wave_sum_i(all);
     const int i = first + tid;
-    const bool mine = i < n && pred(flags[i]);
+    const bool mine = i < n && pred(i);
     const unsigned long long b = __ballot(mine);
     const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
     __syncthreads();
@@ -97,6 +99,12 @@ __device__ int ordered_rank(const uint8_t *__restrict__ flags, int n, Pred pred,
     return r;
 }
 
+template <class Pred>
+__device__ int ordered_rank(const uint8_t *__restrict__ flags, int n, Pred pred, int &total, int *sh)
+{
+    return ordered_rank_if(n, [=](int j) { return pred(flags[j]); }, total, sh);
+}
+
 struct is_set {
     __device__ bool operator()(uint8_t f) const { return f != 0; }
 };
@@ -107,6 +115,21 @@ struct is_zero {
     __device__ bool operator()(uint8_t f) const { return f == 0; }
 };
 
+// uniform draws -> 3 distinct indices in [0, n)
+__device__ __forceinline__ void triple_from_uniforms(const double *r, int n, int32_t *s)
+{
+    int a = min((int)(r[0] * (double)n), n - 1);
+    int b = min((int)(r[1] * (double)(n - 1)), n - 2);
+    int c = min((int)(r[2] * (double)(n - 2)), n - 3);
+    b += b >= a;
+    const int lo = min(a, b), hi = max(a, b);
+    c += c >= lo;
+    c += c >= hi;
+    s[0] = a;
+    s[1] = b;
+    s[2] = c;
+}
+
 // main_demo.m:380-381 + the S.X(:, validity) of :387: tracked landmarks that are still valid.
 __global__ __launch_bounds__(256) void select_tracked_kernel(const double *__restrict__ out_xy, int ld,
                                                              const uint8_t *__restrict__ valid,
@@ -114,7 +137,8 @@ __global__ __launch_bounds__(256) void select_tracked_kernel(const double *__res
                                                              const double *__restrict__ L_id, int n,
                                                              double *__restrict__ mv_rc, double *__restrict__ Xv,
                                                              double *__restrict__ idv, int *__restrict__ cnt,
-                                                             double *__restrict__ dv)
+                                                             double *__restrict__ dv, const double *__restrict__ u3,
+                                                             int h0, int32_t *__restrict__ samples)
 {
     __shared__ int sh[12];
     int total;
@@ -130,7 +154,11 @@ __global__ __launch_bounds__(256) void select_tracked_kernel(const double *__res
         Xv[3 * r + 2] = L_X[3 * i + 2];
         idv[r] = L_id[i];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[N_V] = total;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) cnt[N_V] = total;
+        // the first h0 sample triples (every thread of this workgroup knows the count already)
+        for (int k = threadIdx.x; k < h0; k += 256) triple_from_uniforms(u3 + 3 * (size_t)k, total, samples + 3 * (size_t)k);
+    }
 }
 
 // uniform draws -> index triples (3 distinct indices in [0, n)), for hypotheses [first, first + h)
@@ -139,19 +167,7 @@ __global__ __launch_bounds__(256) void triples_kernel(const double *__restrict__
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= h) return;
-    const int n = cnt[N_V];
-    const double *r = u + 3 * (size_t)(first + k);
-    int a = min((int)(r[0] * (double)n), n - 1);
-    int b = min((int)(r[1] * (double)(n - 1)), n - 2);
-    int c = min((int)(r[2] * (double)(n - 2)), n - 3);
-    b += b >= a;
-    const int lo = min(a, b), hi = max(a, b);
-    c += c >= lo;
-    c += c >= hi;
-    int32_t *s = samples + 3 * (size_t)(first + k);
-    s[0] = a;
-    s[1] = b;
-    s[2] = c;
+    triple_from_uniforms(u + 3 * (size_t)(first + k), cnt[N_V], samples + 3 * (size_t)(first + k));
 }
 
 // ransacLocalization.m:118-129
@@ -264,21 +280,27 @@ __global__ __launch_bounds__(64) void localize_decide_kernel(const int32_t *__re
     }
 }
 
-// main_demo.m:394-396: S.P, S.X restricted to the inliers; also the (u, v) copy the refinement reads.
+// main_demo.m:394-396: S.P, S.X restricted to the inliers of the winning pose (the same test,
+// operation for operation, as the scoring kernel counts with); also the (u, v) copy the refinement reads.
 __global__ __launch_bounds__(256) void select_inliers_kernel(const double *__restrict__ mv_rc,
                                                              const double *__restrict__ Xv,
                                                              const double *__restrict__ idv,
-                                                             const uint8_t *__restrict__ mask,
+                                                             const double *__restrict__ dv,
                                                              int *__restrict__ cnt, double *__restrict__ L_rc,
                                                              double *__restrict__ L_X, double *__restrict__ L_id,
                                                              double *__restrict__ kp_uv)
 {
     __shared__ int sh[12];
     const int n = cnt[N_V];
+    double m[12];   // K [R | t] of the winning hypothesis (NaN when there is none: nothing is an inlier)
+    for (int q = 0; q < 12; ++q) m[q] = dv[D_M + q];
+    auto inlier = [&](int j) {
+        return vohip_dev::is_inlier(m, Xv[3 * j], Xv[3 * j + 1], Xv[3 * j + 2], mv_rc[2 * j + 1], mv_rc[2 * j]);
+    };
     int total;
-    const int r = ordered_rank(mask, n, is_set(), total, sh);
+    const int r = ordered_rank_if(n, inlier, total, sh);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && mask[i]) {
+    if (i < n && inlier(i)) {
         const double row = mv_rc[2 * i], col = mv_rc[2 * i + 1];
         L_rc[2 * r] = row;
         L_rc[2 * r + 1] = col;
@@ -428,7 +450,7 @@ __global__ __launch_bounds__(256) void split_candidates_kernel(const uint8_t *__
                                                                const double *__restrict__ T2,
                                                                const double *__restrict__ Xnew,
                                                                int *__restrict__ cnt, double *__restrict__ dv,
-                                                               int capL, double *__restrict__ L_rc,
+                                                               int capL, int capK, double *__restrict__ L_rc,
                                                                double *__restrict__ L_X, double *__restrict__ L_id,
                                                                double *__restrict__ C_rc, double *__restrict__ F_rc,
                                                                double *__restrict__ T12)
@@ -470,10 +492,14 @@ __global__ __launch_bounds__(256) void split_candidates_kernel(const uint8_t *__
         cnt[N_C_MID] = k_stay;
         cnt[NUM_NEW] = n - k_stay;
         dv[D_IDX_NEXT] = idx0 + (double)k_new;
+        // the three counts the redundancy filter reads (update_candidate.m:12-24)
+        cnt[FILT0] = min(cnt[N_DET], capK);
+        cnt[FILT1] = k_stay;
+        cnt[FILT2] = nL + kept;
     }
 }
 
-// Fills the three counts the redundancy filter reads (update_candidate.m:12-24).
+// The same three counts for a frame without candidates (update_landmarks does not run).
 __global__ void filter_counts_kernel(int *__restrict__ cnt, int capK, int have_map, double *__restrict__ dv)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -483,12 +509,15 @@ __global__ void filter_counts_kernel(int *__restrict__ cnt, int capK, int have_m
     if (!have_map) dv[D_IDX_NEXT] = dv[D_IDX];
 }
 
-// update_candidate.m:55-57: kept detections become candidates, first seen here, under this pose.
+// update_candidate.m:55-57: kept detections become candidates, first seen here, under this pose;
+// also writes the track points of the next frame.
 __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__restrict__ corner_xy, int ld,
                                                                 const uint8_t *__restrict__ keep,
                                                                 int *__restrict__ cnt, double *__restrict__ dv,
                                                                 int capC, double *__restrict__ C_rc,
-                                                                double *__restrict__ F_rc, double *__restrict__ T12)
+                                                                double *__restrict__ F_rc, double *__restrict__ T12,
+                                                                const double *__restrict__ L_rc, int ldL,
+                                                                double *__restrict__ L_xy, double *__restrict__ C_xy)
 {
     __shared__ int sh[12];
     const int n = cnt[FILT0];
@@ -496,9 +525,20 @@ __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__r
     int total;
     const int r = ordered_rank(keep, n, is_set(), total, sh);
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // main_demo.m:417-424: the points both trackers start from in the next frame, as (x, y) columns
+    if (i < cnt[N_L_END]) {
+        L_xy[i] = L_rc[2 * i + 1];
+        L_xy[ldL + i] = L_rc[2 * i];
+    }
+    if (i < nC) {
+        C_xy[i] = C_rc[2 * i + 1];
+        C_xy[capC + i] = C_rc[2 * i];
+    }
     if (i < n && keep[i] && nC + r < capC) {
         const int d = nC + r;
         const double row = (double)corner_xy[ld + i], col = (double)corner_xy[i];
+        C_xy[d] = col;
+        C_xy[capC + d] = row;
         C_rc[2 * d] = row;
         C_rc[2 * d + 1] = col;
         F_rc[2 * d] = row;
@@ -563,6 +603,7 @@ struct vohip_frame {
     int evaluated = 0;           // hypotheses scored in the current frame
     int stage = 0;               // 0 = between frames, 1 = a frame waits for more hypotheses
     bool have_map = false;       // the frame started with candidates (update_landmarks runs)
+    std::chrono::steady_clock::time_point t_entry;   // host-side timing of the current call
 };
 
 namespace {
@@ -706,24 +747,29 @@ int enqueue_detection(vohip_frame *f, const uint8_t *d_img)
 // Localisation over hypotheses [f->evaluated, h) (ransacLocalization.m, T_refinement.m) on the
 // context's stream.  Every kernel reads only buffers an earlier run leaves intact, so it can run
 // again with more hypotheses when the adaptive bound asks for them.
-int enqueue_localize(vohip_frame *f, const double *u3, int h)
+// `ready` hypotheses at the front of the range already have their draws on the device and their
+// triples made (by the selection kernel).
+int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready)
 {
     vohip_ctx *ctx = f->ctx;
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
     const int first = f->evaluated, more = h - first;
-    std::memcpy(pin_u3(f) + 3 * (size_t)first, u3 + 3 * (size_t)first, sizeof(double) * 3 * (size_t)more);
-    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3 + 3 * (size_t)first, pin_u3(f) + 3 * (size_t)first,
-                                  sizeof(double) * 3 * (size_t)more, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more)), dim3(256), 0, s, f->u3, first, more, f->cnt, f->samples3);
+    if (ready == 0) {
+        std::memcpy(pin_u3(f) + 3 * (size_t)first, u3 + 3 * (size_t)first, sizeof(double) * 3 * (size_t)more);
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->u3 + 3 * (size_t)first, pin_u3(f) + 3 * (size_t)first,
+                                      sizeof(double) * 3 * (size_t)more, hipMemcpyHostToDevice, s));
+    }
+    if (more > ready)
+        hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more - ready)), dim3(256), 0, s, f->u3, first + ready,
+                           more - ready, f->cnt, f->samples3);
     VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
                                    f->counts4));
     f->evaluated = h;
     hipLaunchKernelGGL(localize_decide_kernel, dim3(1), dim3(64), 0, s, f->counts4, h,
                        (const double *)ctx->bufs[B_RANSAC_RT].ptr, (const double *)ctx->bufs[B_RANSAC_M].ptr, f->cnt,
                        f->dv);
-    VOHIP_TRY(vohip_ransac_mask_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->dv + D_M, f->mask));
-    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->mv_rc, f->Xv, f->idv, f->mask,
+    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->mv_rc, f->Xv, f->idv, f->dv,
                        f->cnt, f->L_rc, f->L_X, f->L_id, f->kp_uv);
     VOHIP_HIP(ctx, hipGetLastError());
     if (p.refine_pose)   // main_demo.m:398-400
@@ -745,16 +791,17 @@ int enqueue_tail(vohip_frame *f)
                                                       f->K, p.angle_threshold_deg, p.min_depth, p.max_depth, 0,
                                                       f->status, f->Xnew));
         hipLaunchKernelGGL(split_candidates_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->status, f->m2_rc, f->F2,
-                           f->T2, f->Xnew, f->cnt, f->dv, f->capL, f->L_rc, f->L_X, f->L_id, f->C_rc, f->F_rc, f->T12);
+                           f->T2, f->Xnew, f->cnt, f->dv, f->capL, f->capK, f->L_rc, f->L_X, f->L_id, f->C_rc, f->F_rc,
+                           f->T12);
+    } else {
+        hipLaunchKernelGGL(filter_counts_kernel, dim3(1), dim3(64), 0, s, f->cnt, f->capK, 0, f->dv);
     }
-    hipLaunchKernelGGL(filter_counts_kernel, dim3(1), dim3(64), 0, s, f->cnt, f->capK, f->have_map ? 1 : 0, f->dv);
     VOHIP_TRY(vohip_candidate_filter_enqueue(ctx, f->corner_xy, f->capK, f->capK, f->C_rc, f->L_rc, f->cnt + FILT0,
                                              p.r_discard_redundant, f->keep));
-    hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s, f->corner_xy, f->capK,
-                       f->keep, f->cnt, f->dv, f->capC, f->C_rc, f->F_rc, f->T12);
-    const int nmax = f->capL > f->capC ? f->capL : f->capC;
-    hipLaunchKernelGGL(next_tracks_kernel, dim3(blocks256(nmax)), dim3(256), 0, s, f->L_rc, f->capL, f->L_xy, f->C_rc,
-                       f->capC, f->C_xy, f->cnt);
+    int nmax = f->capL > f->capC ? f->capL : f->capC;
+    nmax = nmax > f->capK ? nmax : f->capK;
+    hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(nmax)), dim3(256), 0, s, f->corner_xy, f->capK, f->keep,
+                       f->cnt, f->dv, f->capC, f->C_rc, f->F_rc, f->T12, f->L_rc, f->capL, f->L_xy, f->C_xy);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
@@ -763,7 +810,9 @@ int enqueue_tail(vohip_frame *f)
 int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_counts *out)
 {
     vohip_ctx *ctx = f->ctx;
+    const auto t_enq = std::chrono::steady_clock::now();
     VOHIP_TRY(fetch_summary(f));
+    const auto t_done = std::chrono::steady_clock::now();
     const int *hc = pin_cnt(f);
     const double *hd = pin_dv(f);
     std::memset(pose, 0, sizeof(*pose));
@@ -791,6 +840,8 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     out->n_candidates_inliers = f->have_map ? hc[N_CI] : 0;
     out->fm_trials_run = f->have_map ? hc[F_TRIALS] : 0;
     out->overflow = hc[OVERFLOW];
+    out->host_enqueue_us = std::chrono::duration<double, std::micro>(t_enq - f->t_entry).count();
+    out->host_wait_us = std::chrono::duration<double, std::micro>(t_done - t_enq).count();
     const int t = f->slot_prev;   // main_demo.m:417-424: this frame's pyramid is the next "previous"
     f->slot_prev = f->slot_cur;
     f->slot_cur = t;
@@ -987,6 +1038,7 @@ int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, 
     VOHIP_REQUIRE(ctx, f->stage == 0, "a frame is still waiting for vohip_frame_retry");
     VOHIP_REQUIRE(ctx, h >= 1 && h <= f->hmax, "hypothesis count outside 1..max_hypotheses");
     VOHIP_REQUIRE(ctx, f->n_C == 0 || u8, "candidates exist: the fundamental-matrix draws are needed");
+    f->t_entry = std::chrono::steady_clock::now();
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
@@ -1002,16 +1054,20 @@ int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, 
     // landmark tracker -> localisation) is fed first at every step, the two long trackers start
     // as early as possible, the short kernels of the other streams are enqueued while they run.
     VOHIP_HIP(ctx, hipEventRecord(f->ev_img, s));
+    // the localisation draws go up first: they are needed right after the tracker
+    std::memcpy(pin_u3(f), u3, sizeof(double) * 3 * (size_t)h);
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3, pin_u3(f), sizeof(double) * 3 * (size_t)h, hipMemcpyHostToDevice, s));
     VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
     VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));
     // landmark tracker (main_demo.m:380) and the selection of the valid tracks (:381, :387)
     VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->L_xy, f->capL, f->n_L, nullptr, p.klt_block,
                                 p.klt_max_iter, p.klt_max_bidir_error, f->kL_out, f->kL_valid, nullptr));
     VOHIP_TRY(enqueue_side_track(f));
+    const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
     hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->kL_out, f->capL, f->kL_valid,
-                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->cnt, f->dv);
+                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->cnt, f->dv, f->u3, h0, f->samples3);
     VOHIP_HIP(ctx, hipGetLastError());
-    VOHIP_TRY(enqueue_localize(f, u3, h));
+    VOHIP_TRY(enqueue_localize(f, u3, h, h0));
     VOHIP_TRY(enqueue_detection(f, d_img));
     VOHIP_TRY(enqueue_side_filter(f, u8));
     VOHIP_TRY(enqueue_tail(f));
@@ -1025,8 +1081,9 @@ int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose 
     VOHIP_REQUIRE(ctx, u3 && pose && counts, "NULL argument");
     VOHIP_REQUIRE(ctx, f->stage == 1, "no frame is waiting for more hypotheses");
     VOHIP_REQUIRE(ctx, h > f->evaluated && h <= f->hmax, "hypothesis count must grow and stay within max_hypotheses");
+    f->t_entry = std::chrono::steady_clock::now();
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
-    VOHIP_TRY(enqueue_localize(f, u3, h));
+    VOHIP_TRY(enqueue_localize(f, u3, h, 0));
     VOHIP_TRY(enqueue_tail(f));
     return complete_frame(f, h, pose, counts);
 }

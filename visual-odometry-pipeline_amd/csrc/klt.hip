@@ -207,20 +207,27 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                     __syncthreads();
                 }
                 const float *org = sJ + (jb - cjb + C::MARG) * C::SJ + (ja - cja + C::MARG);
-                // per-lane partial sums in fp32 (at most PER_LANE fused multiply-adds, fixed order),
-                // widened to fp64 for the reduction across the wavefront
-                float baf = 0.f, bbf = 0.f;
+                // all LDS reads first, so that their latencies overlap
+                float c00[C::PER_LANE], c01[C::PER_LANE], c10[C::PER_LANE], c11[C::PER_LANE];
 #pragma unroll
                 for (int k = 0; k < C::PER_LANE; ++k) {
                     const float *p = org + offJ[k];
-                    const float j = bilerp(p[0], p[1], p[C::SJ], p[C::SJ + 1], ga, gb);
+                    c00[k] = p[0];
+                    c01[k] = p[1];
+                    c10[k] = p[C::SJ];
+                    c11[k] = p[C::SJ + 1];
+                }
+                // per-lane partial sums in fp32 (at most PER_LANE fused multiply-adds, fixed order),
+                // then a fixed fp32 tree across the wavefront
+                float baf = 0.f, bbf = 0.f;
+#pragma unroll
+                for (int k = 0; k < C::PER_LANE; ++k) {
+                    const float j = bilerp(c00[k], c01[k], c10[k], c11[k], ga, gb);
                     const float e = T[k] - j;
                     baf = __builtin_fmaf(e, GX[k], baf);
                     bbf = __builtin_fmaf(e, GY[k], bbf);
                 }
-                double ba = (double)baf, bb = (double)bbf;
-                ba = wave_sum(ba);
-                bb = wave_sum(bb);
+                const double ba = (double)vohip_dev::wave_sum_f32(baf), bb = (double)vohip_dev::wave_sum_f32(bbf);
                 const double sa = (gyy * ba - gxy * bb) * inv_det;
                 const double sb = (gxx * bb - gxy * ba) * inv_det;
                 da += sa;
@@ -390,12 +397,13 @@ int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double 
     VOHIP_REQUIRE(ctx, pp.rows == pq.rows && pp.cols == pq.cols && pp.colmajor == pq.colmajor && pp.levels == pq.levels,
                   "previous and current pyramids differ in shape");
     const int swap_xy = pp.colmajor;
-    if (!ctx->bufs[B_KLT_STATS].ptr) {
+    // the work counters cost two same-address atomics per track: only on request
+    if (ctx->opt_klt_stats && !ctx->bufs[B_KLT_STATS].ptr) {
         VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_KLT_STATS], 64));
         VOHIP_HIP(ctx, hipMemsetAsync(ctx->bufs[B_KLT_STATS].ptr, 0, 64, ctx->stream));
         VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    unsigned long long *d_stats = (unsigned long long *)ctx->bufs[B_KLT_STATS].ptr;
+    unsigned long long *d_stats = ctx->opt_klt_stats ? (unsigned long long *)ctx->bufs[B_KLT_STATS].ptr : nullptr;
     if (block_size == 21)
         hipLaunchKernelGGL(klt_track_kernel<21>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, d_n, ld,
                            swap_xy, max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err, d_stats);

@@ -24,6 +24,7 @@
 // per-hypothesis inlier counts; it is replayed on the host in sample order after each chunk
 // of hypotheses, so hypotheses past the stop index never influence the result.
 #include "vohip_internal.h"
+#include "inlier_test.h"
 
 #include <cmath>
 #include <vector>
@@ -355,18 +356,7 @@ __global__ __launch_bounds__(64) void p3p_batch_kernel(const double *__restrict_
 // Inlier test, shared by the scoring and the mask kernels so that popcount(mask) == count.
 // m = K [R | t] row-major 3x4.  13 FMA + 2 MUL + 1 CMP.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool is_inlier(const double m[12], double X, double Y, double Z, double u,
-                                          double v)
-{
-    const double x = __builtin_fma(m[0], X, __builtin_fma(m[1], Y, __builtin_fma(m[2], Z, m[3])));
-    const double y = __builtin_fma(m[4], X, __builtin_fma(m[5], Y, __builtin_fma(m[6], Z, m[7])));
-    const double z = __builtin_fma(m[8], X, __builtin_fma(m[9], Y, __builtin_fma(m[10], Z, m[11])));
-    const double dx = __builtin_fma(-u, z, x);
-    const double dy = __builtin_fma(-v, z, y);
-    const double e = __builtin_fma(dy, dy, dx * dx);
-    const double zz = z * z;
-    return __builtin_fma(-100.0, zz, e) < 0.0;  // pixel_tolerance^2 = 100, strict
-}
+using vohip_dev::is_inlier;   // inlier_test.h
 
 // Inlier test with the 9 rotation-part coefficients as wave-uniform scalars (SGPR operands of
 // v_fma_f64: one scalar operand per VALU instruction is free) and the 3 translation-part

@@ -57,6 +57,7 @@ struct vohip_ctx {
     vohip_pyramid pyr[VOHIP_PYR_SLOTS];
     int ransac_h = 0;  // hypotheses held by B_RANSAC_RT / B_RANSAC_M
     int opt_ransac_variant = -1;  // scoring-kernel geometry, see vohip_set_option
+    int opt_klt_stats = 0;        // count tracker work (two atomics per track), see vohip_klt_stats
 };
 
 int vohip_fail(vohip_ctx *ctx, int status, const char *fmt, ...);

@@ -25,6 +25,37 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+template <int CTRL>
+__device__ __forceinline__ float dpp_add_f32(float v)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return v + __int_as_float(t);
+}
+
+// Wave-wide fp32 sum in a fixed tree: fours, pairs of fours, pairs of eights (DPP within each row
+// of 16 lanes), then the four row sums as ((r0 + r1) + r2) + r3.  Every lane receives the same bits.
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    v = dpp_add_f32<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add_f32<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add_f32<0x141>(v);   // row_half_mirror
+    v = dpp_add_f32<0x140>(v);   // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return ((r0 + r1) + r2) + r3;
+}
+
+// Sum over each aligned group of 8 lanes (every lane of the group receives it): three DPP steps.
+__device__ __forceinline__ double group8_sum_f64(double v)
+{
+    v += dpp_move_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move_f64<0x141>(v);  // row_half_mirror
+    return v;
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
     v += dpp_move_f64<0xB1>(v);   // quad_perm [1,0,3,2]
