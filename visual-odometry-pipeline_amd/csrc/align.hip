@@ -165,36 +165,44 @@ __global__ __launch_bounds__(AL_THREADS) void align_sim3_kernel(const double *__
         while (!accepted && !stop) {
             __syncthreads();
             if (tid == 0) {
+                // 7x7 Cholesky with every loop unrolled, so that A and d stay in registers
                 double A[NP * NP], d[NP];
+#pragma unroll
                 for (int q = 0; q < NP * NP; ++q) A[q] = sH[q];
+#pragma unroll
                 for (int a = 0; a < NP; ++a) {
                     A[(NP + 1) * a] *= 1.0 + lambda;
                     d[a] = -sG[a];
                 }
                 int ok = 1;
-                for (int j = 0; j < NP && ok; ++j) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
                     double dd = A[j * NP + j];
+#pragma unroll
                     for (int k = 0; k < j; ++k) dd -= A[j * NP + k] * A[j * NP + k];
-                    if (!(dd > 0.0)) {
-                        ok = 0;
-                        break;
-                    }
+                    if (!(dd > 0.0)) ok = 0;
                     dd = sqrt(dd);
                     A[j * NP + j] = dd;
+#pragma unroll
                     for (int i = j + 1; i < NP; ++i) {
                         double s = A[i * NP + j];
+#pragma unroll
                         for (int k = 0; k < j; ++k) s -= A[i * NP + k] * A[j * NP + k];
                         A[i * NP + j] = s / dd;
                     }
                 }
                 if (ok) {
+#pragma unroll
                     for (int i = 0; i < NP; ++i) {
                         double s = d[i];
+#pragma unroll
                         for (int k = 0; k < i; ++k) s -= A[i * NP + k] * d[k];
                         d[i] = s / A[i * NP + i];
                     }
+#pragma unroll
                     for (int i = NP - 1; i >= 0; --i) {
                         double s = d[i];
+#pragma unroll
                         for (int k = i + 1; k < NP; ++k) s -= A[k * NP + i] * d[k];
                         d[i] = s / A[i * NP + i];
                     }

@@ -10,7 +10,7 @@
 //   the largest count; trial budget shrinks to ceil(log(1-c)/log(1-(inl/n)^8)) after each
 //   improvement (c = Confidence / 100; the toolbox default is 99).
 // Kernels: fm_normalise_kernel (one workgroup, two block reductions), fm_solve_kernel (one
-// thread per trial), fm_count_kernel (one wavefront per trial, ballot/popcount), fm_mask_kernel.
+// group of 8 lanes per trial), fm_count_kernel (one wavefront per trial, ballot/popcount), fm_mask_kernel.
 #include "vohip_internal.h"
 
 #include <cmath>
@@ -70,54 +70,96 @@ __global__ __launch_bounds__(256) void fm_normalise_kernel(const double *__restr
     }
 }
 
-__device__ bool null9(double A[8][9], double x[9])
+// Null vector of the 8x9 system of one trial by Gaussian elimination with complete pivoting, done
+// by a group of 8 lanes (lane g owns row g) on a matrix that lives in LDS (the pivot search indexes it
+// with data-dependent rows and columns, which registers cannot do).  The operations on every
+// element are those of the one-thread formulation, in the same order.  All 64 lanes of the
+// wavefront must call it (8 trials per wavefront); `A` is this group's 72 doubles, `perm` its 9
+// ints.  Returns false for a singular system.  x (unit norm) is valid in every lane.
+__device__ bool null9_group8(double *A, int *perm, double x[9])
 {
-    int perm[9];
-    for (int c = 0; c < 9; ++c) perm[c] = c;
+    const int g = threadIdx.x & 7;
+    bool ok = true;
+    if (g == 0)
+        for (int c = 0; c < 9; ++c) perm[c] = c;
     for (int k = 0; k < 8; ++k) {
-        int pr = k, pc = k;
-        double best = 0.0;
-        for (int r = k; r < 8; ++r)
-            for (int c = k; c < 9; ++c)
-                if (fabs(A[r][c]) > best) {
-                    best = fabs(A[r][c]);
-                    pr = r;
-                    pc = c;
+        __syncthreads();
+        // pivot search: largest |A[r][c]| over r, c >= k; the first one in row-major order wins ties
+        double best = -1.0;
+        int rc = 0;
+        if (g >= k) {
+            best = 0.0;
+            rc = 16 * g + k;
+            for (int c = k; c < 9; ++c) {
+                const double v = fabs(A[g * 9 + c]);
+                if (v > best) {
+                    best = v;
+                    rc = 16 * g + c;
                 }
-        if (!(best > 0.0)) return false;
-        if (pr != k)
-            for (int c = 0; c < 9; ++c) {
-                const double t = A[k][c];
-                A[k][c] = A[pr][c];
-                A[pr][c] = t;
             }
-        if (pc != k) {
-            for (int r = 0; r < 8; ++r) {
-                const double t = A[r][k];
-                A[r][k] = A[r][pc];
-                A[r][pc] = t;
-            }
-            const int t = perm[k];
-            perm[k] = perm[pc];
-            perm[pc] = t;
         }
-        for (int r = k + 1; r < 8; ++r) {
-            const double f = A[r][k] / A[k][k];
-            for (int c = k; c < 9; ++c) A[r][c] -= f * A[k][c];
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            const double ob = __shfl_xor(best, m, 8);
+            const int orc = __shfl_xor(rc, m, 8);
+            if (ob > best || (ob == best && orc < rc)) {
+                best = ob;
+                rc = orc;
+            }
+        }
+        if (!(best > 0.0)) ok = false;   // keep going on garbage: the wavefront stays uniform
+        const int pr = rc >> 4, pc = rc & 15;
+        __syncthreads();
+        if (pr != k) {   // row swap, lane g takes column g (lane 0 also column 8)
+            const double t = A[k * 9 + g];
+            A[k * 9 + g] = A[pr * 9 + g];
+            A[pr * 9 + g] = t;
+            if (g == 0) {
+                const double u = A[k * 9 + 8];
+                A[k * 9 + 8] = A[pr * 9 + 8];
+                A[pr * 9 + 8] = u;
+            }
+        }
+        __syncthreads();
+        if (pc != k) {   // column swap, lane g takes row g
+            const double t = A[g * 9 + k];
+            A[g * 9 + k] = A[g * 9 + pc];
+            A[g * 9 + pc] = t;
+            if (g == 0) {
+                const int u = perm[k];
+                perm[k] = perm[pc];
+                perm[pc] = u;
+            }
+        }
+        __syncthreads();
+        if (g > k) {
+            const double f = A[g * 9 + k] / A[k * 9 + k];
+            for (int c = k; c < 9; ++c) A[g * 9 + c] -= f * A[k * 9 + c];
         }
     }
+    __syncthreads();
     double y[9];
     y[8] = 1.0;
+#pragma unroll
     for (int k = 7; k >= 0; --k) {
         double s = 0.0;
-        for (int c = k + 1; c < 9; ++c) s += A[k][c] * y[c];
-        y[k] = -s / A[k][k];
+#pragma unroll
+        for (int c = k + 1; c < 9; ++c) s += A[k * 9 + c] * y[c];
+        y[k] = -s / A[k * 9 + k];
     }
     double nn = 0.0;
+#pragma unroll
     for (int c = 0; c < 9; ++c) nn += y[c] * y[c];
     nn = sqrt(nn);
-    for (int c = 0; c < 9; ++c) x[perm[c]] = y[c] / nn;
-    return true;
+    __syncthreads();
+    // un-permute through LDS (row 0 of the matrix is no longer needed)
+    if (g == 0)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) A[perm[c]] = y[c] / nn;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 9; ++c) x[c] = A[c];
+    return ok;
 }
 
 __device__ void rank2(double F[3][3])
@@ -165,38 +207,47 @@ __device__ void rank2(double F[3][3])
         }
 }
 
-// One thread per trial; F_out[t] row-major 3x3 (all zeros for a degenerate sample).
+// Eight lanes per trial (eight trials per wavefront); F_out[t] row-major 3x3 (all zeros for a
+// degenerate sample).
 __global__ __launch_bounds__(64) void fm_solve_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
                                                       int n, const int *__restrict__ n_dev,
                                                       const int32_t *__restrict__ samples, int trials,
                                                       const double *__restrict__ nrm, double *__restrict__ F_out)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= trials) return;
+    __shared__ double sA[8][72];
+    __shared__ int sP[8][9];
+    const int g = threadIdx.x & 7, slot = threadIdx.x >> 3;
+    const int t_raw = blockIdx.x * 8 + slot;
+    const int t = t_raw < trials ? t_raw : trials - 1;   // surplus groups redo the last trial, no store
     if (n_dev) n = *n_dev;
     const double s1 = nrm[0], cx1 = nrm[1], cy1 = nrm[2], s2 = nrm[3], cx2 = nrm[4], cy2 = nrm[5];
-    double A[8][9];
+    double *A = sA[slot];
     bool ok = true;
-    for (int r = 0; r < 8; ++r) {
-        int i = samples[8 * (size_t)t + r];
+    {   // lane g builds row g
+        int i = samples[8 * (size_t)t + g];
         if (i < 0 || i >= n) {
             ok = false;
             i = 0;
         }
         const double x1 = s1 * (p1[2 * i] - cx1), y1 = s1 * (p1[2 * i + 1] - cy1);
         const double x2 = s2 * (p2[2 * i] - cx2), y2 = s2 * (p2[2 * i + 1] - cy2);
-        A[r][0] = x2 * x1;
-        A[r][1] = x2 * y1;
-        A[r][2] = x2;
-        A[r][3] = y2 * x1;
-        A[r][4] = y2 * y1;
-        A[r][5] = y2;
-        A[r][6] = x1;
-        A[r][7] = y1;
-        A[r][8] = 1.0;
+        double *row = A + 9 * g;
+        row[0] = x2 * x1;
+        row[1] = x2 * y1;
+        row[2] = x2;
+        row[3] = y2 * x1;
+        row[4] = y2 * y1;
+        row[5] = y2;
+        row[6] = x1;
+        row[7] = y1;
+        row[8] = 1.0;
     }
+    // a bad index in any of the 8 rows invalidates the trial
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) ok = ok && (__shfl_xor(ok ? 1 : 0, m, 8) != 0);
     double f[9];
-    ok = ok && null9(A, f);
+    ok = null9_group8(A, sP[slot], f) && ok;
+    if (g != 0 || t_raw >= trials) return;
     double F[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (ok) {
         double Fh[3][3] = {{f[0], f[1], f[2]}, {f[3], f[4], f[5]}, {f[6], f[7], f[8]}};
@@ -279,7 +330,7 @@ int vohip_fm_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int
 {
     hipStream_t s = ctx->stream;
     hipLaunchKernelGGL(fm_normalise_kernel, dim3(1), dim3(256), 0, s, d_p1, d_p2, n, d_n, d_nrm);
-    hipLaunchKernelGGL(fm_solve_kernel, dim3((num_trials + 63) / 64), dim3(64), 0, s, d_p1, d_p2, n, d_n, d_samples,
+    hipLaunchKernelGGL(fm_solve_kernel, dim3((num_trials + 7) / 8), dim3(64), 0, s, d_p1, d_p2, n, d_n, d_samples,
                        num_trials, (const double *)d_nrm, d_F);
     hipLaunchKernelGGL(fm_count_kernel, dim3((num_trials + 3) / 4), dim3(256), 0, s, d_p1, d_p2, n, d_n,
                        (const double *)d_F, num_trials, threshold, d_counts);

@@ -3,14 +3,14 @@
 // Restates main_demo.m:377-427 with is_BA = false -- detection (genKeypoints.m), the landmark
 // tracker, ransacLocalization.m, T_refinement.m, update_landmarks.m, update_candidate.m and the
 // tracker re-initialisation -- as ONE call and ONE synchronisation per frame (vohip_frame_step):
-//   context stream  image pyramid -> landmark tracking -> ordered selection -> P3P hypotheses from
-//                   the caller's uniform draws -> scoring -> the adaptive stopping rule replayed by
-//                   one wavefront -> inlier selection -> pose refinement -> [join] -> triangulation
-//                   of the filtered candidates -> landmark append -> redundancy filter ->
-//                   candidate append -> next frame's track points
-//   second stream   (after the pyramid) candidate tracking -> ordered selection -> fundamental-matrix
-//                   RANSAC from the caller's second set of draws -> inlier selection; corner
-//                   detection
+//   context stream  image pyramid -> landmark AND candidate tracking (one launch) -> ordered selection
+//                   (+ sample triples from the caller's uniform draws) -> P3P solve -> scoring -> the
+//                   adaptive stopping rule replayed by one wavefront -> inlier selection -> pose
+//                   refinement -> [join] -> triangulation of the filtered candidates -> landmark
+//                   append -> redundancy filter -> candidate append + next frame's track points
+//   second stream   (after the trackers) ordered selection of the tracked candidates ->
+//                   fundamental-matrix RANSAC from the caller's second set of draws -> inlier selection
+//   third stream    (after the image) corner detection
 // S.P, S.X, S.C, S.F, S.T never leave the device; every count between the stages stays in device
 // memory (kernels are launched over capacity-sized grids and read the count themselves), and
 // selections are ordered, so the state is element for element the one the stage-by-stage entry
@@ -21,6 +21,7 @@
 
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 namespace {
@@ -587,6 +588,8 @@ struct vohip_frame {
     int capL = 0, capC = 0, capK = 0, hmax = 0;
     hipStream_t side = nullptr, side2 = nullptr;
     hipEvent_t ev_pyr = nullptr, ev_side = nullptr, ev_det = nullptr, ev_img = nullptr;
+    hipEvent_t tr[8] = {nullptr};   // timing events of the trace option
+    bool trace = false;
     void *block = nullptr;       // one device allocation, carved up below
     void *pinned = nullptr;      // host mirror of the counters and doubles
     uint8_t *img = nullptr;      // image staging (host images)
@@ -689,21 +692,8 @@ int fetch_summary(vohip_frame *f)
     return VOHIP_OK;
 }
 
-// Second stream, part 1: the candidate tracker (update_landmarks.m:10), the long pole of that stream.
-int enqueue_side_track(vohip_frame *f)
-{
-    vohip_ctx *ctx = f->ctx;
-    const vohip_frame_params &p = f->prm;
-    stream_swap sw(ctx, f->side);
-    VOHIP_HIP(ctx, hipStreamWaitEvent(f->side, f->ev_pyr, 0));
-    if (f->have_map)
-        VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->C_xy, f->capC, f->n_C, nullptr, p.klt_block,
-                                    p.klt_max_iter, p.klt_max_bidir_error, f->kC_out, f->kC_valid, nullptr));
-    return VOHIP_OK;
-}
-
-// Second stream, part 2: the epipolar filter over the candidate tracks (update_landmarks.m:11-25),
-// which needs neither the new pose nor the localisation draws.
+// Second stream, after the trackers: the epipolar filter over the candidate tracks
+// (update_landmarks.m:11-25), which needs neither the new pose nor the localisation draws.
 int enqueue_side_filter(vohip_frame *f, const double *u8)
 {
     vohip_ctx *ctx = f->ctx;
@@ -711,6 +701,8 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
     const int T = p.fm_trials;
     stream_swap sw(ctx, f->side);
     hipStream_t s = f->side;
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_pyr, 0));
+    if (f->trace) (void)hipEventRecord(f->tr[3], s);
     if (f->have_map) {
         std::memcpy(pin_u8(f), u8, sizeof(double) * 8 * (size_t)T);
         VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, pin_u8(f), sizeof(double) * 8 * (size_t)T, hipMemcpyHostToDevice, s));
@@ -728,6 +720,7 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
         VOHIP_HIP(ctx, hipGetLastError());
     }
     VOHIP_HIP(ctx, hipEventRecord(f->ev_side, s));
+    if (f->trace) (void)hipEventRecord(f->tr[4], s);   // epipolar filter done
     return VOHIP_OK;
 }
 
@@ -741,6 +734,7 @@ int enqueue_detection(vohip_frame *f, const uint8_t *d_img)
     VOHIP_TRY(vohip_detect_corners_dev(ctx, d_img, f->rows, f->cols, f->colmajor, p.min_quality, p.filter_size, p.border,
                                        p.detector, f->corner_xy, f->corner_metric, f->capK, f->cnt + N_DET));
     VOHIP_HIP(ctx, hipEventRecord(f->ev_det, f->side2));
+    if (f->trace) (void)hipEventRecord(f->tr[5], f->side2);   // detection done
     return VOHIP_OK;
 }
 
@@ -803,6 +797,7 @@ int enqueue_tail(vohip_frame *f)
     hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(nmax)), dim3(256), 0, s, f->corner_xy, f->capK, f->keep,
                        f->cnt, f->dv, f->capC, f->C_rc, f->F_rc, f->T12, f->L_rc, f->capL, f->L_xy, f->C_xy);
     VOHIP_HIP(ctx, hipGetLastError());
+    if (f->trace) (void)hipEventRecord(f->tr[6], s);   // tail done
     return VOHIP_OK;
 }
 
@@ -842,6 +837,12 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     out->overflow = hc[OVERFLOW];
     out->host_enqueue_us = std::chrono::duration<double, std::micro>(t_enq - f->t_entry).count();
     out->host_wait_us = std::chrono::duration<double, std::micro>(t_done - t_enq).count();
+    if (f->trace) {
+        float ms[7] = {0};
+        for (int q = 1; q < 7; ++q) (void)hipEventElapsedTime(&ms[q], f->tr[0], f->tr[q]);
+        std::fprintf(stderr, "vohip frame trace (us from start): klt_L %.0f  refined %.0f  klt_C %.0f  filter %.0f  detect %.0f  tail %.0f | host enqueue %.0f wait %.0f\n",
+                     1e3 * ms[1], 1e3 * ms[2], 1e3 * ms[3], 1e3 * ms[4], 1e3 * ms[5], 1e3 * ms[6], out->host_enqueue_us, out->host_wait_us);
+    }
     const int t = f->slot_prev;   // main_demo.m:417-424: this frame's pyramid is the next "previous"
     f->slot_prev = f->slot_cur;
     f->slot_cur = t;
@@ -939,6 +940,10 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
         return vohip_fail(ctx, VOHIP_ERR_HIP, "frame state allocation failed: %s", hipGetErrorString(e));
     }
     layout(f, (char *)f->block);
+    if (std::getenv("VOHIP_FRAME_TRACE")) {   // per-stage GPU timeline of every frame, for tuning
+        f->trace = true;
+        for (int q = 0; q < 8; ++q) (void)hipEventCreate(&f->tr[q]);
+    }
     // the pose buffers of the hypothesis solver must hold every hypothesis of a frame
     int st = vohip_reserve(ctx, ctx->bufs[B_RANSAC_RT], (size_t)f->hmax * 48 * sizeof(double));
     if (st == VOHIP_OK) st = vohip_reserve(ctx, ctx->bufs[B_RANSAC_M], (size_t)f->hmax * 48 * sizeof(double));
@@ -965,6 +970,8 @@ int vohip_frame_destroy(vohip_frame *f)
     if (f->ev_det) (void)hipEventDestroy(f->ev_det);
     if (f->ctx) (void)hipStreamSynchronize(f->ctx->stream);
     if (f->ev_pyr) (void)hipEventDestroy(f->ev_pyr);
+    for (int q = 0; q < 8; ++q)
+        if (f->tr[q]) (void)hipEventDestroy(f->tr[q]);
     if (f->ev_side) (void)hipEventDestroy(f->ev_side);
     if (f->ev_img) (void)hipEventDestroy(f->ev_img);
     if (f->block) (void)hipFree(f->block);
@@ -1053,21 +1060,26 @@ int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, 
     // The order of the enqueues follows the critical path: the context's stream (pyramid ->
     // landmark tracker -> localisation) is fed first at every step, the two long trackers start
     // as early as possible, the short kernels of the other streams are enqueued while they run.
+    if (f->trace) (void)hipEventRecord(f->tr[0], s);
     VOHIP_HIP(ctx, hipEventRecord(f->ev_img, s));
     // the localisation draws go up first: they are needed right after the tracker
     std::memcpy(pin_u3(f), u3, sizeof(double) * 3 * (size_t)h);
     VOHIP_HIP(ctx, hipMemcpyAsync(f->u3, pin_u3(f), sizeof(double) * 3 * (size_t)h, hipMemcpyHostToDevice, s));
     VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
-    VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));
     // landmark tracker (main_demo.m:380) and the selection of the valid tracks (:381, :387)
-    VOHIP_TRY(vohip_klt_enqueue(ctx, f->slot_prev, f->slot_cur, f->L_xy, f->capL, f->n_L, nullptr, p.klt_block,
-                                p.klt_max_iter, p.klt_max_bidir_error, f->kL_out, f->kL_valid, nullptr));
-    VOHIP_TRY(enqueue_side_track(f));
+    // and the candidate tracker (update_landmarks.m:10) in the same launch: same two images, and a
+    // launch of this kernel lasts as long as its slowest track however many tracks it carries
+    VOHIP_TRY(vohip_klt_enqueue2(ctx, f->slot_prev, f->slot_cur, f->L_xy, f->capL, f->n_L, nullptr, f->kL_out,
+                                 f->kL_valid, nullptr, f->C_xy, f->capC, f->have_map ? f->n_C : 0, f->kC_out,
+                                 f->kC_valid, p.klt_block, p.klt_max_iter, p.klt_max_bidir_error));
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));      // the second stream starts from here
+    if (f->trace) (void)hipEventRecord(f->tr[1], s);   // trackers done
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
     hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->kL_out, f->capL, f->kL_valid,
                        f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->cnt, f->dv, f->u3, h0, f->samples3);
     VOHIP_HIP(ctx, hipGetLastError());
     VOHIP_TRY(enqueue_localize(f, u3, h, h0));
+    if (f->trace) (void)hipEventRecord(f->tr[2], s);   // pose refined
     VOHIP_TRY(enqueue_detection(f, d_img));
     VOHIP_TRY(enqueue_side_filter(f, u8));
     VOHIP_TRY(enqueue_tail(f));

@@ -259,19 +259,35 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
 // pts_xy / out_xy: x column then y column with leading dimension ld, MATLAB's (x, y), 1-based.
 // swap_xy: the image is a column-major MATLAB image, so a = y - 1, b = x - 1; otherwise a = x - 1,
 // b = y - 1.  The point count is n, or *n_dev when n_dev is given (n then only sizes the grid).
+// A launch can carry a second, independent point set (the frame pipeline tracks landmarks and
+// candidates between the same two images in one launch): workgroups past the first set serve it.
+struct klt_set {
+    const double *pts_xy;
+    double *out_xy;
+    uint8_t *valid;
+    double *fb_err;
+    int ld, n;
+};
+
 template <int W>
-__global__ __launch_bounds__(64) void klt_track_kernel(pyr_desc P, pyr_desc Q, const double *__restrict__ pts_xy,
-                                                       int n, const int *__restrict__ n_dev, int ld, int swap_xy,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 21 ? 3 : 2, W <= 21 ? 3 : 2))) void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_set S0, klt_set S1,
+                                                       const int *__restrict__ n_dev, int swap_xy,
                                                        int max_iter, double max_bidir,
-                                                       double *__restrict__ out_xy, uint8_t *__restrict__ valid,
-                                                       double *__restrict__ fb_err,
                                                        unsigned long long *__restrict__ stats)
 {
     using C = klt_cfg<W>;
     __shared__ float sI[C::SI * C::SI];
     __shared__ float sJ[C::SJ * C::SJ];
-    const int i = blockIdx.x;
-    if (n_dev) n = *n_dev;
+    int i = blockIdx.x;
+    const bool second = i >= S0.n;
+    if (second) i -= S0.n;
+    const double *__restrict__ pts_xy = second ? S1.pts_xy : S0.pts_xy;
+    double *__restrict__ out_xy = second ? S1.out_xy : S0.out_xy;
+    uint8_t *__restrict__ valid = second ? S1.valid : S0.valid;
+    double *__restrict__ fb_err = second ? S1.fb_err : S0.fb_err;
+    const int ld = second ? S1.ld : S0.ld;
+    int n = second ? S1.n : S0.n;
+    if (n_dev && !second) n = *n_dev;
     if (i >= n) return;
     const double x = pts_xy[i] - 1.0, y = pts_xy[ld + i] - 1.0;
     const double pa = swap_xy ? y : x, pb = swap_xy ? x : y;
@@ -386,10 +402,23 @@ int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double 
                       const int *d_n, int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
                       uint8_t *d_valid, double *d_fb_err)
 {
+    return vohip_klt_enqueue2(ctx, slot_prev, slot_cur, d_pts_xy, ld, n, d_n, d_out_xy, d_valid, d_fb_err, nullptr, 0, 0,
+                              nullptr, nullptr, block_size, max_iter, max_bidir_error);
+}
+
+int vohip_klt_enqueue2(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int ld, int n,
+                       const int *d_n, double *d_out_xy, uint8_t *d_valid, double *d_fb_err, const double *d_pts2,
+                       int ld2, int n2, double *d_out2, uint8_t *d_valid2, int block_size, int max_iter,
+                       double max_bidir_error)
+{
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
-    VOHIP_REQUIRE(ctx, n >= 0 && max_iter >= 1 && ld >= n, "bad argument");
-    if (n == 0) return VOHIP_OK;
-    VOHIP_REQUIRE(ctx, d_pts_xy && d_out_xy && d_valid, "NULL array");
+    VOHIP_REQUIRE(ctx, n >= 0 && n2 >= 0 && max_iter >= 1 && ld >= n && ld2 >= n2, "bad argument");
+    if (n + n2 == 0) return VOHIP_OK;
+    VOHIP_REQUIRE(ctx, (n == 0 || (d_pts_xy && d_out_xy && d_valid)) && (n2 == 0 || (d_pts2 && d_out2 && d_valid2)),
+                  "NULL array");
+    VOHIP_REQUIRE(ctx, !(d_n && n2 > 0), "a device-side count cannot be combined with a second point set");
+    const klt_set S0 = {d_pts_xy, d_out_xy, d_valid, d_fb_err, ld, n};
+    const klt_set S1 = {d_pts2, d_out2, d_valid2, nullptr, ld2, n2};
     pyr_desc P, Q;
     VOHIP_TRY(vohip_pyramid_desc(ctx, slot_prev, P));
     VOHIP_TRY(vohip_pyramid_desc(ctx, slot_cur, Q));
@@ -405,11 +434,11 @@ int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double 
     }
     unsigned long long *d_stats = ctx->opt_klt_stats ? (unsigned long long *)ctx->bufs[B_KLT_STATS].ptr : nullptr;
     if (block_size == 21)
-        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, d_n, ld,
-                           swap_xy, max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err, d_stats);
+        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(n + n2), dim3(64), 0, ctx->stream, P, Q, S0, S1, d_n, swap_xy,
+                           max_iter, max_bidir_error, d_stats);
     else if (block_size == 31)
-        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(n), dim3(64), 0, ctx->stream, P, Q, d_pts_xy, n, d_n, ld,
-                           swap_xy, max_iter, max_bidir_error, d_out_xy, d_valid, d_fb_err, d_stats);
+        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(n + n2), dim3(64), 0, ctx->stream, P, Q, S0, S1, d_n, swap_xy,
+                           max_iter, max_bidir_error, d_stats);
     else
         return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "BlockSize %d not built (21 and 31 are)", block_size);
     VOHIP_HIP(ctx, hipGetLastError());

@@ -105,6 +105,10 @@ static inline int vohip_download(vohip_ctx *ctx, void *dst, const void *dsrc, si
 int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int ld, int n,
                       const int *d_n, int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
                       uint8_t *d_valid, double *d_fb_err);
+int vohip_klt_enqueue2(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int ld, int n,
+                       const int *d_n, double *d_out_xy, uint8_t *d_valid, double *d_fb_err, const double *d_pts2,
+                       int ld2, int n2, double *d_out2, uint8_t *d_valid2, int block_size, int max_iter,
+                       double max_bidir_error);
 int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                          const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts);
 int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
