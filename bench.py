@@ -211,10 +211,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # VOHIP_BENCH_BACKEND=gloo lets several ranks rehearse the multi-process path on one GPU
+    backend = os.environ.get("VOHIP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     vo = importlib.import_module("visual_odometry_pipeline_amd")
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -229,7 +237,7 @@ def main():
         def gather(pipe, seconds):
             et, er = pipe.trajectory()
             rec = vo.batch.pack_record(rank, seconds, et, er, pipe.num_X, pipe.num_C, pipe.num_new)
-            return vo.batch.gather_records([rec], world, device=torch.device("cuda", local_rank) if world > 1 else None)
+            return vo.batch.gather_records([rec], world, device=coll_device if (world > 1 and backend == "nccl") else None)
 
         n_frames = args.warmup + args.steps + 1
         # with the CPU baseline leg the sequence is longer, so that its sample is about 10 s of CPU work
@@ -241,7 +249,7 @@ def main():
         elapsed_h2d, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
                                       gather, resident=False)
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         fps = world * args.steps / elapsed
