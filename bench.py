@@ -108,7 +108,10 @@ def bench_ransac(vo, torch, ctx, n, h, steps, warmup, seed):
     def count_only():
         ctx.check(lib.vohip_ransac_p3p_count_dev(ctx.handle, d_kp.data_ptr(), d_X.data_ptr(), n, h, d_c.data_ptr()))
 
-    for _ in range(warmup):
+    # The clocks need a few milliseconds of load to settle (a 2 ms burst of fp64 FMAs runs at ~50-60
+    # TFLOP/s, a sustained one at ~72), so both measurements run long enough to be steady-state.
+    steps = max(steps, 200)
+    for _ in range(max(warmup, 50)):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -118,8 +121,9 @@ def bench_ransac(vo, torch, ctx, n, h, steps, warmup, seed):
     hyps_per_s = h * steps / (time.perf_counter() - t0)
     # scoring kernel alone, HIP events on the stream it is launched on
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = max(steps, 20)
-    count_only()
+    reps = steps
+    for _ in range(50):
+        count_only()
     torch.cuda.synchronize()
     ev0.record()
     for _ in range(reps):

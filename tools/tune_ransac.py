@@ -25,11 +25,11 @@ with torch.cuda.stream(s):
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
                 lib.vohip_ransac_p3p_count_dev(ctx.handle, d_kp.data_ptr(), d_X.data_ptr(), n, h, d_c.data_ptr())
                 e0.record(s)
-                for _ in range(20):
+                for _ in range(150):
                     lib.vohip_ransac_p3p_count_dev(ctx.handle, d_kp.data_ptr(), d_X.data_ptr(), n, h, d_c.data_ptr())
                 e1.record(s)
                 torch.cuda.synchronize()
-                res.setdefault(v, []).append(e0.elapsed_time(e1) / 20 * 1e3)
+                res.setdefault(v, []).append(e0.elapsed_time(e1) / 150 * 1e3)
                 c = d_c.cpu().numpy()
                 if ref is None: ref = c
                 assert np.array_equal(ref, c), v

@@ -425,7 +425,8 @@ __global__ __launch_bounds__(WAVES * 64) void p3p_score_kernel(
 #pragma unroll
         for (int i = 0; i < PER_X; ++i) {
             const int idx = tid + i * NT;
-            rx[i] = idx < 3 * tn ? X[(size_t)3 * base + idx] : 0.0;
+            // points past the end are NaN: they fail the test, so the scoring loop needs no bound check
+            rx[i] = idx < 3 * tn ? X[(size_t)3 * base + idx] : __builtin_nan("");
         }
 #pragma unroll
         for (int i = 0; i < PER_K; ++i) {
@@ -457,14 +458,32 @@ __global__ __launch_bounds__(WAVES * 64) void p3p_score_kernel(
         const int base = t * TILE;
         const int tn = min(TILE, n - base);
         if (t + 1 < ntiles) load_tile(base + TILE);
-        const double *L = lds[t & 1];
-        for (int p = lane; p < tn; p += 64) {
-            const double px = L[p], py = L[TILE + p], pz = L[2 * TILE + p];
-            const double pv = L[3 * TILE + p], pu = L[4 * TILE + p];
-            c0 += __popcll(__ballot(is_inlier_sv(ms[0], tv[0][0], tv[0][1], tv[0][2], px, py, pz, pu, pv)));
-            c1 += __popcll(__ballot(is_inlier_sv(ms[1], tv[1][0], tv[1][1], tv[1][2], px, py, pz, pu, pv)));
-            c2 += __popcll(__ballot(is_inlier_sv(ms[2], tv[2][0], tv[2][1], tv[2][2], px, py, pz, pu, pv)));
-            c3 += __popcll(__ballot(is_inlier_sv(ms[3], tv[3][0], tv[3][1], tv[3][2], px, py, pz, pu, pv)));
+        const double *L = lds[t & 1] + lane;
+        // Wave-uniform trip count (the tile is NaN-padded, so whole groups of 64 points are tested
+        // without a bound check), two groups per trip: the LDS reads of one group are in flight
+        // while the other one is tested.
+        const int pairs = (tn + 127) >> 7;
+        double ax = L[0], ay = L[TILE], az = L[2 * TILE], av = L[3 * TILE], au = L[4 * TILE];
+        for (int gi = 0; gi < pairs; ++gi) {
+            const int o1 = gi * 128 + 64;
+            const double bx = L[o1], by = L[TILE + o1], bz = L[2 * TILE + o1];
+            const double bv = L[3 * TILE + o1], bu = L[4 * TILE + o1];
+            __builtin_amdgcn_sched_barrier(0);   // keep these reads ahead of the arithmetic below
+            c0 += __popcll(__ballot(is_inlier_sv(ms[0], tv[0][0], tv[0][1], tv[0][2], ax, ay, az, au, av)));
+            c1 += __popcll(__ballot(is_inlier_sv(ms[1], tv[1][0], tv[1][1], tv[1][2], ax, ay, az, au, av)));
+            c2 += __popcll(__ballot(is_inlier_sv(ms[2], tv[2][0], tv[2][1], tv[2][2], ax, ay, az, au, av)));
+            c3 += __popcll(__ballot(is_inlier_sv(ms[3], tv[3][0], tv[3][1], tv[3][2], ax, ay, az, au, av)));
+            const int o2 = gi + 1 < pairs ? (gi + 1) * 128 : 0;   // the last prefetch is a harmless re-read
+            ax = L[o2];
+            ay = L[TILE + o2];
+            az = L[2 * TILE + o2];
+            av = L[3 * TILE + o2];
+            au = L[4 * TILE + o2];
+            __builtin_amdgcn_sched_barrier(0);
+            c0 += __popcll(__ballot(is_inlier_sv(ms[0], tv[0][0], tv[0][1], tv[0][2], bx, by, bz, bu, bv)));
+            c1 += __popcll(__ballot(is_inlier_sv(ms[1], tv[1][0], tv[1][1], tv[1][2], bx, by, bz, bu, bv)));
+            c2 += __popcll(__ballot(is_inlier_sv(ms[2], tv[2][0], tv[2][1], tv[2][2], bx, by, bz, bu, bv)));
+            c3 += __popcll(__ballot(is_inlier_sv(ms[3], tv[3][0], tv[3][1], tv[3][2], bx, by, bz, bu, bv)));
         }
         if (t + 1 < ntiles) store_tile((t + 1) & 1);
         __syncthreads();
