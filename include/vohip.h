@@ -247,6 +247,15 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
 int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, const double *u3, int h,
                      const double *u8, vohip_frame_pose *pose, vohip_frame_counts *counts);
 int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *counts);
+/* vohip_frame_step for a caller that already holds the following image (a stored sequence, as the
+ * loop of main_demo.m:352-375 reads it): while this frame is localised and mapped, `next_image` is
+ * transferred, its pyramid is built and its corners are detected on streams of their own, so that the
+ * next call starts with its trackers.  The results are those of vohip_frame_step, bit for bit; the
+ * next call must pass `next_image` as its `image` (it is not transferred again), and a host
+ * `next_image` must stay readable until that call returns.  next_image = NULL: exactly vohip_frame_step. */
+int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
+                           int next_on_device, const double *u3, int h, const double *u8, vohip_frame_pose *pose,
+                           vohip_frame_counts *counts);
 int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates);
 /* Copies of S.P (2xn), S.X(1:3,:) (3xn), S.X(4,:), S.C, S.F (2xm), S.T (12xm); any pointer may be NULL. */
 int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc, double *T12);

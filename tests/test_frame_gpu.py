@@ -118,3 +118,34 @@ def test_device_loop_accepts_device_images_and_reports_errors(vo, ctx, oracle, s
     # capacity is checked
     with pytest.raises(vo.VohipError):
         vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, ctx=ctx, cap_landmarks=64)
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_preparing_the_next_frame_ahead_changes_nothing(vo, ctx, oracle, sequence, on_device):
+    """vohip_frame_step_ahead: with the next image in hand its pyramid and corners are prepared beside
+    the current frame's localisation.  Bar: every pose, count and state array bit-identical to the
+    plain loop; also when the lookahead starts or stops in mid-sequence."""
+    import torch
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    imgs = [torch.from_numpy(f).cuda() for f in frames] if on_device else frames
+    plain = vo.VOPipelineDevice(K, imgs[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(1), ctx=ctx)
+    ahead = vo.VOPipelineDevice(K, imgs[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(1), ctx=ctx)
+    last = len(frames) - 1
+    for i in range(1, len(frames)):
+        Tp = plain.process_frame(imgs[i])
+        # frame 4 is processed without lookahead: frame 5 then starts from scratch again
+        nxt = imgs[i + 1] if i < last and i != 4 else None
+        Ta = ahead.process_frame(imgs[i], next_image=nxt)
+        np.testing.assert_array_equal(Ta, Tp)
+        assert (ahead.num_X[-1], ahead.num_C[-1]) == (plain.num_X[-1], plain.num_C[-1]), i
+        for k in ("n_detected", "n_kept", "n_candidates_tracked", "n_candidates_inliers", "num_new"):
+            assert getattr(ahead.last_counts, k) == getattr(plain.last_counts, k), (i, k)
+        assert ahead.last_pose.n_tracked == plain.last_pose.n_tracked and ahead.last_pose.n_iter == plain.last_pose.n_iter
+    A, P = ahead.S, plain.S
+    for k in ("X", "P", "C", "F", "T", "est_trans", "est_rot"):
+        np.testing.assert_array_equal(getattr(A, k), getattr(P, k), err_msg=k)
+    assert ahead.rng.bit_generator.state == plain.rng.bit_generator.state
+    plain.close()
+    ahead.close()

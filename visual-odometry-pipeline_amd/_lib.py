@@ -71,6 +71,8 @@ SIGNATURES = {
     "vohip_frame_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_double_p, C.c_int, c_double_p,
                                     C.POINTER(FramePose), C.POINTER(FrameCounts)]),
     "vohip_frame_retry": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.POINTER(FramePose), C.POINTER(FrameCounts)]),
+    "vohip_frame_step_ahead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_double_p, C.c_int,
+                                          c_double_p, C.POINTER(FramePose), C.POINTER(FrameCounts)]),
     "vohip_frame_sizes": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
     "vohip_frame_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]),
@@ -157,6 +159,13 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(
                 "%s not found: build it with `python %s`" % (LIB_PATH, os.path.join(HERE, "build.py")))
+        # PyTorch ships its own copy of the HIP runtime and finds it by file name, so a process that
+        # loaded the system's copy first would end up with two runtimes (and torch with no GPU).
+        # Loading torch's first makes this library resolve to the same one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

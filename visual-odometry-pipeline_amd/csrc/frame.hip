@@ -35,7 +35,8 @@ enum {
     N_L_END,      // landmarks after new ones were appended
     N_C_MID,      // candidates left after triangulation
     NUM_NEW,      // candidates removed by update_landmarks (appended or dropped)
-    N_DET,        // corners detected (may exceed the capacity)
+    N_DET,        // corners detected (may exceed the capacity), frames of even parity ...
+    N_DET_ODD,    // ... and of odd parity (the next frame's detection can run ahead)
     FILT0, FILT1, FILT2,  // {detections, candidates, landmarks} as the redundancy filter reads them
     N_KEPT,       // detections kept
     N_C_END,      // candidates at the end of the frame
@@ -137,9 +138,10 @@ __global__ __launch_bounds__(256) void select_tracked_kernel(const double *__res
                                                              const double *__restrict__ L_X,
                                                              const double *__restrict__ L_id, int n,
                                                              double *__restrict__ mv_rc, double *__restrict__ Xv,
-                                                             double *__restrict__ idv, int *__restrict__ cnt,
-                                                             double *__restrict__ dv, const double *__restrict__ u3,
-                                                             int h0, int32_t *__restrict__ samples)
+                                                             double *__restrict__ idv, int32_t *__restrict__ rowv,
+                                                             int *__restrict__ cnt, double *__restrict__ dv,
+                                                             const double *__restrict__ u3, int h0,
+                                                             int32_t *__restrict__ samples)
 {
     __shared__ int sh[12];
     int total;
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(256) void select_tracked_kernel(const double *__res
         Xv[3 * r + 1] = L_X[3 * i + 1];
         Xv[3 * r + 2] = L_X[3 * i + 2];
         idv[r] = L_id[i];
+        rowv[r] = i;   // landmark i is row i of the track table
     }
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) cnt[N_V] = total;
@@ -286,10 +289,11 @@ __global__ __launch_bounds__(64) void localize_decide_kernel(const int32_t *__re
 __global__ __launch_bounds__(256) void select_inliers_kernel(const double *__restrict__ mv_rc,
                                                              const double *__restrict__ Xv,
                                                              const double *__restrict__ idv,
+                                                             const int32_t *__restrict__ rowv,
                                                              const double *__restrict__ dv,
                                                              int *__restrict__ cnt, double *__restrict__ L_rc,
                                                              double *__restrict__ L_X, double *__restrict__ L_id,
-                                                             double *__restrict__ kp_uv)
+                                                             int32_t *__restrict__ srcL, double *__restrict__ kp_uv)
 {
     __shared__ int sh[12];
     const int n = cnt[N_V];
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(256) void select_inliers_kernel(const double *__res
         L_X[3 * r + 1] = Xv[3 * i + 1];
         L_X[3 * r + 2] = Xv[3 * i + 2];
         L_id[r] = idv[i];
+        srcL[r] = rowv[i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         cnt[N_IN] = total;
@@ -329,6 +334,7 @@ __global__ __launch_bounds__(256) void select_cand_tracked_kernel(const double *
                                                                   const double *__restrict__ T12, int n,
                                                                   double *__restrict__ p1_rc, double *__restrict__ m_rc,
                                                                   double *__restrict__ F_t, double *__restrict__ T_t,
+                                                                  int row_base, int32_t *__restrict__ row_t,
                                                                   int *__restrict__ cnt)
 {
     __shared__ int sh[12];
@@ -343,6 +349,7 @@ __global__ __launch_bounds__(256) void select_cand_tracked_kernel(const double *
         F_t[2 * r] = F_rc[2 * i];
         F_t[2 * r + 1] = F_rc[2 * i + 1];
         for (int q = 0; q < 12; ++q) T_t[12 * (size_t)r + q] = T12[12 * (size_t)i + q];
+        row_t[r] = row_base + i;   // candidate i is row row_base + i of the track table
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt[N_CV] = total;
 }
@@ -425,8 +432,10 @@ __global__ __launch_bounds__(256) void select_f_inliers_kernel(const double *__r
                                                                const double *__restrict__ F_t,
                                                                const double *__restrict__ T_t,
                                                                const uint8_t *__restrict__ fmask,
+                                                               const int32_t *__restrict__ row_t,
                                                                int *__restrict__ cnt, double *__restrict__ m2_rc,
-                                                               double *__restrict__ F2, double *__restrict__ T2)
+                                                               double *__restrict__ F2, double *__restrict__ T2,
+                                                               int32_t *__restrict__ row2)
 {
     __shared__ int sh[12];
     const int n = cnt[F_BEST_T] >= 0 ? cnt[N_CV] : 0;
@@ -439,6 +448,7 @@ __global__ __launch_bounds__(256) void select_f_inliers_kernel(const double *__r
         F2[2 * r] = F_t[2 * i];
         F2[2 * r + 1] = F_t[2 * i + 1];
         for (int q = 0; q < 12; ++q) T2[12 * (size_t)r + q] = T_t[12 * (size_t)i + q];
+        row2[r] = row_t[i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt[N_CI] = total;
 }
@@ -450,11 +460,13 @@ __global__ __launch_bounds__(256) void split_candidates_kernel(const uint8_t *__
                                                                const double *__restrict__ F2,
                                                                const double *__restrict__ T2,
                                                                const double *__restrict__ Xnew,
-                                                               int *__restrict__ cnt, double *__restrict__ dv,
-                                                               int capL, int capK, double *__restrict__ L_rc,
-                                                               double *__restrict__ L_X, double *__restrict__ L_id,
+                                                               const int32_t *__restrict__ row2,
+                                                               int *__restrict__ cnt, const int *__restrict__ n_det,
+                                                               double *__restrict__ dv, int capL, int capK,
+                                                               double *__restrict__ L_rc, double *__restrict__ L_X,
+                                                               double *__restrict__ L_id, int32_t *__restrict__ srcL,
                                                                double *__restrict__ C_rc, double *__restrict__ F_rc,
-                                                               double *__restrict__ T12)
+                                                               double *__restrict__ T12, int32_t *__restrict__ srcC)
 {
     __shared__ int sh[12];
     const int n = cnt[N_CI];
@@ -475,12 +487,14 @@ __global__ __launch_bounds__(256) void split_candidates_kernel(const uint8_t *__
             L_X[3 * d + 1] = Xnew[3 * i + 1];
             L_X[3 * d + 2] = Xnew[3 * i + 2];
             L_id[d] = idx0 + (double)r_new;
+            srcL[d] = row2[i];
         } else if (st == 0) {
             C_rc[2 * r_stay] = m2_rc[2 * i];
             C_rc[2 * r_stay + 1] = m2_rc[2 * i + 1];
             F_rc[2 * r_stay] = F2[2 * i];
             F_rc[2 * r_stay + 1] = F2[2 * i + 1];
             for (int q = 0; q < 12; ++q) T12[12 * (size_t)r_stay + q] = T2[12 * (size_t)i + q];
+            srcC[r_stay] = row2[i];
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -494,31 +508,32 @@ __global__ __launch_bounds__(256) void split_candidates_kernel(const uint8_t *__
         cnt[NUM_NEW] = n - k_stay;
         dv[D_IDX_NEXT] = idx0 + (double)k_new;
         // the three counts the redundancy filter reads (update_candidate.m:12-24)
-        cnt[FILT0] = min(cnt[N_DET], capK);
+        cnt[FILT0] = min(*n_det, capK);
         cnt[FILT1] = k_stay;
         cnt[FILT2] = nL + kept;
     }
 }
 
 // The same three counts for a frame without candidates (update_landmarks does not run).
-__global__ void filter_counts_kernel(int *__restrict__ cnt, int capK, int have_map, double *__restrict__ dv)
+__global__ void filter_counts_kernel(int *__restrict__ cnt, const int *__restrict__ n_det, int capK, int have_map,
+                                     double *__restrict__ dv)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    cnt[FILT0] = min(cnt[N_DET], capK);
+    cnt[FILT0] = min(*n_det, capK);
     cnt[FILT1] = cnt[N_C_MID];
     cnt[FILT2] = cnt[N_L_END];
     if (!have_map) dv[D_IDX_NEXT] = dv[D_IDX];
 }
 
-// update_candidate.m:55-57: kept detections become candidates, first seen here, under this pose;
-// also writes the track points of the next frame.
+// update_candidate.m:55-57: kept detections become candidates, first seen here, under this pose.
+// Detection i is row det_base + i of the track table.
 __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__restrict__ corner_xy, int ld,
                                                                 const uint8_t *__restrict__ keep,
                                                                 int *__restrict__ cnt, double *__restrict__ dv,
-                                                                int capC, double *__restrict__ C_rc,
+                                                                int capC, int det_base, double *__restrict__ C_rc,
                                                                 double *__restrict__ F_rc, double *__restrict__ T12,
-                                                                const double *__restrict__ L_rc, int ldL,
-                                                                double *__restrict__ L_xy, double *__restrict__ C_xy)
+                                                                int32_t *__restrict__ srcC, double *__restrict__ mirror_dv,
+                                                                int *__restrict__ mirror_cnt)
 {
     __shared__ int sh[12];
     const int n = cnt[FILT0];
@@ -526,24 +541,14 @@ __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__r
     int total;
     const int r = ordered_rank(keep, n, is_set(), total, sh);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    // main_demo.m:417-424: the points both trackers start from in the next frame, as (x, y) columns
-    if (i < cnt[N_L_END]) {
-        L_xy[i] = L_rc[2 * i + 1];
-        L_xy[ldL + i] = L_rc[2 * i];
-    }
-    if (i < nC) {
-        C_xy[i] = C_rc[2 * i + 1];
-        C_xy[capC + i] = C_rc[2 * i];
-    }
     if (i < n && keep[i] && nC + r < capC) {
         const int d = nC + r;
         const double row = (double)corner_xy[ld + i], col = (double)corner_xy[i];
-        C_xy[d] = col;
-        C_xy[capC + d] = row;
         C_rc[2 * d] = row;
         C_rc[2 * d + 1] = col;
         F_rc[2 * d] = row;
         F_rc[2 * d + 1] = col;
+        srcC[d] = det_base + i;
         const double *T = dv + D_T;   // [R_W_C(:); t_W_C]
         double *o = T12 + 12 * (size_t)d;
         for (int c = 0; c < 3; ++c)
@@ -559,23 +564,49 @@ __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__r
         cnt[N_KEPT] = kept;
         cnt[N_C_END] = nC + kept;
     }
+    // This is the last kernel of a frame: the frame's summary goes to the caller's (pinned host)
+    // mirror from here, which saves a copy command between this kernel and the synchronisation.
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        if (threadIdx.x < N_DOUBLES) mirror_dv[threadIdx.x] = dv[threadIdx.x];
+        if (threadIdx.x < N_COUNTERS) mirror_cnt[threadIdx.x] = cnt[threadIdx.x];
+    }
 }
 
-// main_demo.m:417-424: the points both trackers start from in the next frame, as (x, y) columns.
-__global__ __launch_bounds__(256) void next_tracks_kernel(const double *__restrict__ L_rc, int ldL,
-                                                          double *__restrict__ L_xy,
-                                                          const double *__restrict__ C_rc, int ldC,
-                                                          double *__restrict__ C_xy, const int *__restrict__ cnt)
+// The track tables, one for even and one for odd frames.  Row r holds a point of that frame's image
+// which the tracker can follow into the next image: rows [0, capL) the landmarks in the order the
+// frame starts with, rows [capL, capL + capC) the candidates, rows [capL + capC, capL + capC + capK)
+// the frame's detections.  xy: x column then y column (leading dimension ld), MATLAB's (x, y); live:
+// the row holds a point.  The tracker reads the row of the previous frame's table that a landmark
+// (candidate) kept by that frame came from -- srcL (srcC) -- and writes the landmark (candidate)
+// rows of the current frame's table.
+
+// Detections -> their rows of the table (main_demo.m:377; every detection may become a candidate).
+__global__ __launch_bounds__(256) void detection_rows_kernel(const float *__restrict__ corner_xy, int capK,
+                                                             const int *__restrict__ n_det, int base, int ld,
+                                                             double *__restrict__ U_xy, uint8_t *__restrict__ U_live)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < cnt[N_L_END]) {
-        L_xy[i] = L_rc[2 * i + 1];
-        L_xy[ldL + i] = L_rc[2 * i];
+    if (i >= capK) return;
+    const bool on = i < *n_det;
+    if (on) {
+        U_xy[base + i] = (double)corner_xy[i];
+        U_xy[ld + base + i] = (double)corner_xy[capK + i];
     }
-    if (i < cnt[N_C_END]) {
-        C_xy[i] = C_rc[2 * i + 1];
-        C_xy[ldC + i] = C_rc[2 * i];
-    }
+    U_live[base + i] = on ? 1 : 0;
+}
+
+// main_demo.m:342-344: the landmarks a sequence starts with, as rows of the table.
+__global__ __launch_bounds__(256) void init_rows_kernel(const double *__restrict__ L_rc, int n, int ld,
+                                                        double *__restrict__ U_xy, uint8_t *__restrict__ U_live,
+                                                        int32_t *__restrict__ srcL)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    U_xy[i] = L_rc[2 * i + 1];
+    U_xy[ld + i] = L_rc[2 * i];
+    U_live[i] = 1;
+    srcL[i] = i;
 }
 
 }  // namespace
@@ -586,22 +617,31 @@ struct vohip_frame {
     double K[9];
     int rows = 0, cols = 0, colmajor = 0;
     int capL = 0, capC = 0, capK = 0, hmax = 0;
-    hipStream_t side = nullptr, side2 = nullptr;
-    hipEvent_t ev_pyr = nullptr, ev_side = nullptr, ev_det = nullptr, ev_img = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr, trk = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_side = nullptr, ev_img = nullptr, ev_adv = nullptr, ev_next = nullptr, ev_draws = nullptr;
+    hipEvent_t ev_det[2] = {nullptr, nullptr};
     hipEvent_t tr[8] = {nullptr};   // timing events of the trace option
     bool trace = false;
     void *block = nullptr;       // one device allocation, carved up below
     void *pinned = nullptr;      // host mirror of the counters and doubles
-    uint8_t *img = nullptr;      // image staging (host images)
-    double *L_rc, *L_X, *L_id, *L_xy, *C_rc, *F_rc, *T12, *C_xy;
-    double *kL_out, *mv_rc, *Xv, *idv, *kp_uv;
-    double *kC_out, *p1_rc, *m_rc, *F_t, *T_t, *m2_rc, *F2, *T2, *Xnew;
+    uint8_t *img[2] = {nullptr, nullptr};   // image staging (host images), by frame parity
+    double *L_rc, *L_X, *L_id, *C_rc, *F_rc, *T12;
+    double *mv_rc, *Xv, *idv, *kp_uv;
+    double *p1_rc, *m_rc, *F_t, *T_t, *m2_rc, *F2, *T2, *Xnew;
     double *u3, *u8, *fm_F, *dv;
-    float *corner_xy, *corner_metric;
+    double *U_xy[2];             // the track tables of even and odd frames
+    uint8_t *U_live[2];
+    int32_t *srcL, *srcC;        // table row of every landmark / candidate the next frame starts with
+    int32_t *rowv, *row_t, *row2;
+    float *corner_xy[2], *corner_metric[2];   // detections, by frame parity
     int32_t *samples3, *counts4, *samples8, *fm_counts;
     int *cnt;
-    uint8_t *kL_valid, *kC_valid, *mask, *fmask, *status, *keep;
+    uint8_t *mask, *fmask, *status, *keep;
+    int capU = 0;                // rows of the track table
     int slot_prev = 0, slot_cur = 0;
+    int par = 0;                 // parity of the frame being processed
+    bool ahead_launched = false; // this call prepares the next image
+    bool ahead = false;          // the previous call left this image's pyramid and corners on the device
     int n_L = 0, n_C = 0;        // counts at the start of the frame (known to the host)
     int evaluated = 0;           // hypotheses scored in the current frame
     int stage = 0;               // 0 = between frames, 1 = a frame waits for more hypotheses
@@ -622,23 +662,21 @@ T *carve(char *&p, size_t count)
 size_t layout(vohip_frame *f, char *base)
 {
     char *p = base;
-    const size_t L = f->capL, C = f->capC, Kc = f->capK, H = f->hmax, T = f->prm.fm_trials;
+    const size_t L = f->capL, C = f->capC, Kc = f->capK, H = f->hmax, T = f->prm.fm_trials, U = f->capU;
     f->dv = carve<double>(p, N_DOUBLES);   // dv and cnt are adjacent: one copy brings both to the host
     f->cnt = carve<int>(p, N_COUNTERS);
     f->L_rc = carve<double>(p, 2 * L);
     f->L_X = carve<double>(p, 3 * L);
     f->L_id = carve<double>(p, L);
-    f->L_xy = carve<double>(p, 2 * L);
     f->C_rc = carve<double>(p, 2 * C);
     f->F_rc = carve<double>(p, 2 * C);
     f->T12 = carve<double>(p, 12 * C);
-    f->C_xy = carve<double>(p, 2 * C);
-    f->kL_out = carve<double>(p, 2 * L);
+    f->U_xy[0] = carve<double>(p, 2 * U);
+    f->U_xy[1] = carve<double>(p, 2 * U);
     f->mv_rc = carve<double>(p, 2 * L);
     f->Xv = carve<double>(p, 3 * L);
     f->idv = carve<double>(p, L);
     f->kp_uv = carve<double>(p, 2 * L);
-    f->kC_out = carve<double>(p, 2 * C);
     f->p1_rc = carve<double>(p, 2 * C);
     f->m_rc = carve<double>(p, 2 * C);
     f->F_t = carve<double>(p, 2 * C);
@@ -650,19 +688,26 @@ size_t layout(vohip_frame *f, char *base)
     f->u3 = carve<double>(p, 3 * H);
     f->u8 = carve<double>(p, 8 * T);
     f->fm_F = carve<double>(p, 9 * T);
-    f->corner_xy = carve<float>(p, 2 * Kc);
-    f->corner_metric = carve<float>(p, Kc);
+    for (int q = 0; q < 2; ++q) {
+        f->corner_xy[q] = carve<float>(p, 2 * Kc);
+        f->corner_metric[q] = carve<float>(p, Kc);
+    }
+    f->srcL = carve<int32_t>(p, L);
+    f->srcC = carve<int32_t>(p, C);
+    f->rowv = carve<int32_t>(p, L);
+    f->row_t = carve<int32_t>(p, C);
+    f->row2 = carve<int32_t>(p, C);
     f->samples3 = carve<int32_t>(p, 3 * H);
     f->counts4 = carve<int32_t>(p, 4 * H);
     f->samples8 = carve<int32_t>(p, 8 * T);
     f->fm_counts = carve<int32_t>(p, T);
-    f->kL_valid = carve<uint8_t>(p, L);
-    f->kC_valid = carve<uint8_t>(p, C);
+    f->U_live[0] = carve<uint8_t>(p, U);
+    f->U_live[1] = carve<uint8_t>(p, U);
     f->mask = carve<uint8_t>(p, L);
     f->fmask = carve<uint8_t>(p, C);
     f->status = carve<uint8_t>(p, C);
     f->keep = carve<uint8_t>(p, Kc);
-    f->img = carve<uint8_t>(p, (size_t)f->rows * f->cols);
+    for (int q = 0; q < 2; ++q) f->img[q] = carve<uint8_t>(p, (size_t)f->rows * f->cols);
     return (size_t)(p - base);
 }
 
@@ -686,8 +731,7 @@ inline double *pin_u8(vohip_frame *f) { return pin_u3(f) + 3 * (size_t)f->hmax; 
 int fetch_summary(vohip_frame *f)
 {
     vohip_ctx *ctx = f->ctx;
-    static_assert(sizeof(double) * N_DOUBLES % 256 == 0, "cnt must follow dv directly");
-    VOHIP_HIP(ctx, hipMemcpyAsync(f->pinned, f->dv, PIN_U3, hipMemcpyDeviceToHost, ctx->stream));
+    // (the last kernel of the frame wrote the summary into the pinned mirror)
     VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VOHIP_OK;
 }
@@ -699,15 +743,15 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
     const int T = p.fm_trials;
+    (void)u8;   // already on its way up (the caller's stream order)
     stream_swap sw(ctx, f->side);
     hipStream_t s = f->side;
-    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_pyr, 0));
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_adv, 0));
     if (f->trace) (void)hipEventRecord(f->tr[3], s);
     if (f->have_map) {
-        std::memcpy(pin_u8(f), u8, sizeof(double) * 8 * (size_t)T);
-        VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, pin_u8(f), sizeof(double) * 8 * (size_t)T, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->kC_out, f->capC,
-                           f->kC_valid, f->C_rc, f->F_rc, f->T12, f->n_C, f->p1_rc, f->m_rc, f->F_t, f->T_t, f->cnt);
+        hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->U_xy[f->par] + f->capL,
+                           f->capU, f->U_live[f->par] + f->capL, f->C_rc, f->F_rc, f->T12, f->n_C, f->p1_rc, f->m_rc, f->F_t,
+                           f->T_t, f->capL, f->row_t, f->cnt);
         hipLaunchKernelGGL(octets_kernel, dim3((T + 63) / 64), dim3(64), 0, s, f->u8, T, f->cnt, f->samples8);
         VOHIP_TRY(vohip_fm_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->samples8, T, p.fm_threshold,
                                    f->dv + D_NRM, f->fm_F, f->fm_counts));
@@ -716,7 +760,7 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
         VOHIP_TRY(vohip_fm_mask_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->dv + D_F, p.fm_threshold,
                                         f->fmask));
         hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->m_rc, f->F_t, f->T_t,
-                           f->fmask, f->cnt, f->m2_rc, f->F2, f->T2);
+                           f->fmask, f->row_t, f->cnt, f->m2_rc, f->F2, f->T2, f->row2);
         VOHIP_HIP(ctx, hipGetLastError());
     }
     VOHIP_HIP(ctx, hipEventRecord(f->ev_side, s));
@@ -724,17 +768,23 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
     return VOHIP_OK;
 }
 
-// Third stream: corner detection (main_demo.m:377) needs only the image.
-int enqueue_detection(vohip_frame *f, const uint8_t *d_img)
+// Third stream: corner detection (main_demo.m:377) needs only the image; the detections also become
+// rows of the track table.  `par`: parity of the frame the image belongs to; `ready`: event after
+// which the image is on the device.
+int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t ready)
 {
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
     stream_swap sw(ctx, f->side2);
-    VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, f->ev_img, 0));
+    VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, ready, 0));
     VOHIP_TRY(vohip_detect_corners_dev(ctx, d_img, f->rows, f->cols, f->colmajor, p.min_quality, p.filter_size, p.border,
-                                       p.detector, f->corner_xy, f->corner_metric, f->capK, f->cnt + N_DET));
-    VOHIP_HIP(ctx, hipEventRecord(f->ev_det, f->side2));
-    if (f->trace) (void)hipEventRecord(f->tr[5], f->side2);   // detection done
+                                       p.detector, f->corner_xy[par], f->corner_metric[par], f->capK,
+                                       f->cnt + N_DET + par));
+    hipLaunchKernelGGL(detection_rows_kernel, dim3(blocks256(f->capK)), dim3(256), 0, f->side2, f->corner_xy[par], f->capK,
+                       f->cnt + N_DET + par, f->capL + f->capC, f->capU, f->U_xy[par], f->U_live[par]);
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_det[par], f->side2));
+    if (f->trace && par == f->par) (void)hipEventRecord(f->tr[5], f->side2);   // detection done
     return VOHIP_OK;
 }
 
@@ -763,8 +813,8 @@ int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready)
     hipLaunchKernelGGL(localize_decide_kernel, dim3(1), dim3(64), 0, s, f->counts4, h,
                        (const double *)ctx->bufs[B_RANSAC_RT].ptr, (const double *)ctx->bufs[B_RANSAC_M].ptr, f->cnt,
                        f->dv);
-    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->mv_rc, f->Xv, f->idv, f->dv,
-                       f->cnt, f->L_rc, f->L_X, f->L_id, f->kp_uv);
+    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->mv_rc, f->Xv, f->idv, f->rowv,
+                       f->dv, f->cnt, f->L_rc, f->L_X, f->L_id, f->srcL, f->kp_uv);
     VOHIP_HIP(ctx, hipGetLastError());
     if (p.refine_pose)   // main_demo.m:398-400
         VOHIP_TRY(vohip_pose_refine_enqueue(ctx, f->dv + D_T, f->kp_uv, f->L_X, f->n_L, f->cnt + N_IN, f->K,
@@ -779,23 +829,23 @@ int enqueue_tail(vohip_frame *f)
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
     VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_side, 0));
-    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_det, 0));
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_det[f->par], 0));
+    const int *n_det = f->cnt + N_DET + f->par;
     if (f->have_map) {
         VOHIP_TRY(vohip_candidate_triangulate_enqueue(ctx, f->m2_rc, f->F2, f->T2, f->n_C, f->cnt + N_CI, f->dv + D_T,
                                                       f->K, p.angle_threshold_deg, p.min_depth, p.max_depth, 0,
                                                       f->status, f->Xnew));
         hipLaunchKernelGGL(split_candidates_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->status, f->m2_rc, f->F2,
-                           f->T2, f->Xnew, f->cnt, f->dv, f->capL, f->capK, f->L_rc, f->L_X, f->L_id, f->C_rc, f->F_rc,
-                           f->T12);
+                           f->T2, f->Xnew, f->row2, f->cnt, n_det, f->dv, f->capL, f->capK, f->L_rc, f->L_X, f->L_id,
+                           f->srcL, f->C_rc, f->F_rc, f->T12, f->srcC);
     } else {
-        hipLaunchKernelGGL(filter_counts_kernel, dim3(1), dim3(64), 0, s, f->cnt, f->capK, 0, f->dv);
+        hipLaunchKernelGGL(filter_counts_kernel, dim3(1), dim3(64), 0, s, f->cnt, n_det, f->capK, 0, f->dv);
     }
-    VOHIP_TRY(vohip_candidate_filter_enqueue(ctx, f->corner_xy, f->capK, f->capK, f->C_rc, f->L_rc, f->cnt + FILT0,
-                                             p.r_discard_redundant, f->keep));
-    int nmax = f->capL > f->capC ? f->capL : f->capC;
-    nmax = nmax > f->capK ? nmax : f->capK;
-    hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(nmax)), dim3(256), 0, s, f->corner_xy, f->capK, f->keep,
-                       f->cnt, f->dv, f->capC, f->C_rc, f->F_rc, f->T12, f->L_rc, f->capL, f->L_xy, f->C_xy);
+    VOHIP_TRY(vohip_candidate_filter_enqueue(ctx, f->corner_xy[f->par], f->capK, f->capK, f->C_rc, f->L_rc,
+                                             f->cnt + FILT0, p.r_discard_redundant, f->keep));
+    hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s, f->corner_xy[f->par], f->capK,
+                       f->keep, f->cnt, f->dv, f->capC, f->capL + f->capC, f->C_rc, f->F_rc, f->T12, f->srcC, pin_dv(f),
+                       pin_cnt(f));
     VOHIP_HIP(ctx, hipGetLastError());
     if (f->trace) (void)hipEventRecord(f->tr[6], s);   // tail done
     return VOHIP_OK;
@@ -829,7 +879,7 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     out->n_landmarks = hc[N_L_END];
     out->n_candidates = hc[N_C_END];
     out->num_new = hc[NUM_NEW];
-    out->n_detected = hc[N_DET];
+    out->n_detected = hc[N_DET + f->par];
     out->n_kept = hc[N_KEPT];
     out->n_candidates_tracked = f->have_map ? hc[N_CV] : 0;
     out->n_candidates_inliers = f->have_map ? hc[N_CI] : 0;
@@ -838,10 +888,12 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     out->host_enqueue_us = std::chrono::duration<double, std::micro>(t_enq - f->t_entry).count();
     out->host_wait_us = std::chrono::duration<double, std::micro>(t_done - t_enq).count();
     if (f->trace) {
-        float ms[7] = {0};
-        for (int q = 1; q < 7; ++q) (void)hipEventElapsedTime(&ms[q], f->tr[0], f->tr[q]);
-        std::fprintf(stderr, "vohip frame trace (us from start): klt_L %.0f  refined %.0f  klt_C %.0f  filter %.0f  detect %.0f  tail %.0f | host enqueue %.0f wait %.0f\n",
-                     1e3 * ms[1], 1e3 * ms[2], 1e3 * ms[3], 1e3 * ms[4], 1e3 * ms[5], 1e3 * ms[6], out->host_enqueue_us, out->host_wait_us);
+        float ms[8] = {0};
+        for (int q = 1; q < 8; ++q) (void)hipEventElapsedTime(&ms[q], f->tr[0], f->tr[q]);
+        std::fprintf(stderr, "vohip frame trace (us from start): tracks %.0f-%.0f  refined %.0f  filter %.0f-%.0f  detect %.0f  tail %.0f | host enqueue %.0f wait %.0f",
+                     1e3 * ms[7], 1e3 * ms[1], 1e3 * ms[2], 1e3 * ms[3], 1e3 * ms[4], 1e3 * ms[5], 1e3 * ms[6], out->host_enqueue_us,
+                     out->host_wait_us);
+        std::fprintf(stderr, " | rows L %d C %d det %d\n", f->n_L, f->n_C, hc[N_DET + f->par]);
     }
     const int t = f->slot_prev;   // main_demo.m:417-424: this frame's pyramid is the next "previous"
     f->slot_prev = f->slot_cur;
@@ -849,13 +901,16 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     f->n_L = hc[N_L_END];
     f->n_C = hc[N_C_END];
     f->stage = 0;
+    f->ahead = f->ahead_launched;
+    const int n_det_now = hc[N_DET + f->par];
+    f->par ^= 1;
     if (hc[N_V] < 3) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "only %d landmarks were tracked", hc[N_V]);
     if (!hc[R_FOUND])
         return vohip_fail(ctx, VOHIP_NO_MODEL, "no hypothesis reached 30 inliers in %d iterations", hc[R_ITER]);
     if (f->have_map && hc[N_CV] < 8)
         return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "the 8-point algorithm needs 8 candidate tracks, got %d", hc[N_CV]);
-    if (hc[N_DET] > f->capK)
-        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "%d corners found, capacity %d", hc[N_DET], f->capK);
+    if (n_det_now > f->capK)
+        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "%d corners found, capacity %d", n_det_now, f->capK);
     if (hc[OVERFLOW])
         return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "landmark or candidate capacity exceeded (flags %d)", hc[OVERFLOW]);
     return VOHIP_OK;
@@ -921,6 +976,7 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     f->capC = p.cap_candidates;
     f->capK = p.cap_corners;
     f->hmax = (p.max_hypotheses + 7) / 8 * 8;
+    f->capU = f->capL + f->capC + f->capK;
     f->slot_prev = p.slot_a;
     f->slot_cur = p.slot_b;
     const size_t bytes = layout(f, nullptr);
@@ -930,7 +986,12 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
         e = hipHostMalloc(&f->pinned, PIN_U3 + sizeof(double) * (3 * (size_t)f->hmax + 8 * (size_t)p.fm_trials),
                           hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det[1], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->trk, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_adv, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_next, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_draws, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_pyr, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_side, hipEventDisableTiming);
@@ -967,7 +1028,15 @@ int vohip_frame_destroy(vohip_frame *f)
         (void)hipStreamSynchronize(f->side2);
         (void)hipStreamDestroy(f->side2);
     }
-    if (f->ev_det) (void)hipEventDestroy(f->ev_det);
+    if (f->trk) {
+        (void)hipStreamSynchronize(f->trk);
+        (void)hipStreamDestroy(f->trk);
+    }
+    for (int q = 0; q < 2; ++q)
+        if (f->ev_det[q]) (void)hipEventDestroy(f->ev_det[q]);
+    if (f->ev_adv) (void)hipEventDestroy(f->ev_adv);
+    if (f->ev_next) (void)hipEventDestroy(f->ev_next);
+    if (f->ev_draws) (void)hipEventDestroy(f->ev_draws);
     if (f->ctx) (void)hipStreamSynchronize(f->ctx->stream);
     if (f->ev_pyr) (void)hipEventDestroy(f->ev_pyr);
     for (int q = 0; q < 8; ++q)
@@ -992,10 +1061,14 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     hipStream_t s = ctx->stream;
     VOHIP_HIP(ctx, hipStreamSynchronize(f->side));
     VOHIP_HIP(ctx, hipStreamSynchronize(f->side2));
+    VOHIP_HIP(ctx, hipStreamSynchronize(f->trk));
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    f->ahead = f->ahead_launched = false;
+    f->par = 1;   // the first image of a sequence counts as an even frame
     const uint8_t *d_img = image;
     if (!image_on_device) {
-        VOHIP_HIP(ctx, hipMemcpyAsync(f->img, image, (size_t)f->rows * f->cols, hipMemcpyHostToDevice, s));
-        d_img = f->img;
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->img[0], image, (size_t)f->rows * f->cols, hipMemcpyHostToDevice, s));
+        d_img = f->img[0];
     }
     VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_prev, d_img, f->rows, f->cols, f->colmajor, f->prm.klt_levels));
     VOHIP_HIP(ctx, hipMemsetAsync(f->cnt, 0, sizeof(int) * N_COUNTERS, s));
@@ -1026,8 +1099,8 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     int *hc = pin_cnt(f);
     hc[0] = n;
     VOHIP_HIP(ctx, hipMemcpyAsync(f->cnt + N_L_END, hc, sizeof(int), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(next_tracks_kernel, dim3(blocks256(n)), dim3(256), 0, s, f->L_rc, f->capL, f->L_xy, f->C_rc,
-                       f->capC, f->C_xy, f->cnt);
+    hipLaunchKernelGGL(init_rows_kernel, dim3(blocks256(n)), dim3(256), 0, s, f->L_rc, n, f->capU, f->U_xy[0], f->U_live[0],
+                       f->srcL);
     VOHIP_HIP(ctx, hipGetLastError());
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
     f->n_L = n;
@@ -1039,6 +1112,13 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
 int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, const double *u3, int h,
                      const double *u8, vohip_frame_pose *pose, vohip_frame_counts *counts)
 {
+    return vohip_frame_step_ahead(f, image, image_on_device, nullptr, 0, u3, h, u8, pose, counts);
+}
+
+int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
+                           int next_on_device, const double *u3, int h, const double *u8, vohip_frame_pose *pose,
+                           vohip_frame_counts *counts)
+{
     if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
     vohip_ctx *ctx = f->ctx;
     VOHIP_REQUIRE(ctx, image && u3 && pose && counts, "NULL argument");
@@ -1049,40 +1129,71 @@ int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, 
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
-    const uint8_t *d_img = image;
-    if (!image_on_device) {
-        VOHIP_HIP(ctx, hipMemcpyAsync(f->img, image, (size_t)f->rows * f->cols, hipMemcpyHostToDevice, s));
-        d_img = f->img;
-    }
+    const int par = f->par;
+    const size_t img_bytes = (size_t)f->rows * f->cols;
     f->have_map = f->n_C > 0;   // main_demo.m:406
     f->evaluated = 0;
     f->stage = 1;
-    // The order of the enqueues follows the critical path: the context's stream (pyramid ->
-    // landmark tracker -> localisation) is fed first at every step, the two long trackers start
-    // as early as possible, the short kernels of the other streams are enqueued while they run.
+    f->ahead_launched = next_image != nullptr;
+    // The order of the enqueues follows the critical paths: what feeds the trackers first, then the
+    // context's stream (localisation), the short kernels of the other streams while those run.
     if (f->trace) (void)hipEventRecord(f->tr[0], s);
-    VOHIP_HIP(ctx, hipEventRecord(f->ev_img, s));
-    // the localisation draws go up first: they are needed right after the tracker
+    // the draws go up on the second stream while the trackers run
     std::memcpy(pin_u3(f), u3, sizeof(double) * 3 * (size_t)h);
-    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3, pin_u3(f), sizeof(double) * 3 * (size_t)h, hipMemcpyHostToDevice, s));
-    VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
-    // landmark tracker (main_demo.m:380) and the selection of the valid tracks (:381, :387)
-    // and the candidate tracker (update_landmarks.m:10) in the same launch: same two images, and a
-    // launch of this kernel lasts as long as its slowest track however many tracks it carries
-    VOHIP_TRY(vohip_klt_enqueue2(ctx, f->slot_prev, f->slot_cur, f->L_xy, f->capL, f->n_L, nullptr, f->kL_out,
-                                 f->kL_valid, nullptr, f->C_xy, f->capC, f->have_map ? f->n_C : 0, f->kC_out,
-                                 f->kC_valid, p.klt_block, p.klt_max_iter, p.klt_max_bidir_error));
-    VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));      // the second stream starts from here
+    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3, pin_u3(f), sizeof(double) * 3 * (size_t)h, hipMemcpyHostToDevice, f->side));
+    if (f->have_map) {
+        const size_t T8 = 8 * (size_t)p.fm_trials;
+        std::memcpy(pin_u8(f), u8, sizeof(double) * T8);
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, pin_u8(f), sizeof(double) * T8, hipMemcpyHostToDevice, f->side));
+    }
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_draws, f->side));
+    const uint8_t *d_img = image_on_device ? image : f->img[par];
+    const uint8_t *d_next = next_image ? (next_on_device ? next_image : f->img[par ^ 1]) : nullptr;
+    if (!f->ahead) {
+        // nothing was done ahead: this image, its pyramid and its corners
+        if (!image_on_device) VOHIP_HIP(ctx, hipMemcpyAsync(f->img[par], image, img_bytes, hipMemcpyHostToDevice, s));
+        VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));
+        VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
+    } else {
+        VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_img, 0));   // the pyramid the previous call built
+    }
+    // the trackers from the previous image (main_demo.m:380, update_landmarks.m:10) over the rows the
+    // last frame kept, in one launch: it lasts as long as its slowest track however many tracks it carries
+    if (f->trace) (void)hipEventRecord(f->tr[7], s);
+    {
+        const vohip_klt_set sets[2] = {
+            {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcL, nullptr, nullptr, f->capU, f->n_L, 0, 0},
+            {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcC, nullptr, nullptr, f->capU,
+             f->have_map ? f->n_C : 0, 0, f->capL}};
+        VOHIP_TRY(vohip_klt_enqueue_sets(ctx, f->slot_prev, f->slot_cur, sets, 2, p.klt_block, p.klt_max_iter,
+                                         p.klt_max_bidir_error));
+    }
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_adv, s));      // the other streams start from here
+    if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, f->ev_pyr));
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_draws, 0));
     if (f->trace) (void)hipEventRecord(f->tr[1], s);   // trackers done
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
-    hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->kL_out, f->capL, f->kL_valid,
-                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->cnt, f->dv, f->u3, h0, f->samples3);
+    // the selection of the valid landmark tracks (main_demo.m:381, :387)
+    hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->U_xy[par], f->capU, f->U_live[par],
+                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->rowv, f->cnt, f->dv, f->u3, h0, f->samples3);
     VOHIP_HIP(ctx, hipGetLastError());
     VOHIP_TRY(enqueue_localize(f, u3, h, h0));
     if (f->trace) (void)hipEventRecord(f->tr[2], s);   // pose refined
-    VOHIP_TRY(enqueue_detection(f, d_img));
     VOHIP_TRY(enqueue_side_filter(f, u8));
     VOHIP_TRY(enqueue_tail(f));
+    // (enqueued last: nothing of this frame waits for it)
+    if (next_image) {
+        // own stream, once the trackers have read the older pyramid for the last time: the next image
+        // and its pyramid, so that the next call starts with its trackers
+        stream_swap sw(ctx, f->trk);
+        VOHIP_HIP(ctx, hipStreamWaitEvent(f->trk, f->ev_adv, 0));
+        if (!next_on_device)
+            VOHIP_HIP(ctx, hipMemcpyAsync(f->img[par ^ 1], next_image, img_bytes, hipMemcpyHostToDevice, f->trk));
+        VOHIP_HIP(ctx, hipEventRecord(f->ev_next, f->trk));
+        VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_prev, d_next, f->rows, f->cols, f->colmajor, p.klt_levels));
+        VOHIP_HIP(ctx, hipEventRecord(f->ev_img, f->trk));
+    }
+    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, f->ev_next));
     return complete_frame(f, h, pose, counts);
 }
 

@@ -28,6 +28,8 @@
 #include "vohip_internal.h"
 #include "wave_reduce.h"
 
+#include <cstring>
+
 namespace {
 
 constexpr int MAX_LEVELS = 8;
@@ -258,38 +260,51 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
 
 // pts_xy / out_xy: x column then y column with leading dimension ld, MATLAB's (x, y), 1-based.
 // swap_xy: the image is a column-major MATLAB image, so a = y - 1, b = x - 1; otherwise a = x - 1,
-// b = y - 1.  The point count is n, or *n_dev when n_dev is given (n then only sizes the grid).
-// A launch can carry a second, independent point set (the frame pipeline tracks landmarks and
-// candidates between the same two images in one launch): workgroups past the first set serve it.
-struct klt_set {
-    const double *pts_xy;
-    double *out_xy;
-    uint8_t *valid;
-    double *fb_err;
-    int ld, n;
+// b = y - 1.  A launch carries up to three independent point sets between the same two images
+// (the frame pipeline tracks landmarks, candidates and fresh detections in one launch): workgroups
+// past one set serve the next.
+struct klt_sets {
+    vohip_klt_set s[3];
 };
 
 template <int W>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 21 ? 3 : 2, W <= 21 ? 3 : 2))) void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_set S0, klt_set S1,
-                                                       const int *__restrict__ n_dev, int swap_xy,
-                                                       int max_iter, double max_bidir,
-                                                       unsigned long long *__restrict__ stats)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 21 ? 3 : 2, W <= 21 ? 3 : 2)))
+void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_iter, double max_bidir,
+                      unsigned long long *__restrict__ stats)
 {
     using C = klt_cfg<W>;
     __shared__ float sI[C::SI * C::SI];
     __shared__ float sJ[C::SJ * C::SJ];
-    int i = blockIdx.x;
-    const bool second = i >= S0.n;
-    if (second) i -= S0.n;
-    const double *__restrict__ pts_xy = second ? S1.pts_xy : S0.pts_xy;
-    double *__restrict__ out_xy = second ? S1.out_xy : S0.out_xy;
-    uint8_t *__restrict__ valid = second ? S1.valid : S0.valid;
-    double *__restrict__ fb_err = second ? S1.fb_err : S0.fb_err;
-    const int ld = second ? S1.ld : S0.ld;
-    int n = second ? S1.n : S0.n;
-    if (n_dev && !second) n = *n_dev;
+    int i = blockIdx.x, k = 0;
+    if (i >= S.s[0].n) {
+        i -= S.s[0].n;
+        k = 1;
+        if (i >= S.s[1].n) {
+            i -= S.s[1].n;
+            k = 2;
+        }
+    }
+    // (selected field by field: the sets are kernel arguments, an indexed copy would go through scratch)
+#define KLT_PICK(field) (k == 0 ? S.s[0].field : k == 1 ? S.s[1].field : S.s[2].field)
+    const double *__restrict__ pts_xy = KLT_PICK(pts_xy);
+    double *__restrict__ out_xy = KLT_PICK(out_xy);
+    uint8_t *__restrict__ valid = KLT_PICK(valid);
+    double *__restrict__ fb_err = KLT_PICK(fb_err);
+    const int32_t *__restrict__ rows = KLT_PICK(rows);
+    const uint8_t *__restrict__ live = KLT_PICK(live);
+    const int *__restrict__ n_dev = KLT_PICK(n_dev);
+    const int ld = KLT_PICK(ld), base = KLT_PICK(base), out_base = KLT_PICK(out_base);
+    int n = KLT_PICK(n);
+#undef KLT_PICK
+    if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
-    const double x = pts_xy[i] - 1.0, y = pts_xy[ld + i] - 1.0;
+    const int r = rows ? rows[i] : base + i;
+    const int o = out_base < 0 ? r : out_base + i;
+    if (live && !live[r]) {
+        if (threadIdx.x == 0) valid[o] = 0;
+        return;
+    }
+    const double x = pts_xy[r] - 1.0, y = pts_xy[ld + r] - 1.0;
     const double pa = swap_xy ? y : x, pb = swap_xy ? x : y;
     double qa, qb, ra, rb;
     int iters = 0;
@@ -299,10 +314,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 21 ? 3 
     const double err = sqrt(ea * ea + eb * eb);
     const bool inside = qa >= 0.0 && qa <= (double)(P.A[0] - 1) && qb >= 0.0 && qb <= (double)(P.B[0] - 1);
     if (threadIdx.x == 0) {
-        out_xy[i] = (swap_xy ? qb : qa) + 1.0;
-        out_xy[ld + i] = (swap_xy ? qa : qb) + 1.0;
-        valid[i] = (ok_f && ok_b && inside && err <= max_bidir) ? 1 : 0;
-        if (fb_err) fb_err[i] = err;
+        out_xy[o] = (swap_xy ? qb : qa) + 1.0;
+        out_xy[ld + o] = (swap_xy ? qa : qb) + 1.0;
+        valid[o] = (ok_f && ok_b && inside && err <= max_bidir) ? 1 : 0;
+        if (fb_err) fb_err[o] = err;
         if (stats) {   // work counters: tracks, Gauss-Newton iterations (both directions, all levels)
             atomicAdd(stats, 1ull);
             atomicAdd(stats + 1, (unsigned long long)iters);
@@ -402,23 +417,26 @@ int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double 
                       const int *d_n, int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
                       uint8_t *d_valid, double *d_fb_err)
 {
-    return vohip_klt_enqueue2(ctx, slot_prev, slot_cur, d_pts_xy, ld, n, d_n, d_out_xy, d_valid, d_fb_err, nullptr, 0, 0,
-                              nullptr, nullptr, block_size, max_iter, max_bidir_error);
+    const vohip_klt_set set = {d_pts_xy, d_out_xy, d_valid, d_fb_err, nullptr, nullptr, d_n, ld, n, 0, -1};
+    return vohip_klt_enqueue_sets(ctx, slot_prev, slot_cur, &set, 1, block_size, max_iter, max_bidir_error);
 }
 
-int vohip_klt_enqueue2(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int ld, int n,
-                       const int *d_n, double *d_out_xy, uint8_t *d_valid, double *d_fb_err, const double *d_pts2,
-                       int ld2, int n2, double *d_out2, uint8_t *d_valid2, int block_size, int max_iter,
-                       double max_bidir_error)
+int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vohip_klt_set *sets, int nsets,
+                           int block_size, int max_iter, double max_bidir_error)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
-    VOHIP_REQUIRE(ctx, n >= 0 && n2 >= 0 && max_iter >= 1 && ld >= n && ld2 >= n2, "bad argument");
-    if (n + n2 == 0) return VOHIP_OK;
-    VOHIP_REQUIRE(ctx, (n == 0 || (d_pts_xy && d_out_xy && d_valid)) && (n2 == 0 || (d_pts2 && d_out2 && d_valid2)),
-                  "NULL array");
-    VOHIP_REQUIRE(ctx, !(d_n && n2 > 0), "a device-side count cannot be combined with a second point set");
-    const klt_set S0 = {d_pts_xy, d_out_xy, d_valid, d_fb_err, ld, n};
-    const klt_set S1 = {d_pts2, d_out2, d_valid2, nullptr, ld2, n2};
+    VOHIP_REQUIRE(ctx, sets && nsets >= 1 && nsets <= 3 && max_iter >= 1, "bad argument");
+    klt_sets S;
+    std::memset(&S, 0, sizeof(S));
+    int total = 0;
+    for (int q = 0; q < nsets; ++q) {
+        const vohip_klt_set &t = sets[q];
+        VOHIP_REQUIRE(ctx, t.n >= 0 && t.base >= 0 && (t.rows || t.ld >= t.base + t.n), "bad point set");
+        VOHIP_REQUIRE(ctx, t.n == 0 || (t.pts_xy && t.out_xy && t.valid), "NULL array");
+        S.s[q] = t;
+        total += t.n;
+    }
+    if (total == 0) return VOHIP_OK;
     pyr_desc P, Q;
     VOHIP_TRY(vohip_pyramid_desc(ctx, slot_prev, P));
     VOHIP_TRY(vohip_pyramid_desc(ctx, slot_cur, Q));
@@ -434,11 +452,11 @@ int vohip_klt_enqueue2(vohip_ctx *ctx, int slot_prev, int slot_cur, const double
     }
     unsigned long long *d_stats = ctx->opt_klt_stats ? (unsigned long long *)ctx->bufs[B_KLT_STATS].ptr : nullptr;
     if (block_size == 21)
-        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(n + n2), dim3(64), 0, ctx->stream, P, Q, S0, S1, d_n, swap_xy,
-                           max_iter, max_bidir_error, d_stats);
+        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(total), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
+                           max_bidir_error, d_stats);
     else if (block_size == 31)
-        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(n + n2), dim3(64), 0, ctx->stream, P, Q, S0, S1, d_n, swap_xy,
-                           max_iter, max_bidir_error, d_stats);
+        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(total), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
+                           max_bidir_error, d_stats);
     else
         return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "BlockSize %d not built (21 and 31 are)", block_size);
     VOHIP_HIP(ctx, hipGetLastError());
@@ -455,7 +473,10 @@ int vohip_klt_stats(vohip_ctx *ctx, long long *tracks, long long *iterations, in
         VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         VOHIP_HIP(ctx, hipDeviceSynchronize());   // trackers may run on other streams of this context's owner
         VOHIP_HIP(ctx, hipMemcpy(h, ctx->bufs[B_KLT_STATS].ptr, sizeof(h), hipMemcpyDeviceToHost));
-        if (reset) VOHIP_HIP(ctx, hipMemset(ctx->bufs[B_KLT_STATS].ptr, 0, 64));
+        if (reset) {   // the fill may run asynchronously: finish it before a tracker can be launched
+            VOHIP_HIP(ctx, hipMemset(ctx->bufs[B_KLT_STATS].ptr, 0, 64));
+            VOHIP_HIP(ctx, hipDeviceSynchronize());
+        }
     }
     if (tracks) *tracks = (long long)h[0];
     if (iterations) *iterations = (long long)h[1];

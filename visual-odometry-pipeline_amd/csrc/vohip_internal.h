@@ -105,10 +105,24 @@ static inline int vohip_download(vohip_ctx *ctx, void *dst, const void *dsrc, si
 int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int ld, int n,
                       const int *d_n, int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
                       uint8_t *d_valid, double *d_fb_err);
-int vohip_klt_enqueue2(vohip_ctx *ctx, int slot_prev, int slot_cur, const double *d_pts_xy, int ld, int n,
-                       const int *d_n, double *d_out_xy, uint8_t *d_valid, double *d_fb_err, const double *d_pts2,
-                       int ld2, int n2, double *d_out2, uint8_t *d_valid2, int block_size, int max_iter,
-                       double max_bidir_error);
+// One point set of a tracker launch.  Track i of the set is read from row r = rows ? rows[i] :
+// base + i of pts_xy (x column then y column, leading dimension ld) and of live; its results go to row
+// out_base + i of out_xy / valid / fb_err, or to row r when out_base < 0.  Rows whose `live` byte is 0
+// are not tracked (valid = 0).
+struct vohip_klt_set {
+    const double *pts_xy;
+    double *out_xy;
+    uint8_t *valid;
+    double *fb_err;        // may be NULL
+    const int32_t *rows;   // may be NULL
+    const uint8_t *live;   // may be NULL
+    const int *n_dev;      // may be NULL; else the device-side count (<= n, n then only sizes the grid)
+    int ld, n, base, out_base;
+};
+// Up to three sets in one launch (a launch lasts as long as its slowest track however many tracks
+// it carries).
+int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vohip_klt_set *sets, int nsets,
+                           int block_size, int max_iter, double max_bidir_error);
 int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                          const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts);
 int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,

@@ -72,7 +72,7 @@ class VOPipelineDevice:
         ptr, on_dev, keep = self._image_ptr(first_image)
         self.ctx.check(lib.vohip_frame_reset(self._h, ptr, on_dev, dptr(X), None, dptr(P_rc), X.shape[0],
                                              dptr(colmajor(T))))
-        del keep
+        self._keep_images = (keep, None)
         self.est_trans = [T[:3, 3].copy()]
         self.est_rot = [T[:3, :3].reshape(-1, order="F").copy()]
         self.num_X, self.num_C, self.num_new = [X.shape[0]], [0], [0]
@@ -93,23 +93,27 @@ class VOPipelineDevice:
             img = np.asfortranarray(img) if self._colmajor else np.ascontiguousarray(img)
         return C.c_void_p(img.ctypes.data), 0, img
 
-    def process_frame(self, image):
+    def process_frame(self, image, next_image=None):
+        """One frame of the loop (main_demo.m:377-427).  next_image: the frame after this one, when the
+        caller already holds it (a stored sequence): its transfer, pyramid and corner detection then run
+        beside this frame's localisation; the results do not change, and the next call must pass that image."""
         lib = _lib.load()
         ptr, on_dev, keep = self._image_ptr(image)
+        nptr, non_dev, nkeep = self._image_ptr(next_image) if next_image is not None else (None, 0, None)
         pose, counts = _lib.FramePose(), _lib.FrameCounts()
         have_map = self.num_C[-1] > 0                                                       # :406
         u8 = self.rng_map.random((self.params.fm_trials, 8)) if have_map else None          # update_landmarks.m:13
         state = self.rng.bit_generator.state
         have = 104
         u3 = self.rng.random((have, 3))                                                     # :387-388
-        st = lib.vohip_frame_step(self._h, ptr, on_dev, dptr(u3), have, dptr(u8) if have_map else None,
-                                  C.byref(pose), C.byref(counts))
+        st = lib.vohip_frame_step_ahead(self._h, ptr, on_dev, nptr, non_dev, dptr(u3), have,
+                                        dptr(u8) if have_map else None, C.byref(pose), C.byref(counts))
         while st == VOHIP_SAMPLES_EXHAUSTED and have < MAX_ITERATIONS:
             have = min(max(8 * have, int(np.ceil(pose.num_iterations)) + 8), MAX_ITERATIONS)
             self.rng.bit_generator.state = state
             u3 = self.rng.random((have, 3))         # the same leading draws, then more
             st = lib.vohip_frame_retry(self._h, dptr(u3), have, C.byref(pose), C.byref(counts))
-        del keep
+        self._keep_images = (keep, nkeep)   # a host image handed over ahead is read until the next call returns
         self.rng.bit_generator.state = state
         if pose.n_iter > 0:
             self.rng.random((pose.n_iter, 3))       # the generator as n_iter executed iterations leave it
