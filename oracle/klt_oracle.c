@@ -26,8 +26,9 @@
  *    (G^-1 = adj(G) * (1 / det G)),
  *    stopping after a step shorter than 0.01 px, or when a step cancels the previous one to
  *    within 0.01 px (oscillation: half of the last step is taken back).  G is summed in double; the right-hand side is
- *    summed in float within each of 64 pixel groups (pixel q in group q mod 64, increasing q,
- *    fmaf) and across the groups by a fixed float tree: fours ((g0+g1)+(g2+g3)), pairs of fours,
+ *    summed in float within each of 64 pixel groups (the window's rows are split into 64 / W bands;
+ *    a group is one window column within one band, summed down the column with fmaf; W <= 64) and
+ *    across the groups by a fixed float tree: fours ((g0+g1)+(g2+g3)), pairs of fours,
  *    pairs of eights, then the four sixteens as ((r0+r1)+r2)+r3.
  *    The displacement doubles between levels.
  *  - A point is valid iff at level 0 G is well conditioned in both directions
@@ -174,13 +175,17 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
                 const double ta = ca + da, tb = cb + db;
                 const int ja = (int)floor(ta), jb = (int)floor(tb);
                 const float ga = (float)(ta - ja), gb = (float)(tb - jb);
-                /* right-hand side: window pixel q = (wb + half) W + (wa + half) belongs to group
-                 * q mod 64; each group is summed in float with fmaf in increasing q, the 64 group
-                 * sums are added in float by the fixed tree of tree64() */
+                /* right-hand side: the window's rows are split into 64 / W bands of rpl rows; band g of
+                 * window column c is group g W + c (the remaining groups are empty); each group is
+                 * summed in float with fmaf down its column, the 64 group sums are added in float by
+                 * the fixed tree of tree64() */
+                const int bands = 64 / W, rpl = (W + bands - 1) / bands;
                 float pa_[64], pb_[64];
                 for (int grp = 0; grp < 64; ++grp) {
                     float baf = 0.f, bbf = 0.f;
-                    for (int k = grp; k < W * W; k += 64) {
+                    const int band = grp / W, col = grp % W;
+                    for (int row = band * rpl; grp < bands * W && row < (band + 1) * rpl && row < W; ++row) {
+                        int k = row * W + col;
                         int wb = k / W - half, wa = k % W - half;
                         float j = bilinear(Q[l], A, B, ja + wa, jb + wb, ga, gb);
                         float e = T[k] - j;

@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libvohip.so")
+# VOHIP_LIB: another build of the library (kernel tuning experiments)
+LIB_PATH = os.environ.get("VOHIP_LIB") or os.path.join(HERE, "lib", "libvohip.so")
 
 VOHIP_OK = 0
 VOHIP_ERR_INVALID_ARGUMENT = 1

@@ -13,18 +13,19 @@
 //
 // klt_track_kernel: ONE WAVEFRONT PER TRACK, forward then backward pass in the same launch.
 //   per pyramid level (coarse to fine):
-//     * the (W+3)^2 neighbourhood of the point in the previous image is staged in LDS; each lane
-//       owns ceil(W^2/64) window pixels and keeps their template value and central-difference
-//       gradients in registers;
-//     * G = sum [gx gx, gx gy; gy gy] and, per iteration, b = sum e [gx; gy] are accumulated
-//       in fp64 per lane and reduced across the wavefront with DPP row operations + readlane
+//     * the (W+3)^2 neighbourhood of the point in the previous image is staged in LDS; the window's
+//       rows are split into 64 / W bands and a lane owns one window column within one band (7
+//       vertically consecutive pixels for W = 21), so the taps and the row-wise interpolations that
+//       neighbouring pixels share stay in registers; it keeps the template values and the
+//       central-difference gradients of its pixels in registers;
+//     * G = sum [gx gx, gx gy; gy gy] (fp64) and, per iteration, b = sum e [gx; gy] (fp32) are
+//       accumulated per lane and reduced across the wavefront with DPP row operations + readlane
 //       (every lane ends up with the same bits, so the Gauss-Newton step is wave-uniform);
 //     * a (W+12)^2 region of the current image around the running estimate is staged in LDS and
 //       re-used by successive iterations while the estimate stays within +-5 px of its centre.
 //   Pixel arithmetic is fp32 with explicit fmaf (bit-identical to a scalar evaluation of the
-//   same formulas).  G is summed in fp64; the right-hand side b is summed per lane in fp32 over
-//   the lane's <= ceil(W^2/64) pixels (pixel q belongs to lane q mod 64, in increasing q) and
-//   across lanes in fp64.
+//   same formulas).  G is summed in fp64; the right-hand side b is summed per lane in fp32 down the
+//   lane's column and across lanes by a fixed fp32 tree.
 #include "vohip_internal.h"
 #include "wave_reduce.h"
 
@@ -90,8 +91,12 @@ template <int W>
 struct klt_cfg {
     static constexpr int HALF = W / 2;
     static constexpr int NPIX = W * W;
-    static constexpr int PER_LANE = (NPIX + 63) / 64;
+    // window pixel (wb, wa) belongs to lane (wb / RPL) * W + wa: a lane owns RPL vertically
+    // consecutive pixels of one window column, so neighbouring pixels share their taps in registers
+    static constexpr int GROUPS = 64 / W;                     // row groups (3 for W = 21, 2 for W = 31)
+    static constexpr int RPL = (W + GROUPS - 1) / GROUPS;     // rows per lane (7 and 16)
     static constexpr int SI = W + 3;        // template neighbourhood side
+    static constexpr int SI_ROWS = GROUPS * RPL + 3;          // rows of LDS behind it (the last ones only feed masked pixels)
     static constexpr int MARG = 5;          // px the estimate may drift before the region is re-staged
     static constexpr int SJ = W + 2 * MARG + 2;
 };
@@ -105,17 +110,15 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
     const int lane = threadIdx.x;
     double da = 0.0, db = 0.0;
     bool ok0 = true;
-    // window pixels owned by this lane: q = lane + 64 k  ->  (wb, wa) = (q / W, q % W)
-    int offI[C::PER_LANE], offJ[C::PER_LANE];
-    bool live[C::PER_LANE];
+    // this lane's pixels: window column wa, rows wb0 .. wb0 + RPL - 1 (those past the window, and the
+    // lanes past the last column group, are masked: they read valid LDS and contribute zeros)
+    const bool lane_on = lane < C::GROUPS * W;
+    const int grp = lane_on ? lane / W : 0, wa = lane_on ? lane - grp * W : 0, wb0 = grp * C::RPL;
+    bool live[C::RPL];
 #pragma unroll
-    for (int k = 0; k < C::PER_LANE; ++k) {
-        const int q = lane + 64 * k;
-        live[k] = q < C::NPIX;
-        const int wb = live[k] ? q / W : 0, wa = live[k] ? q - wb * W : 0;
-        offI[k] = (wb + 1) * C::SI + (wa + 1);
-        offJ[k] = wb * C::SJ + wa;
-    }
+    for (int k = 0; k < C::RPL; ++k) live[k] = lane_on && wb0 + k < W;
+    const int offI = (wb0 + 1) * C::SI + (wa + 1);   // top-left tap of the lane's first pixel
+    const int offJ = wb0 * C::SJ + wa;
     for (int l = P.levels - 1; l >= 0; --l) {
         const int A = P.A[l], B = P.B[l];
         const float *__restrict__ Pl = P.lvl[l];
@@ -148,23 +151,49 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
         }
         __syncthreads();
 
-        float T[C::PER_LANE], GX[C::PER_LANE], GY[C::PER_LANE];
+        float T[C::RPL], GX[C::RPL], GY[C::RPL];
         double gxx = 0.0, gxy = 0.0, gyy = 0.0;
+        {
+            // S(q, j): the previous image sampled at window row wb0 + q, column wa - 1 + j.  Tap rows are
+            // interpolated along a first (h; tap row r serves the samples of rows r - 1 and r), so
+            // S(r - 1, .) is complete at tap row r: pixel r - 1 gets its value and its a-gradient there,
+            // pixel r - 2 its b-gradient (S(r - 1, centre) is the sample below it).
+            const float *c = sI + offI;
+            float h_prev[3], s_prev = 0.f, s_cur = 0.f, sm = 0.f, sp = 0.f;
 #pragma unroll
-        for (int k = 0; k < C::PER_LANE; ++k) {
-            // lanes past the window read pixel (0, 0) and have their template zeroed: no branches
-            const float *c = sI + offI[k];
-            auto samp = [&](const float *p) { return bilerp(p[0], p[1], p[C::SI], p[C::SI + 1], fa, fb); };
-            const float v = samp(c);
-            const float ap = samp(c + 1), am = samp(c - 1);
-            const float bp = samp(c + C::SI), bm = samp(c - C::SI);
-            const float gx = live[k] ? (ap - am) * 0.5f : 0.f, gy = live[k] ? (bp - bm) * 0.5f : 0.f;
-            T[k] = live[k] ? v : 0.f;
-            GX[k] = gx;
-            GY[k] = gy;
-            gxx += (double)gx * (double)gx;
-            gxy += (double)gx * (double)gy;
-            gyy += (double)gy * (double)gy;
+            for (int r = -1; r <= C::RPL + 1; ++r) {
+                const float *row = c + r * C::SI;
+                const float t0 = row[-1], t1 = row[0], t2 = row[1], t3 = row[2];
+                float h[3];
+                h[0] = __builtin_fmaf(fa, t1 - t0, t0);
+                h[1] = __builtin_fmaf(fa, t2 - t1, t1);
+                h[2] = __builtin_fmaf(fa, t3 - t2, t2);
+                if (r >= 0) {
+                    // samples of row r - 1 (every column) are complete now
+                    const float s_next = __builtin_fmaf(fb, h[1] - h_prev[1], h_prev[1]);   // S(r - 1, centre)
+                    sm = __builtin_fmaf(fb, h[0] - h_prev[0], h_prev[0]);
+                    sp = __builtin_fmaf(fb, h[2] - h_prev[2], h_prev[2]);
+                    if (r >= 2) {
+                        const int k = r - 2;
+                        const float gy = live[k] ? (s_next - s_prev) * 0.5f : 0.f;
+                        GY[k] = gy;
+                        gyy += (double)gy * (double)gy;
+                        gxy += (double)GX[k] * (double)gy;
+                    }
+                    if (r >= 1 && r <= C::RPL) {
+                        const int k = r - 1;
+                        const float gx = live[k] ? (sp - sm) * 0.5f : 0.f;
+                        T[k] = live[k] ? s_next : 0.f;
+                        GX[k] = gx;
+                        gxx += (double)gx * (double)gx;
+                    }
+                    s_prev = s_cur;
+                    s_cur = s_next;
+                }
+                h_prev[0] = h[0];
+                h_prev[1] = h[1];
+                h_prev[2] = h[2];
+            }
         }
         gxx = wave_sum(gxx);
         gxy = wave_sum(gxy);
@@ -208,26 +237,26 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                     }
                     __syncthreads();
                 }
-                const float *org = sJ + (jb - cjb + C::MARG) * C::SJ + (ja - cja + C::MARG);
-                // all LDS reads first, so that their latencies overlap
-                float c00[C::PER_LANE], c01[C::PER_LANE], c10[C::PER_LANE], c11[C::PER_LANE];
+                const float *org = sJ + (jb - cjb + C::MARG) * C::SJ + (ja - cja + C::MARG) + offJ;
+                // all LDS reads first, so that their latencies overlap: RPL + 1 tap rows, two taps each
+                float t0[C::RPL + 1], t1[C::RPL + 1];
 #pragma unroll
-                for (int k = 0; k < C::PER_LANE; ++k) {
-                    const float *p = org + offJ[k];
-                    c00[k] = p[0];
-                    c01[k] = p[1];
-                    c10[k] = p[C::SJ];
-                    c11[k] = p[C::SJ + 1];
+                for (int r = 0; r <= C::RPL; ++r) {
+                    t0[r] = org[r * C::SJ];
+                    t1[r] = org[r * C::SJ + 1];
                 }
-                // per-lane partial sums in fp32 (at most PER_LANE fused multiply-adds, fixed order),
-                // then a fixed fp32 tree across the wavefront
+                // per-lane partial sums in fp32 (RPL fused multiply-adds, rows in increasing order), then
+                // a fixed fp32 tree across the wavefront
                 float baf = 0.f, bbf = 0.f;
+                float h0 = __builtin_fmaf(ga, t1[0] - t0[0], t0[0]);
 #pragma unroll
-                for (int k = 0; k < C::PER_LANE; ++k) {
-                    const float j = bilerp(c00[k], c01[k], c10[k], c11[k], ga, gb);
+                for (int k = 0; k < C::RPL; ++k) {
+                    const float h1 = __builtin_fmaf(ga, t1[k + 1] - t0[k + 1], t0[k + 1]);
+                    const float j = __builtin_fmaf(gb, h1 - h0, h0);
                     const float e = T[k] - j;
                     baf = __builtin_fmaf(e, GX[k], baf);
                     bbf = __builtin_fmaf(e, GY[k], bbf);
+                    h0 = h1;
                 }
                 const double ba = (double)vohip_dev::wave_sum_f32(baf), bb = (double)vohip_dev::wave_sum_f32(bbf);
                 const double sa = (gyy * ba - gxy * bb) * inv_det;
@@ -273,7 +302,7 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
                       unsigned long long *__restrict__ stats)
 {
     using C = klt_cfg<W>;
-    __shared__ float sI[C::SI * C::SI];
+    __shared__ float sI[C::SI_ROWS * C::SI + 8];
     __shared__ float sJ[C::SJ * C::SJ];
     int i = blockIdx.x, k = 0;
     if (i >= S.s[0].n) {
