@@ -29,7 +29,7 @@
  *    summed in float within each of 64 pixel groups (the window's rows are split into 64 / W bands;
  *    a group is one window column within one band, summed down the column with fmaf; W <= 64) and
  *    across the groups by a fixed float tree: fours ((g0+g1)+(g2+g3)), pairs of fours,
- *    pairs of eights, then the four sixteens as ((r0+r1)+r2)+r3.
+ *    pairs of eights, pairs of sixteens ((r0+r1)+(r2+r3)).
  *    The displacement doubles between levels.
  *  - A point is valid iff at level 0 G is well conditioned in both directions
  *    (lambda_min(G) / W^2 >= 1e-3), the forward result lies inside the image, and the
@@ -58,7 +58,7 @@ static float tree64(const float *g)
         }
         r[n] = h[0] + h[1];
     }
-    return ((r[0] + r[1]) + r[2]) + r[3];
+    return (r[0] + r[1]) + (r[2] + r[3]);
 }
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

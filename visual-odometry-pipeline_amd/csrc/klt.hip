@@ -21,8 +21,9 @@
 //     * G = sum [gx gx, gx gy; gy gy] (fp64) and, per iteration, b = sum e [gx; gy] (fp32) are
 //       accumulated per lane and reduced across the wavefront with DPP row operations + readlane
 //       (every lane ends up with the same bits, so the Gauss-Newton step is wave-uniform);
-//     * a (W+12)^2 region of the current image around the running estimate is staged in LDS and
-//       re-used by successive iterations while the estimate stays within +-5 px of its centre.
+//     * a (W+8)^2 region of the current image around the running estimate is staged in LDS and
+//       re-used by successive iterations while the estimate stays within +-3 px of its centre; the lane's
+//       taps of it stay in registers while the integer part of the estimate does not change.
 //   Pixel arithmetic is fp32 with explicit fmaf (bit-identical to a scalar evaluation of the
 //   same formulas).  G is summed in fp64; the right-hand side b is summed per lane in fp32 down the
 //   lane's column and across lanes by a fixed fp32 tree.
@@ -87,6 +88,15 @@ __device__ __forceinline__ float bilerp(float i00, float i01, float i10, float i
 
 __device__ __forceinline__ double wave_sum(double v) { return vohip_dev::wave_sum_f64(v); }
 
+// (int)min(max(t, -1e6), 1e6) for a finite integral t: the conversion instruction saturates, so the
+// bounds can be applied to the integer.
+__device__ __forceinline__ int bounded_int(double t)
+{
+    int j;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(j) : "v"(t));
+    return min(max(j, -1000000), 1000000);
+}
+
 template <int W>
 struct klt_cfg {
     static constexpr int HALF = W / 2;
@@ -97,7 +107,9 @@ struct klt_cfg {
     static constexpr int RPL = (W + GROUPS - 1) / GROUPS;     // rows per lane (7 and 16)
     static constexpr int SI = W + 3;        // template neighbourhood side
     static constexpr int SI_ROWS = GROUPS * RPL + 3;          // rows of LDS behind it (the last ones only feed masked pixels)
-    static constexpr int MARG = 5;          // px the estimate may drift before the region is re-staged
+    // px the estimate may drift before the region is re-staged (measured: 3 beats 1..11; wider regions
+    // cost every track more staging than they save the few wandering ones)
+    static constexpr int MARG = 3;
     static constexpr int SJ = W + 2 * MARG + 2;
 };
 
@@ -207,56 +219,65 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
             int cja = 0, cjb = 0;
             bool staged = false;
             double pa_prev = 0.0, pb_prev = 0.0;
+            // The lane's taps of the current image stay in registers while the integer part of the
+            // estimate does not change (most steps are shorter than a pixel): t0 = left tap, dt = right
+            // minus left, per tap row.
+            double fta_taps = __builtin_nan(""), ftb_taps = __builtin_nan("");
+            float t0[C::RPL + 1], dt[C::RPL + 1];
             for (int it = 0; it < max_iter; ++it) {
                 const double ta = ca + da, tb = cb + db;
                 const double fta = floor(ta), ftb = floor(tb);
-                // positions far outside the image cannot come back; keep integer math bounded
-                const int ja = (int)fmin(fmax(fta, -1.0e6), 1.0e6), jb = (int)fmin(fmax(ftb, -1.0e6), 1.0e6);
                 const float ga = (float)(ta - fta), gb = (float)(tb - ftb);
-                if (!staged || abs(ja - cja) > C::MARG || abs(jb - cjb) > C::MARG) {
-                    cja = ja;
-                    cjb = jb;
-                    staged = true;
-                    __syncthreads();
-                    {
-                        constexpr int NLD = (C::SJ * C::SJ + 63) / 64;
-                        float tmp[NLD];
+                if (__builtin_amdgcn_ballot_w64(fta == fta_taps && ftb == ftb_taps) == 0) {   // (wave-uniform)
+                    fta_taps = fta;
+                    ftb_taps = ftb;
+                    // positions far outside the image cannot come back; keep integer math bounded
+                    const int ja = bounded_int(fta), jb = bounded_int(ftb);
+                    if (!staged || abs(ja - cja) > C::MARG || abs(jb - cjb) > C::MARG) {
+                        cja = ja;
+                        cjb = jb;
+                        staged = true;
+                        __syncthreads();
+                        {
+                            constexpr int NLD = (C::SJ * C::SJ + 63) / 64;
+                            float tmp[NLD];
 #pragma unroll
-                        for (int k = 0; k < NLD; ++k) {
-                            const int q = lane + 64 * k;
-                            const int rb = q / C::SJ, ra = q - rb * C::SJ;
-                            const int a = min(max(cja - C::HALF - C::MARG + ra, 0), A - 1);
-                            const int b = min(max(cjb - C::HALF - C::MARG + rb, 0), B - 1);
-                            tmp[k] = Ql[(size_t)b * A + a];
-                        }
+                            for (int k = 0; k < NLD; ++k) {
+                                const int q = lane + 64 * k;
+                                const int rb = q / C::SJ, ra = q - rb * C::SJ;
+                                const int a = min(max(cja - C::HALF - C::MARG + ra, 0), A - 1);
+                                const int b = min(max(cjb - C::HALF - C::MARG + rb, 0), B - 1);
+                                tmp[k] = Ql[(size_t)b * A + a];
+                            }
 #pragma unroll
-                        for (int k = 0; k < NLD; ++k) {
-                            const int q = lane + 64 * k;
-                            if (q < C::SJ * C::SJ) sJ[q] = tmp[k];
+                            for (int k = 0; k < NLD; ++k) {
+                                const int q = lane + 64 * k;
+                                if (q < C::SJ * C::SJ) sJ[q] = tmp[k];
+                            }
                         }
+                        __syncthreads();
                     }
-                    __syncthreads();
-                }
-                const float *org = sJ + (jb - cjb + C::MARG) * C::SJ + (ja - cja + C::MARG) + offJ;
-                // all LDS reads first, so that their latencies overlap: RPL + 1 tap rows, two taps each
-                float t0[C::RPL + 1], t1[C::RPL + 1];
+                    const float *org = sJ + (jb - cjb + C::MARG) * C::SJ + (ja - cja + C::MARG) + offJ;
+                    float t1[C::RPL + 1];
 #pragma unroll
-                for (int r = 0; r <= C::RPL; ++r) {
-                    t0[r] = org[r * C::SJ];
-                    t1[r] = org[r * C::SJ + 1];
+                    for (int r = 0; r <= C::RPL; ++r) {   // all LDS reads first, so that their latencies overlap
+                        t0[r] = org[r * C::SJ];
+                        t1[r] = org[r * C::SJ + 1];
+                    }
+#pragma unroll
+                    for (int r = 0; r <= C::RPL; ++r) dt[r] = t1[r] - t0[r];
                 }
                 // per-lane partial sums in fp32 (RPL fused multiply-adds, rows in increasing order), then
                 // a fixed fp32 tree across the wavefront
-                float baf = 0.f, bbf = 0.f;
-                float h0 = __builtin_fmaf(ga, t1[0] - t0[0], t0[0]);
+                float h[C::RPL + 1], baf = 0.f, bbf = 0.f;
+#pragma unroll
+                for (int r = 0; r <= C::RPL; ++r) h[r] = __builtin_fmaf(ga, dt[r], t0[r]);
 #pragma unroll
                 for (int k = 0; k < C::RPL; ++k) {
-                    const float h1 = __builtin_fmaf(ga, t1[k + 1] - t0[k + 1], t0[k + 1]);
-                    const float j = __builtin_fmaf(gb, h1 - h0, h0);
+                    const float j = __builtin_fmaf(gb, h[k + 1] - h[k], h[k]);
                     const float e = T[k] - j;
                     baf = __builtin_fmaf(e, GX[k], baf);
                     bbf = __builtin_fmaf(e, GY[k], bbf);
-                    h0 = h1;
                 }
                 const double ba = (double)vohip_dev::wave_sum_f32(baf), bb = (double)vohip_dev::wave_sum_f32(bbf);
                 const double sa = (gyy * ba - gxy * bb) * inv_det;
@@ -327,6 +348,7 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
 #undef KLT_PICK
     if (n_dev) n = min(n, *n_dev);
     if (i >= n) return;
+    const long long t_start = stats ? clock64() : 0;
     const int r = rows ? rows[i] : base + i;
     const int o = out_base < 0 ? r : out_base + i;
     if (live && !live[r]) {
@@ -350,6 +372,7 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
         if (stats) {   // work counters: tracks, Gauss-Newton iterations (both directions, all levels)
             atomicAdd(stats, 1ull);
             atomicAdd(stats + 1, (unsigned long long)iters);
+            atomicMax(stats + 2, (unsigned long long)(clock64() - t_start));   // longest track, shader clock ticks
         }
     }
 }
@@ -497,7 +520,7 @@ extern "C" {
 int vohip_klt_stats(vohip_ctx *ctx, long long *tracks, long long *iterations, int reset)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
-    unsigned long long h[2] = {0, 0};
+    unsigned long long h[3] = {0, 0, 0};
     if (ctx->bufs[B_KLT_STATS].ptr) {
         VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
         VOHIP_HIP(ctx, hipDeviceSynchronize());   // trackers may run on other streams of this context's owner
@@ -507,6 +530,7 @@ int vohip_klt_stats(vohip_ctx *ctx, long long *tracks, long long *iterations, in
             VOHIP_HIP(ctx, hipDeviceSynchronize());
         }
     }
+    if (std::getenv("VOHIP_KLT_CYCLES")) std::fprintf(stderr, "vohip klt: longest track %llu ticks\n", h[2]);
     if (tracks) *tracks = (long long)h[0];
     if (iterations) *iterations = (long long)h[1];
     return VOHIP_OK;

@@ -32,19 +32,20 @@ __device__ __forceinline__ float dpp_add_f32(float v)
     return v + __int_as_float(t);
 }
 
-// Wave-wide fp32 sum in a fixed tree: fours, pairs of fours, pairs of eights (DPP within each row
-// of 16 lanes), then the four row sums as ((r0 + r1) + r2) + r3.  Every lane receives the same bits.
+// Wave-wide fp32 sum in a fixed, balanced tree: fours, pairs of fours, pairs of eights (DPP within
+// each row of 16 lanes), then the four row sums as (r0 + r1) + (r2 + r3) by two row broadcasts
+// (row 1 += row 0 and row 3 += row 2, then row 3 += row 1); the total is read from the last lane,
+// so every lane receives the same bits.
 __device__ __forceinline__ float wave_sum_f32(float v)
 {
     v = dpp_add_f32<0xB1>(v);    // quad_perm [1,0,3,2]
     v = dpp_add_f32<0x4E>(v);    // quad_perm [2,3,0,1]
     v = dpp_add_f32<0x141>(v);   // row_half_mirror
     v = dpp_add_f32<0x140>(v);   // row_mirror
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return ((r0 + r1) + r2) + r3;
+    // row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3 (other rows add zero)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Sum over each aligned group of 8 lanes (every lane of the group receives it): three DPP steps.
