@@ -68,6 +68,9 @@ def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barr
     else:   # frames stay in host memory; every step uploads its 466 KB image
         # pinned, so that the transfers are asynchronous
         keep = [torch.from_numpy(f).pin_memory() for f in frames[:warmup + steps + 2]]
+        for t in keep:   # the first transfer out of a fresh pinned buffer maps its pages (~100 us): not the loop's cost
+            t.to(dev)
+        torch.cuda.synchronize()
         d_frames = [t.numpy() for t in keep]
     X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
     hp = vo.default_hyper_paras("kitti", is_BA=False)

@@ -210,7 +210,7 @@ typedef struct vohip_frame_params {
     double fm_threshold, fm_confidence;
     int cap_landmarks, cap_candidates, cap_corners;   /* capacities of the device arrays */
     int max_hypotheses;                        /* 15000, ransacLocalization.m:128 */
-    int slot_a, slot_b;                        /* the two pyramid slots of the context this loop uses */
+    int slot_a, slot_b, slot_c;                /* the three pyramid slots of the context this loop uses */
 } vohip_frame_params;
 
 typedef struct vohip_frame_pose {

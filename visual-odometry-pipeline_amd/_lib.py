@@ -41,7 +41,7 @@ class FrameParams(C.Structure):
                 ("refine_pose", C.c_int), ("refine_max_iter", C.c_int), ("fm_trials", C.c_int),
                 ("fm_threshold", C.c_double), ("fm_confidence", C.c_double), ("cap_landmarks", C.c_int),
                 ("cap_candidates", C.c_int), ("cap_corners", C.c_int), ("max_hypotheses", C.c_int),
-                ("slot_a", C.c_int), ("slot_b", C.c_int)]
+                ("slot_a", C.c_int), ("slot_b", C.c_int), ("slot_c", C.c_int)]
 
 
 class FramePose(C.Structure):

@@ -581,6 +581,18 @@ __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__r
 // (candidate) kept by that frame came from -- srcL (srcC) -- and writes the landmark (candidate)
 // rows of the current frame's table.
 
+// Image transfer by a kernel: src is pinned host memory that the GPU can address (16 bytes per lane).
+__global__ __launch_bounds__(256) void fetch_image_kernel(const uint8_t *__restrict__ src, size_t bytes,
+                                                          uint8_t *__restrict__ dst)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i + 16 <= bytes) {
+        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+    } else {
+        for (size_t k = i; k < bytes; ++k) dst[k] = src[k];
+    }
+}
+
 // Detections -> their rows of the table (main_demo.m:377; every detection may become a candidate).
 __global__ __launch_bounds__(256) void detection_rows_kernel(const float *__restrict__ corner_xy, int capK,
                                                              const int *__restrict__ n_det, int base, int ld,
@@ -638,7 +650,7 @@ struct vohip_frame {
     int *cnt;
     uint8_t *mask, *fmask, *status, *keep;
     int capU = 0;                // rows of the track table
-    int slot_prev = 0, slot_cur = 0;
+    int slot_prev = 0, slot_cur = 0, slot_next = 0;   // pyramids of the previous, the current and the following image
     int par = 0;                 // parity of the frame being processed
     bool ahead_launched = false; // this call prepares the next image
     bool ahead = false;          // the previous call left this image's pyramid and corners on the device
@@ -736,6 +748,28 @@ int fetch_summary(vohip_frame *f)
     return VOHIP_OK;
 }
 
+// A host image to its device buffer on `stream`.  Pinned memory the GPU can address is fetched by a
+// kernel (one launch; a copy command followed by kernels on the same stream costs the host far more),
+// anything else goes through hipMemcpyAsync.
+int enqueue_image_transfer(vohip_frame *f, const uint8_t *host, uint8_t *dst, hipStream_t stream)
+{
+    vohip_ctx *ctx = f->ctx;
+    const size_t bytes = (size_t)f->rows * f->cols;
+    hipPointerAttribute_t attr;
+    void *dev = nullptr;
+    if (hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost &&
+        hipHostGetDevicePointer(&dev, const_cast<uint8_t *>(host), 0) == hipSuccess && dev &&
+        (reinterpret_cast<uintptr_t>(dev) & 15) == 0) {
+        hipLaunchKernelGGL(fetch_image_kernel, dim3((unsigned)((bytes + 4095) / 4096)), dim3(256), 0, stream,
+                           (const uint8_t *)dev, bytes, dst);
+        VOHIP_HIP(ctx, hipGetLastError());
+        return VOHIP_OK;
+    }
+    (void)hipGetLastError();   // (a pageable pointer makes the query fail: not an error here)
+    VOHIP_HIP(ctx, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, stream));
+    return VOHIP_OK;
+}
+
 // Second stream, after the trackers: the epipolar filter over the candidate tracks
 // (update_landmarks.m:11-25), which needs neither the new pose nor the localisation draws.
 int enqueue_side_filter(vohip_frame *f, const double *u8)
@@ -770,8 +804,9 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
 
 // Third stream: corner detection (main_demo.m:377) needs only the image; the detections also become
 // rows of the track table.  `par`: parity of the frame the image belongs to; `ready`: event after
-// which the image is on the device.
-int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t ready)
+// which the image is on the device; `table_free`: event after which the rows may be written (the
+// trackers of the current frame still read the table of that parity), or NULL.
+int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t ready, hipEvent_t table_free)
 {
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
@@ -780,6 +815,7 @@ int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t 
     VOHIP_TRY(vohip_detect_corners_dev(ctx, d_img, f->rows, f->cols, f->colmajor, p.min_quality, p.filter_size, p.border,
                                        p.detector, f->corner_xy[par], f->corner_metric[par], f->capK,
                                        f->cnt + N_DET + par));
+    if (table_free) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, table_free, 0));
     hipLaunchKernelGGL(detection_rows_kernel, dim3(blocks256(f->capK)), dim3(256), 0, f->side2, f->corner_xy[par], f->capK,
                        f->cnt + N_DET + par, f->capL + f->capC, f->capU, f->U_xy[par], f->U_live[par]);
     VOHIP_HIP(ctx, hipGetLastError());
@@ -897,7 +933,8 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     }
     const int t = f->slot_prev;   // main_demo.m:417-424: this frame's pyramid is the next "previous"
     f->slot_prev = f->slot_cur;
-    f->slot_cur = t;
+    f->slot_cur = f->slot_next;   // (holds the following image's pyramid when it was prepared ahead)
+    f->slot_next = t;
     f->n_L = hc[N_L_END];
     f->n_C = hc[N_C_END];
     f->stage = 0;
@@ -947,6 +984,7 @@ void vohip_frame_default_params(vohip_frame_params *p)
     p->max_hypotheses = 15000;    // ransacLocalization.m:128
     p->slot_a = 6;
     p->slot_b = 7;
+    p->slot_c = 5;
 }
 
 int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor,
@@ -959,8 +997,9 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     VOHIP_REQUIRE(ctx, p.cap_landmarks >= 64 && p.cap_candidates >= 64 && p.cap_corners >= 64 && p.cap_corners <= 16384,
                   "capacities out of range");
     VOHIP_REQUIRE(ctx, p.fm_trials >= 1 && p.max_hypotheses >= 104, "bad RANSAC sizes");
-    VOHIP_REQUIRE(ctx, p.slot_a != p.slot_b && p.slot_a >= 0 && p.slot_a < VOHIP_PYR_SLOTS && p.slot_b >= 0 &&
-                           p.slot_b < VOHIP_PYR_SLOTS,
+    VOHIP_REQUIRE(ctx, p.slot_a != p.slot_b && p.slot_a != p.slot_c && p.slot_b != p.slot_c && p.slot_a >= 0 &&
+                           p.slot_a < VOHIP_PYR_SLOTS && p.slot_b >= 0 && p.slot_b < VOHIP_PYR_SLOTS && p.slot_c >= 0 &&
+                           p.slot_c < VOHIP_PYR_SLOTS,
                   "bad pyramid slots");
     VOHIP_REQUIRE(ctx, p.klt_block == 21 || p.klt_block == 31, "BlockSize 21 or 31");
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
@@ -979,6 +1018,7 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     f->capU = f->capL + f->capC + f->capK;
     f->slot_prev = p.slot_a;
     f->slot_cur = p.slot_b;
+    f->slot_next = p.slot_c;
     const size_t bytes = layout(f, nullptr);
     hipError_t e = hipMalloc(&f->block, bytes);
     if (e == hipSuccess) e = hipMemsetAsync(f->block, 0, bytes, ctx->stream);
@@ -1130,7 +1170,6 @@ int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_de
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
     const int par = f->par;
-    const size_t img_bytes = (size_t)f->rows * f->cols;
     f->have_map = f->n_C > 0;   // main_demo.m:406
     f->evaluated = 0;
     f->stage = 1;
@@ -1151,7 +1190,7 @@ int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_de
     const uint8_t *d_next = next_image ? (next_on_device ? next_image : f->img[par ^ 1]) : nullptr;
     if (!f->ahead) {
         // nothing was done ahead: this image, its pyramid and its corners
-        if (!image_on_device) VOHIP_HIP(ctx, hipMemcpyAsync(f->img[par], image, img_bytes, hipMemcpyHostToDevice, s));
+        if (!image_on_device) VOHIP_TRY(enqueue_image_transfer(f, image, f->img[par], s));
         VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));
         VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
     } else {
@@ -1169,7 +1208,17 @@ int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_de
                                          p.klt_max_bidir_error));
     }
     VOHIP_HIP(ctx, hipEventRecord(f->ev_adv, s));      // the other streams start from here
-    if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, f->ev_pyr));
+    if (next_image) {
+        // streams of their own, beside the trackers (which leave most of the GPU idle): the next image,
+        // its pyramid (third slot) and its corners, so that the next call starts with its trackers
+        stream_swap sw(ctx, f->trk);
+        if (!next_on_device) VOHIP_TRY(enqueue_image_transfer(f, next_image, f->img[par ^ 1], f->trk));
+        VOHIP_HIP(ctx, hipEventRecord(f->ev_next, f->trk));
+        VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_next, d_next, f->rows, f->cols, f->colmajor, p.klt_levels));
+        VOHIP_HIP(ctx, hipEventRecord(f->ev_img, f->trk));
+    }
+    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, f->ev_next, f->ev_adv));
+    if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, f->ev_pyr, nullptr));
     VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_draws, 0));
     if (f->trace) (void)hipEventRecord(f->tr[1], s);   // trackers done
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
@@ -1181,19 +1230,6 @@ int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_de
     if (f->trace) (void)hipEventRecord(f->tr[2], s);   // pose refined
     VOHIP_TRY(enqueue_side_filter(f, u8));
     VOHIP_TRY(enqueue_tail(f));
-    // (enqueued last: nothing of this frame waits for it)
-    if (next_image) {
-        // own stream, once the trackers have read the older pyramid for the last time: the next image
-        // and its pyramid, so that the next call starts with its trackers
-        stream_swap sw(ctx, f->trk);
-        VOHIP_HIP(ctx, hipStreamWaitEvent(f->trk, f->ev_adv, 0));
-        if (!next_on_device)
-            VOHIP_HIP(ctx, hipMemcpyAsync(f->img[par ^ 1], next_image, img_bytes, hipMemcpyHostToDevice, f->trk));
-        VOHIP_HIP(ctx, hipEventRecord(f->ev_next, f->trk));
-        VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_prev, d_next, f->rows, f->cols, f->colmajor, p.klt_levels));
-        VOHIP_HIP(ctx, hipEventRecord(f->ev_img, f->trk));
-    }
-    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, f->ev_next));
     return complete_frame(f, h, pose, counts);
 }
 

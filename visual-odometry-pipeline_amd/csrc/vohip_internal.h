@@ -41,7 +41,7 @@ enum vohip_buf_id {
 };
 
 // One image pyramid (float levels, all in one context buffer B_PYR0 + slot).
-constexpr int VOHIP_PYR_SLOTS = 8;
+constexpr int VOHIP_PYR_SLOTS = 16;
 struct vohip_pyramid {
     int rows = 0, cols = 0, colmajor = 0, levels = 0;
     int A[8] = {0}, B[8] = {0};   // fast / slow axis length per level

@@ -50,11 +50,11 @@ class VOPipelineDevice:
         prm.max_depth = float(self.hp.max_depth)
         prm.refine_pose = int(bool(self.hp.is_refine_pose))
         prm.cap_landmarks, prm.cap_candidates, prm.cap_corners = int(cap_landmarks), int(cap_candidates), int(cap_corners)
-        free = self.ctx.__dict__.setdefault("_free_pyr_slots", list(range(8)))
-        if len(free) < 2:
-            raise RuntimeError("the context has fewer than 2 free pyramid slots")
-        self._slots = [free.pop(), free.pop()]
-        prm.slot_a, prm.slot_b = self._slots
+        free = self.ctx.__dict__.setdefault("_free_pyr_slots", list(range(16)))
+        if len(free) < 3:
+            raise RuntimeError("the context has fewer than 3 free pyramid slots")
+        self._slots = [free.pop(), free.pop(), free.pop()]
+        prm.slot_a, prm.slot_b, prm.slot_c = self._slots
         self.params = prm
         shape = tuple(first_image.shape)
         self._colmajor = 0

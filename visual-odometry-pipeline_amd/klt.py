@@ -17,7 +17,7 @@ class Pyramid:
 
     def __init__(self, image, levels=5, ctx=None):
         self.ctx = ctx or _lib.default_context()
-        free = self.ctx.__dict__.setdefault("_free_pyr_slots", list(range(8)))
+        free = self.ctx.__dict__.setdefault("_free_pyr_slots", list(range(16)))
         if not free:
             raise RuntimeError("all 8 pyramid slots of the context are in use; release() some")
         self.slot = free.pop(0)
