@@ -188,6 +188,23 @@ def bench_klt(vo, torch, ctx, d_frames, xy, n_points, reps=20):
                 frac_lds=lds / (ms * 1e-3) / 1e12 / LDS_PEAK_TBS)
 
 
+def traffic_from_profile(kernel):
+    """HBM bytes per launch of `kernel` as the committed rocprofv3 counter passes saw them (newest
+    profiles/*_summary.csv that lists it): FETCH_SIZE + WRITE_SIZE, which rocprofv3 reports in KB, as read
+    (the kernel's loads are 8 bytes per lane, for which the counter is not calibrated).  None without a profile."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.csv")), reverse=True):
+        try:
+            for row in csv.DictReader(open(path, newline="")):
+                if row.get("kernel") == kernel and row.get("FETCH_SIZE") and row.get("WRITE_SIZE"):
+                    return {"bytes": (float(row["FETCH_SIZE"]) + float(row["WRITE_SIZE"])) * 1024.0,
+                            "source": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
 def cpu_baseline_frames(vo, scene, frames, poses, X0, xy0, budget_s=12.0):
     """The CPU restatement of the same loop on the first frames of the same sequence."""
     from oracle import pipeline_oracle as po
@@ -278,6 +295,7 @@ def main():
         achieved = 116.0 * n * h / (score_ms * 1e-3) / 1e12
 
     if rank == 0:
+        traffic = traffic_from_profile("p3p_score_kernel<16, 1024>") if (n, h) == (8192, 4096) else None
         out = {
             "metric": METRIC,
             "value": fps,
@@ -309,7 +327,11 @@ def main():
             "ransac_config": {"workload": "RANSAC stress: %d P3P hypotheses x %d correspondences per step" % (h, n)},
             "roofline": {"bound": "valu_fp64", "kernel": "p3p_score_kernel (RANSAC stress)", "achieved": achieved,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS,
-                         "traffic": None, "kernel_ms": score_ms},
+                         "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
+                         # 40 B per correspondence once, 4 x 12 doubles of K[R|t] in and 4 counts out per hypothesis
+                         "algorithmic_bytes": 40.0 * n + (384.0 + 16.0) * h,
+                         "kernel_ms": score_ms},
             "roofline_klt": {"note": "dominant kernel of the frame loop; one wavefront per track, so at ~2k tracks "
                                      "the launch is bound by the dependent-iteration latency of the slowest track, "
                                      "not by LDS or VALU throughput; the 8192-track launch is the stress configuration",

@@ -38,10 +38,11 @@ def main(src, dst):
                 table[k][c] = sum(v) / len(v)
     cols = ["calls", "avg_us", "pct", "FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU",
             "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES"]
-    with open(dst + "_summary.csv", "w") as f:
-        f.write("kernel," + ",".join(cols) + "\n")
+    with open(dst + "_summary.csv", "w", newline="") as f:
+        w = csv.writer(f)   # (kernel names hold commas: quoted)
+        w.writerow(["kernel"] + cols)
         for k, d in sorted(table.items(), key=lambda kv: -kv[1].get("pct", 0)):
-            f.write(k + "," + ",".join("%.6g" % d[c] if c in d else "" for c in cols) + "\n")
+            w.writerow([k] + ["%.6g" % d[c] if c in d else "" for c in cols])
     print(open(dst + "_summary.csv").read())
 
 
