@@ -188,6 +188,53 @@ def bench_klt(vo, torch, ctx, d_frames, xy, n_points, reps=20):
                 frac_lds=lds / (ms * 1e-3) / 1e12 / LDS_PEAK_TBS)
 
 
+def bench_image_kernels(vo, torch, ctx, d_frame, reps=50):
+    """The two per-image stages that stream the frame: pyramid build (5 levels) and corner detection
+    (Harris response, non-maximum suppression, ordered emit), one frame per launch sequence as the loop
+    runs them.  Algorithmic HBM bytes: pyramid = the uint8 image in, every fp32 level written once and read
+    once for the next level; detection = the image in and 8 bytes per corner out."""
+    lib = vo._lib.load()
+    dev = d_frame.device
+    rows, cols = d_frame.shape
+    cap = 16384
+    d_xy = torch.zeros(2 * cap, dtype=torch.float32, device=dev)
+    d_metric = torch.zeros(cap, dtype=torch.float32, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    pyr = vo.Pyramid(d_frame, 5, ctx=ctx)
+
+    def build():
+        ctx.check(lib.vohip_pyramid_build_dev(ctx.handle, pyr.slot, d_frame.data_ptr(), rows, cols, 0, 5))
+
+    def detect():
+        ctx.check(lib.vohip_detect_corners_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 2e-4, 5, 16, 0,
+                                               d_xy.data_ptr(), d_metric.data_ptr(), cap, d_count.data_ptr()))
+
+    out = {}
+    for name, fn in (("pyramid_build", build), ("corner_detection", detect)):
+        fn()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        out[name] = ev0.elapsed_time(ev1) / reps
+    px = float(rows * cols)
+    levels = sum(0.25 ** l for l in range(5))
+    n_corners = min(int(d_count.item()), cap)
+    bytes_pyr = px * (1.0 + 4.0 * levels + 4.0 * (levels - 0.25 ** 4))
+    bytes_det = px + 8.0 * n_corners
+    pyr.release()
+    return {"note": "per-frame launch sequences of %dx%d; at 0.47 MB per frame these stages are launch- and "
+                    "latency-bound, far from the HBM roofline" % (cols, rows),
+            "pyramid_build": {"ms": out["pyramid_build"], "algorithmic_bytes": bytes_pyr,
+                              "achieved_gbs": bytes_pyr / (out["pyramid_build"] * 1e-3) / 1e9, "peak_gbs": 8000.0},
+            "corner_detection": {"ms": out["corner_detection"], "corners": n_corners, "algorithmic_bytes": bytes_det,
+                                 "achieved_gbs": bytes_det / (out["corner_detection"] * 1e-3) / 1e9,
+                                 "peak_gbs": 8000.0}}
+
+
 def traffic_from_profile(kernel):
     """HBM bytes per launch of `kernel` as the committed rocprofv3 counter passes saw them (newest
     profiles/*_summary.csv that lists it): FETCH_SIZE + WRITE_SIZE, which rocprofv3 reports in KB, as read
@@ -289,6 +336,7 @@ def main():
         _, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
         klt_frame = bench_klt(vo, torch, ctx, d2, xy0, len(xy0))
         klt_stress = bench_klt(vo, torch, ctx, d2, xy0, 8192)
+        image_kernels = bench_image_kernels(vo, torch, ctx, d2[0])
 
         n, h = args.points, args.hypotheses
         hyps_per_s, score_ms = bench_ransac(vo, torch, ctx, n, h, max(args.steps, 20), args.warmup, 100 + rank)
@@ -336,6 +384,7 @@ def main():
                                      "the launch is bound by the dependent-iteration latency of the slowest track, "
                                      "not by LDS or VALU throughput; the 8192-track launch is the stress configuration",
                              "frame_config": klt_frame, "stress_config": klt_stress},
+            "roofline_image_kernels": image_kernels,
         }
         if not args.no_cpu_baseline and world == 1:
             X0, xy0 = init_points(vo, ctx, scene, frames_all[0], poses_all[0])

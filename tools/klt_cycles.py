@@ -1,6 +1,6 @@
 import importlib, os, sys, ctypes as C
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 vo = importlib.import_module("visual_odometry_pipeline_amd")
 s = torch.cuda.Stream()

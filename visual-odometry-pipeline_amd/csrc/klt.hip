@@ -79,13 +79,6 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__
 
 #pragma clang fp contract(fast)
 
-__device__ __forceinline__ float bilerp(float i00, float i01, float i10, float i11, float fa, float fb)
-{
-    const float top = __builtin_fmaf(fa, i01 - i00, i00);
-    const float bot = __builtin_fmaf(fa, i11 - i10, i10);
-    return __builtin_fmaf(fb, bot - top, top);
-}
-
 __device__ __forceinline__ double wave_sum(double v) { return vohip_dev::wave_sum_f64(v); }
 
 // (int)min(max(t, -1e6), 1e6) for a finite integral t: the conversion instruction saturates, so the
