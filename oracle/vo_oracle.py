@@ -284,7 +284,7 @@ def run_ba(state, obs, K, max_iter=21, ftol=1e-10, xtol=1e-10):
     return s, dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2], lam=stats[3])
 
 
-def pose_refine(T_W_C, kp_uv, X, K, max_iter=100, ftol=1e-10, xtol=1e-10):
+def pose_refine(T_W_C, kp_uv, X, K, max_iter=100, ftol=1e-6, xtol=1e-6):   # lsqnonlin's default tolerances (T_refinement.m:4)
     """T_refinement(T_W_C, keypoints (2xN (u,v)), landmarks (3xN), K)."""
     T = _f64(np.asarray(T_W_C).T).copy()
     kp = _f64(np.asarray(kp_uv).T)

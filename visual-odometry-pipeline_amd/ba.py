@@ -12,6 +12,9 @@ BA_MAX_ITER = 21          # the reference's budget: lsqnonlin MaxIter 1 + MaxIte
 POSE_MAX_ITER = 100       # T_refinement.m:4
 FTOL = 1e-10
 XTOL = 1e-10
+# T_refinement.m:4 leaves lsqnonlin's tolerances at their defaults (FunctionTolerance = StepTolerance = 1e-6)
+POSE_FTOL = 1e-6
+POSE_XTOL = 1e-6
 
 
 def baError(hidden_state, observations, K, ctx=None):
@@ -41,7 +44,7 @@ def runBA(hidden_state, observations, K, max_iter=BA_MAX_ITER, ftol=FTOL, xtol=X
     return out
 
 
-def T_refinement(T_W_C, keypoints, landmarks, K, max_iter=POSE_MAX_ITER, ftol=FTOL, xtol=XTOL, return_stats=False,
+def T_refinement(T_W_C, keypoints, landmarks, K, max_iter=POSE_MAX_ITER, ftol=POSE_FTOL, xtol=POSE_XTOL, return_stats=False,
                  ctx=None):
     """refined_T_W_C = T_refinement(T_W_C, keypoints, landmarks, K): keypoints 2xN (u, v),
     landmarks 3xN."""

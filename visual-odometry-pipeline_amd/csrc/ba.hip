@@ -25,7 +25,8 @@
 // far too small for a matrix-core contraction, so everything is fp64 VALU.
 //
 // pose_refine_kernel: T_refinement as ONE workgroup running the whole LM loop in-kernel
-// (block-wide fp64 reductions of the 6x6 normal equations, Cholesky by one lane).
+// (one pass over the points per step gives a trial pose its cost and its 6x6 normal equations;
+// Cholesky by one lane).
 #include "vohip_internal.h"
 #include "se3_device.h"
 #include "wave_reduce.h"
@@ -546,18 +547,6 @@ __global__ __launch_bounds__(256) void ba_decide_kernel(int nx, int nblocks, con
 // ------------------------------------------------------------------------------------------
 constexpr int PR_THREADS = 512;
 
-__device__ __forceinline__ double block_sum(double v, double *sWave /*16*/)
-{
-    v = wave_sum_f64(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sWave[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < PR_THREADS / 64; ++w) t += sWave[w];
-    return t;
-}
-
 struct pr_params {
     double K[9];
     int n, max_iter;
@@ -570,8 +559,11 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
                                                                  double *__restrict__ T_io /*16*/,
                                                                  double *__restrict__ stats /*3*/)
 {
-    __shared__ frame_lin sF, sFn;
-    __shared__ double sTw[6], sTwN[6], sH[36], sG[6], sD[6], sWave[16], sPart[27 * (PR_THREADS / 8)];
+    // Two slots (frame, twist, normal equations, cost): the current estimate and the trial step.  One
+    // pass over the points gives a slot its cost AND its normal equations, so an accepted step needs
+    // no second pass (the next step is solved from the trial slot's own system).
+    __shared__ frame_lin sF[2];
+    __shared__ double sTw[2][6], sH[2][36], sG[2][6], sCost[2], sD[6], sPart[28 * (PR_THREADS / 8)];
     __shared__ int sOk;
     const int tid = threadIdx.x;
     if (n_dev) P.n = *n_dev;  // point count kept on the device (the frame pipeline)
@@ -579,33 +571,24 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
         const rigid T = rigid_from_cm44(T_io);
         double tw[6];
         rigid_to_twist(T, tw);
-        for (int k = 0; k < 6; ++k) sTw[k] = tw[k];
-        frame_prepare(tw, sF);
+        for (int k = 0; k < 6; ++k) sTw[0][k] = tw[k];
+        frame_prepare(tw, sF[0]);
     }
     __syncthreads();
-    auto cost_of = [&](const frame_lin &f) {
-        double c = 0.0;
-        for (int k = tid; k < P.n; k += PR_THREADS) {
-            const double Xl[3] = {X[3 * k], X[3 * k + 1], X[3 * k + 2]};
-            double r[2];
-            observe<false>(f, P.K, Xl, kp_uv[2 * k], kp_uv[2 * k + 1], r, nullptr, nullptr);
-            c += r[0] * r[0] + r[1] * r[1];
-        }
-        return block_sum(c, sWave);
-    };
-    double cost = cost_of(sF);
-    const double cost0 = cost;
-    double lambda = 1e-3;
-    int iter = 0, rejects = 0;
-    while (iter < P.max_iter) {
-        // normal equations: 21 + 6 sums
-        double h[21], g[6];
+    // cost, J^T J (21 sums) and J^T r (6 sums) of slot s: three DPP steps leave every group of 8
+    // lanes with its sum, the 64 group sums of each quantity go through LDS, 8 threads per quantity
+    // add them in a fixed order
+    auto linearize = [&](int s) {
+        double h[21], g[6], c = 0.0;
+#pragma unroll
         for (int q = 0; q < 21; ++q) h[q] = 0.0;
+#pragma unroll
         for (int q = 0; q < 6; ++q) g[q] = 0.0;
         for (int k = tid; k < P.n; k += PR_THREADS) {
             const double Xl[3] = {X[3 * k], X[3 * k + 1], X[3 * k + 2]};
             double r[2], Jp[2][6], Jl[2][3];
-            observe<true>(sF, P.K, Xl, kp_uv[2 * k], kp_uv[2 * k + 1], r, Jp, Jl);
+            observe<true>(sF[s], P.K, Xl, kp_uv[2 * k], kp_uv[2 * k + 1], r, Jp, Jl);
+            c += r[0] * r[0] + r[1] * r[1];
             int q = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -614,137 +597,138 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
                 for (int b = a; b < 6; ++b) h[q++] += Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b];
             }
         }
-        // all 27 sums at once: three DPP steps leave every group of 8 lanes with its sum, the 64
-        // group sums of each quantity go through LDS, one thread per quantity adds them in order
-        {
 #pragma unroll
-            for (int q = 0; q < 21; ++q) h[q] = group8_sum_f64(h[q]);
+        for (int q = 0; q < 21; ++q) h[q] = group8_sum_f64(h[q]);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) g[q] = group8_sum_f64(g[q]);
-            __syncthreads();
+        for (int q = 0; q < 6; ++q) g[q] = group8_sum_f64(g[q]);
+        c = group8_sum_f64(c);
+        __syncthreads();
+        if ((tid & 7) == 0) {
+            double *col = sPart + (tid >> 3);
+#pragma unroll
+            for (int q = 0; q < 21; ++q) col[64 * q] = h[q];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) col[64 * (21 + q)] = g[q];
+            col[64 * 27] = c;
+        }
+        __syncthreads();
+        if (tid < 28 * 8) {
+            const int q = tid >> 3;
+            const double *row = sPart + 64 * q + 8 * (tid & 7);
+            double t = ((row[0] + row[1]) + (row[2] + row[3])) + ((row[4] + row[5]) + (row[6] + row[7]));
+            t = group8_sum_f64(t);
             if ((tid & 7) == 0) {
-                double *col = sPart + (tid >> 3);
-#pragma unroll
-                for (int q = 0; q < 21; ++q) col[64 * q] = h[q];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) col[64 * (21 + q)] = g[q];
-            }
-            __syncthreads();
-            if (tid < 27 * 8) {   // 8 threads per quantity: 8 partials each, then one more group sum
-                const int q = tid >> 3;
-                const double *row = sPart + 64 * q + 8 * (tid & 7);
-                double s = ((row[0] + row[1]) + (row[2] + row[3])) + ((row[4] + row[5]) + (row[6] + row[7]));
-                s = group8_sum_f64(s);
-                if ((tid & 7) == 0) {
-                    if (q < 21) {
-                        // upper-triangle index -> (a, b)
-                        int a = 0, rem = q;
-                        while (rem >= 6 - a) {
-                            rem -= 6 - a;
-                            ++a;
-                        }
-                        const int b = a + rem;
-                        sH[6 * a + b] = sH[6 * b + a] = s;
-                    } else {
-                        sG[q - 21] = s;
+                if (q < 21) {
+                    // upper-triangle index -> (a, b)
+                    int a = 0, rem = q;
+                    while (rem >= 6 - a) {
+                        rem -= 6 - a;
+                        ++a;
                     }
+                    const int b = a + rem;
+                    sH[s][6 * a + b] = sH[s][6 * b + a] = t;
+                } else if (q < 27) {
+                    sG[s][q - 21] = t;
+                } else {
+                    sCost[s] = t;
                 }
             }
         }
         __syncthreads();
-        bool accepted = false, stop = false;
-        while (!accepted && !stop) {
-            __syncthreads();
-            if (tid == 0) {
-                // 6x6 Cholesky with every loop unrolled, so that A and d stay in registers
-                double A[36], d[6];
+        return sCost[s];
+    };
+    int cur = 0;
+    double cost = linearize(cur);
+    const double cost0 = cost;
+    double lambda = 1e-3;
+    int iter = 0, rejects = 0;
+    bool stop = false;
+    while (iter < P.max_iter && !stop) {
+        const int nxt = cur ^ 1;
+        if (tid == 0) {
+            // 6x6 Cholesky with every loop unrolled, so that A and d stay in registers
+            double A[36], d[6];
 #pragma unroll
-                for (int q = 0; q < 36; ++q) A[q] = sH[q];
+            for (int q = 0; q < 36; ++q) A[q] = sH[cur][q];
 #pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                A[7 * a] *= 1.0 + lambda;
+                d[a] = -sG[cur][a];
+            }
+            int ok = 1;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double dd = A[j * 6 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) dd -= A[j * 6 + k] * A[j * 6 + k];
+                if (!(dd > 0.0)) ok = 0;
+                dd = sqrt(dd);
+                const double inv = 1.0 / dd;
+                A[j * 6 + j] = dd;
+#pragma unroll
+                for (int i = j + 1; i < 6; ++i) {
+                    double t = A[i * 6 + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) t -= A[i * 6 + k] * A[j * 6 + k];
+                    A[i * 6 + j] = t * inv;
+                }
+            }
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    double t = d[i];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) t -= A[i * 6 + k] * d[k];
+                    d[i] = t / A[i * 6 + i];
+                }
+#pragma unroll
+                for (int i = 5; i >= 0; --i) {
+                    double t = d[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; ++k) t -= A[k * 6 + i] * d[k];
+                    d[i] = t / A[i * 6 + i];
+                }
+                double twn[6];
                 for (int a = 0; a < 6; ++a) {
-                    A[7 * a] *= 1.0 + lambda;
-                    d[a] = -sG[a];
+                    sD[a] = d[a];
+                    twn[a] = sTw[cur][a] + d[a];
+                    sTw[nxt][a] = twn[a];
                 }
-                int ok = 1;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    double dd = A[j * 6 + j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) dd -= A[j * 6 + k] * A[j * 6 + k];
-                    if (!(dd > 0.0)) ok = 0;
-                    dd = sqrt(dd);
-                    const double inv = 1.0 / dd;
-                    A[j * 6 + j] = dd;
-#pragma unroll
-                    for (int i = j + 1; i < 6; ++i) {
-                        double s = A[i * 6 + j];
-#pragma unroll
-                        for (int k = 0; k < j; ++k) s -= A[i * 6 + k] * A[j * 6 + k];
-                        A[i * 6 + j] = s * inv;
-                    }
-                }
-                if (ok) {
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        double s = d[i];
-#pragma unroll
-                        for (int k = 0; k < i; ++k) s -= A[i * 6 + k] * d[k];
-                        d[i] = s / A[i * 6 + i];
-                    }
-#pragma unroll
-                    for (int i = 5; i >= 0; --i) {
-                        double s = d[i];
-#pragma unroll
-                        for (int k = i + 1; k < 6; ++k) s -= A[k * 6 + i] * d[k];
-                        d[i] = s / A[i * 6 + i];
-                    }
-                    double twn[6];
-                    for (int a = 0; a < 6; ++a) {
-                        sD[a] = d[a];
-                        twn[a] = sTw[a] + d[a];
-                        sTwN[a] = twn[a];
-                    }
-                    frame_prepare(twn, sFn);
-                }
-                sOk = ok;
+                frame_prepare(twn, sF[nxt]);
             }
-            __syncthreads();
-            if (!sOk) {
-                lambda *= 10.0;
-                if (++rejects > 10) stop = true;
-                continue;
-            }
-            const double cn = cost_of(sFn);
-            if (cn < cost) {
-                double dn = 0.0, xn = 0.0;
-                for (int a = 0; a < 6; ++a) {
-                    dn += sD[a] * sD[a];
-                    xn += sTw[a] * sTw[a];
-                }
-                const double dec = cost - cn, cost_old = cost;
-                __syncthreads();
-                if (tid == 0) {
-                    for (int a = 0; a < 6; ++a) sTw[a] = sTwN[a];
-                    sF = sFn;
-                }
-                __syncthreads();
-                cost = cn;
-                lambda = lambda * 0.1 > 1e-12 ? lambda * 0.1 : 1e-12;
-                ++iter;
-                rejects = 0;
-                accepted = true;
-                if (dec < P.ftol * (1.0 + cost_old)) stop = true;
-                if (sqrt(dn) < P.xtol * (1.0 + sqrt(xn))) stop = true;
-            } else {
-                lambda *= 10.0;
-                if (++rejects > 10) stop = true;
-            }
+            sOk = ok;
         }
-        if (stop) break;
+        __syncthreads();
+        if (!sOk) {
+            lambda *= 10.0;
+            if (++rejects > 10) stop = true;
+            __syncthreads();   // (sOk is rewritten by the next solve)
+            continue;
+        }
+        const double cn = linearize(nxt);
+        if (cn < cost) {
+            double dn = 0.0, xn = 0.0;
+            for (int a = 0; a < 6; ++a) {
+                dn += sD[a] * sD[a];
+                xn += sTw[cur][a] * sTw[cur][a];
+            }
+            const double dec = cost - cn, cost_old = cost;
+            cur = nxt;
+            cost = cn;
+            lambda = lambda * 0.1 > 1e-12 ? lambda * 0.1 : 1e-12;
+            ++iter;
+            rejects = 0;
+            if (dec < P.ftol * (1.0 + cost_old)) stop = true;
+            if (sqrt(dn) < P.xtol * (1.0 + sqrt(xn))) stop = true;
+        } else {
+            lambda *= 10.0;
+            if (++rejects > 10) stop = true;
+        }
+        __syncthreads();   // every thread has read sD / sTw before the next solve rewrites them
     }
     if (tid == 0) {
         double tw[6];
-        for (int k = 0; k < 6; ++k) tw[k] = sTw[k];
+        for (int k = 0; k < 6; ++k) tw[k] = sTw[cur][k];
         const rigid T = twist_to_rigid(tw);
         rigid_to_cm44(T, T_io);
         if (stats) {

@@ -854,7 +854,7 @@ int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready)
     VOHIP_HIP(ctx, hipGetLastError());
     if (p.refine_pose)   // main_demo.m:398-400
         VOHIP_TRY(vohip_pose_refine_enqueue(ctx, f->dv + D_T, f->kp_uv, f->L_X, f->n_L, f->cnt + N_IN, f->K,
-                                            p.refine_max_iter, 1e-10, 1e-10, f->dv + D_STATS));
+                                            p.refine_max_iter, 1e-6, 1e-6, f->dv + D_STATS));   // lsqnonlin's default tolerances (T_refinement.m:4)
     return VOHIP_OK;
 }
 

@@ -197,7 +197,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         // T = vohip_mex('pose_refine', T_W_C, keypoints_uv 2xN, landmarks 3xN, K, max_iter)
         plhs[0] = mxDuplicateArray(in[0]);
         check(vohip_pose_refine(c, mxGetDoubles(plhs[0]), dbl(in[1], "keypoints"), dbl(in[2], "landmarks"), cols(in[1]),
-                                dbl(in[3], "K"), (int)mxGetScalar(in[4]), 1e-10, 1e-10, nullptr));
+                                dbl(in[3], "K"), (int)mxGetScalar(in[4]), 1e-6, 1e-6, nullptr));   // lsqnonlin's defaults (T_refinement.m:4)
     } else if (op == "detect_corners") {
         // [Location, Metric] = vohip_mex('detect_corners', image uint8, min_quality, filter_size, border, method)
         if (!mxIsUint8(in[0])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
