@@ -646,8 +646,9 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
     while (iter < P.max_iter && !stop) {
         const int nxt = cur ^ 1;
         if (tid == 0) {
-            // 6x6 Cholesky with every loop unrolled, so that A and d stay in registers
-            double A[36], d[6];
+            // 6x6 Cholesky with every loop unrolled, so that A and d stay in registers; the reciprocals
+            // of the pivots serve the two substitutions as well (no further divisions)
+            double A[36], d[6], piv[6];
 #pragma unroll
             for (int q = 0; q < 36; ++q) A[q] = sH[cur][q];
 #pragma unroll
@@ -664,6 +665,7 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
                 if (!(dd > 0.0)) ok = 0;
                 dd = sqrt(dd);
                 const double inv = 1.0 / dd;
+                piv[j] = inv;
                 A[j * 6 + j] = dd;
 #pragma unroll
                 for (int i = j + 1; i < 6; ++i) {
@@ -679,14 +681,14 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
                     double t = d[i];
 #pragma unroll
                     for (int k = 0; k < i; ++k) t -= A[i * 6 + k] * d[k];
-                    d[i] = t / A[i * 6 + i];
+                    d[i] = t * piv[i];
                 }
 #pragma unroll
                 for (int i = 5; i >= 0; --i) {
                     double t = d[i];
 #pragma unroll
                     for (int k = i + 1; k < 6; ++k) t -= A[k * 6 + i] * d[k];
-                    d[i] = t / A[i * 6 + i];
+                    d[i] = t * piv[i];
                 }
                 double twn[6];
                 for (int a = 0; a < 6; ++a) {
