@@ -235,6 +235,32 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50):
                                  "peak_gbs": 8000.0}}
 
 
+def bench_ba(vo, ctx, with_cpu):
+    """The sliding-window bundle adjustment of main_BA.m (runBA: F = 5 keyframes, m landmarks, 60 % visible,
+    0.5 px noise; one call = one whole Levenberg-Marquardt run from the perturbed state, host buffers in and
+    out as the reference calls it), next to the CPU restatement of the same run."""
+    out = {}
+    for m in (300, 1000):
+        s0, obs, _ = vo.synth.ba_problem(F=5, m=m, seed=9)
+        _, info = vo.runBA(s0, obs, vo.synth.K_KITTI, return_stats=True, ctx=ctx)
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            vo.runBA(s0, obs, vo.synth.K_KITTI, ctx=ctx)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        n_obs = int((len(obs) - 2 - 5) // 3)
+        rec = {"ms_per_run": ms, "lm_iterations": info["iterations"], "observations": n_obs,
+               "cost": [info["cost0"], info["cost"]]}
+        if with_cpu:
+            from oracle import vo_oracle
+            vo_oracle.build()
+            t0 = time.perf_counter()
+            vo_oracle.run_ba(s0, obs, vo.synth.K_KITTI)
+            rec["cpu_restatement_ms_per_run"] = (time.perf_counter() - t0) * 1e3
+        out["m=%d" % m] = rec
+    return out
+
+
 def traffic_from_profile(kernel):
     """HBM bytes per launch of `kernel` as the committed rocprofv3 counter passes saw them (newest
     profiles/*_summary.csv that lists it): FETCH_SIZE + WRITE_SIZE, which rocprofv3 reports in KB, as read
@@ -337,6 +363,7 @@ def main():
         klt_frame = bench_klt(vo, torch, ctx, d2, xy0, len(xy0))
         klt_stress = bench_klt(vo, torch, ctx, d2, xy0, 8192)
         image_kernels = bench_image_kernels(vo, torch, ctx, d2[0])
+        ba_runs = bench_ba(vo, ctx, with_cpu=not args.no_cpu_baseline and world == 1) if rank == 0 else None
 
         n, h = args.points, args.hypotheses
         hyps_per_s, score_ms = bench_ransac(vo, torch, ctx, n, h, max(args.steps, 20), args.warmup, 100 + rank)
@@ -385,6 +412,7 @@ def main():
                                      "not by LDS or VALU throughput; the 8192-track launch is the stress configuration",
                              "frame_config": klt_frame, "stress_config": klt_stress},
             "roofline_image_kernels": image_kernels,
+            "bundle_adjustment": ba_runs,
         }
         if not args.no_cpu_baseline and world == 1:
             X0, xy0 = init_points(vo, ctx, scene, frames_all[0], poses_all[0])

@@ -361,6 +361,73 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(ba_problem P, const d
 }
 
 // Sums the partial systems, Cholesky in LDS, pose step dp (np doubles).
+// Solves S x = g (S symmetric positive definite, NP x NP row-major in LDS, g in LDS) with the calling
+// wavefront: lane i keeps row i of the lower triangle in registers (every loop is unrolled, so the
+// row is never indexed dynamically), pivots and multipliers travel by register broadcast.
+// Right-looking Cholesky, then the two substitutions column by column.  Returns false (in every
+// lane) when a pivot is not positive; x = this lane's unknown.
+template <int NP>
+__device__ __forceinline__ bool cholesky_solve_rows(double *S, const double *g, double &x)
+{
+    const int i = threadIdx.x;
+    const bool row = i < NP;
+    double A[NP];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) A[c] = (row && c <= i) ? S[i * NP + c] : 0.0;
+    bool pos = true;
+    double diag = 1.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const double d = readlane_f64(A[j], j);
+        if (!(d > 0.0)) pos = false;
+        const double r = sqrt(d > 0.0 ? d : 1.0);
+        const double Lij = i > j ? A[j] / r : (i == j ? r : 0.0);
+        A[j] = Lij;
+        if (i == j) diag = r;
+#pragma unroll
+        for (int k = j + 1; k < NP; ++k) {
+            const double Lkj = readlane_f64(Lij, k);
+            A[k] -= i >= k ? Lij * Lkj : 0.0;
+            if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (keeps the broadcasts next to their use)
+        }
+    }
+    // the factor goes back to LDS: the backward substitution reads it by columns
+#pragma unroll
+    for (int c = 0; c < NP; ++c)
+        if (row && c <= i) S[i * NP + c] = A[c];
+    __syncthreads();
+    const double inv_diag = 1.0 / diag;
+    double gi = row ? g[i] : 0.0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const double xk = readlane_f64(gi * inv_diag, k);
+        gi = (i == k) ? xk : gi - (i > k ? A[k] : 0.0) * xk;
+    }
+    for (int k = NP - 1; k >= 0; --k) {
+        const double lki = (row && i < k) ? S[k * NP + i] : 0.0;
+        const double xk = readlane_f64(gi * inv_diag, k);
+        gi = (i == k) ? xk : gi - lki * xk;
+    }
+    x = gi;
+    return __builtin_amdgcn_ballot_w64(!pos) == 0;
+}
+
+// sum of the partial systems' entries e, in workgroup order; eight loads are in flight at a time
+__device__ __forceinline__ double ordered_partial_sum(const double *__restrict__ part, size_t stride, int nblocks, int e)
+{
+    double acc = 0.0;
+    int b = 0;
+    for (; b + 8 <= nblocks; b += 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(b + q) * stride + e];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    for (; b < nblocks; ++b) acc += part[(size_t)b * stride + e];
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void ba_solve_kernel(int np, int nblocks, const double *__restrict__ S_part,
                                                        const double *__restrict__ g_part, ba_status *__restrict__ st,
                                                        const int *__restrict__ fail_flag, double *__restrict__ dp)
@@ -370,52 +437,28 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(int np, int nblocks, cons
     __shared__ int ok;
     const int tid = threadIdx.x;
     if (st->done) return;
-    for (int e = tid; e < np * np; e += 256) {
-        double acc = 0.0;
-        for (int b = 0; b < nblocks; ++b) acc += S_part[(size_t)b * np * np + e];
-        S[e] = acc;
-    }
-    for (int e = tid; e < np; e += 256) {
-        double acc = 0.0;
-        for (int b = 0; b < nblocks; ++b) acc += g_part[(size_t)b * np + e];
-        g[e] = -acc;
-    }
+    for (int e = tid; e < np * np; e += blockDim.x) S[e] = ordered_partial_sum(S_part, (size_t)np * np, nblocks, e);
+    for (int e = tid; e < np; e += blockDim.x) g[e] = -ordered_partial_sum(g_part, (size_t)np, nblocks, e);
     if (tid == 0) ok = *fail_flag ? 0 : 1;
     __syncthreads();
-    // right-looking Cholesky, lower triangle
-    for (int j = 0; j < np; ++j) {
-        if (tid == 0) {
-            const double d = S[j * np + j];
-            if (!(d > 0.0)) ok = 0;
-            S[j * np + j] = sqrt(d > 0.0 ? d : 1.0);
-        }
-        __syncthreads();
-        const double d = S[j * np + j];
-        for (int i = j + 1 + tid; i < np; i += 256) S[i * np + j] /= d;
-        __syncthreads();
-        const int rem = np - j - 1;
-        for (int q = tid; q < rem * rem; q += 256) {
-            const int i = j + 1 + q / rem, k = j + 1 + q % rem;
-            if (k <= i) S[i * np + k] -= S[i * np + j] * S[k * np + j];
-        }
-        __syncthreads();
+    // The factorisation and the two substitutions are one wavefront's work (np <= 48 rows, lane i owns
+    // row i, in registers); the other wavefronts leave.
+    if (tid >= 64) return;
+    bool good = false;
+    double x = 0.0;
+    switch (np / 6) {
+    case 1: good = cholesky_solve_rows<6>(S, g, x); break;
+    case 2: good = cholesky_solve_rows<12>(S, g, x); break;
+    case 3: good = cholesky_solve_rows<18>(S, g, x); break;
+    case 4: good = cholesky_solve_rows<24>(S, g, x); break;
+    case 5: good = cholesky_solve_rows<30>(S, g, x); break;
+    case 6: good = cholesky_solve_rows<36>(S, g, x); break;
+    case 7: good = cholesky_solve_rows<42>(S, g, x); break;
+    default: good = cholesky_solve_rows<48>(S, g, x); break;
     }
-    if (tid == 0) {
-        if (ok) {
-            for (int i = 0; i < np; ++i) {
-                double s = g[i];
-                for (int k = 0; k < i; ++k) s -= S[i * np + k] * g[k];
-                g[i] = s / S[i * np + i];
-            }
-            for (int i = np - 1; i >= 0; --i) {
-                double s = g[i];
-                for (int k = i + 1; k < np; ++k) s -= S[k * np + i] * g[k];
-                g[i] = s / S[i * np + i];
-            }
-            for (int i = 0; i < np; ++i) dp[i] = g[i];
-        }
-        st->solve_failed = ok ? 0 : 1;
-    }
+    good = good && ok;
+    if (good && tid < np) dp[tid] = x;
+    if (tid == 0) st->solve_failed = good ? 0 : 1;
 }
 
 // Back-substitution, trial state and its cost.  One thread per landmark.
@@ -884,6 +927,10 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
                            (const double *)d_trial, (double *)d_state, (ba_status *)d_st, (int *)d_fail, max_iter, ftol,
                            xtol);
         VOHIP_HIP(ctx, hipGetLastError());
+        // The status comes back after every third trial only: the kernels of a trial return at once
+        // when the run has ended, so at most two idle trials are enqueued, and two of three
+        // synchronisations are saved.
+        if (trial % 3 != 2 && trial + 1 < max_trials) continue;
         VOHIP_HIP(ctx, hipMemcpyAsync(h_st, d_st, sizeof(ba_status), hipMemcpyDeviceToHost, s));
         VOHIP_HIP(ctx, hipStreamSynchronize(s));
         std::memcpy(&hs, h_st, sizeof(hs));
