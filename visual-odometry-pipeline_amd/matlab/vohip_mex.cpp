@@ -20,9 +20,12 @@
 #include "vohip.h"
 
 static vohip_ctx *g_ctx = nullptr;
+static vohip_frame *g_frame = nullptr;   // the device-resident loop state ('frame_*' opcodes)
 
 static void at_exit()
 {
+    if (g_frame) vohip_frame_destroy(g_frame);
+    g_frame = nullptr;
     if (g_ctx) vohip_destroy(g_ctx);
     g_ctx = nullptr;
 }
@@ -61,6 +64,24 @@ static std::vector<int32_t> idx0(const mxArray *a)
     std::vector<int32_t> v((size_t)numel(a));
     for (size_t i = 0; i < v.size(); ++i) v[i] = (int32_t)p[i] - 1;
     return v;
+}
+
+// [T_W_C, info, status] of the 'frame_step' / 'frame_retry' opcodes
+static void frame_outputs(int nlhs, mxArray *plhs[], const vohip_frame_pose &pose, const vohip_frame_counts &counts,
+                          int status)
+{
+    plhs[0] = mxCreateDoubleMatrix(4, 4, mxREAL);
+    std::memcpy(mxGetDoubles(plhs[0]), pose.T_W_C, sizeof(double) * 16);
+    if (nlhs > 1) {
+        const char *names[] = {"n_tracked", "n_inliers", "n_iter", "num_iterations", "n_landmarks", "n_candidates",
+                               "num_new", "n_detected", "n_kept"};
+        const double values[] = {(double)pose.n_tracked, (double)pose.n_inliers, (double)pose.n_iter, pose.num_iterations,
+                                 (double)counts.n_landmarks, (double)counts.n_candidates, (double)counts.num_new,
+                                 (double)counts.n_detected, (double)counts.n_kept};
+        plhs[1] = mxCreateStructMatrix(1, 1, 9, names);
+        for (int k = 0; k < 9; ++k) mxSetField(plhs[1], 0, names[k], mxCreateDoubleScalar(values[k]));
+    }
+    if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(status);
 }
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
@@ -229,6 +250,83 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                               (int)mxGetScalar(in[3]), (int)mxGetScalar(in[4]), mxGetScalar(in[5]),
                               mxGetDoubles(plhs[0]), (uint8_t *)mxGetLogicals(valid), nullptr));
         plhs[1] = valid;
+    } else if (op == "frame_create") {
+        // vohip_mex('frame_create', K, rows, cols, params struct): the loop body of main_demo.m:377-427 as
+        // one call per frame, state resident on the GPU (one loop per MATLAB session).  params fields
+        // (all optional): r_discard_redundant, angle_threshold_deg, min_depth, max_depth, min_quality,
+        // filter_size, detector, refine_pose.
+        if (g_frame) { vohip_frame_destroy(g_frame); g_frame = nullptr; }
+        vohip_frame_params p;
+        vohip_frame_default_params(&p);
+        if (nrhs > 4 && mxIsStruct(in[3])) {
+            auto field = [&](const char *name, double dflt) {
+                const mxArray *f = mxGetField(in[3], 0, name);
+                return f ? mxGetScalar(f) : dflt;
+            };
+            p.r_discard_redundant = field("r_discard_redundant", p.r_discard_redundant);
+            p.angle_threshold_deg = field("angle_threshold_deg", p.angle_threshold_deg);
+            p.min_depth = field("min_depth", p.min_depth);
+            p.max_depth = field("max_depth", p.max_depth);
+            p.min_quality = field("min_quality", p.min_quality);
+            p.filter_size = (int)field("filter_size", p.filter_size);
+            p.detector = (int)field("detector", p.detector);
+            p.refine_pose = (int)field("refine_pose", p.refine_pose);
+        }
+        check(vohip_frame_create(c, dbl(in[0], "K"), (int)mxGetScalar(in[1]), (int)mxGetScalar(in[2]), 1, &p, &g_frame));
+    } else if (op == "frame_reset") {
+        // vohip_mex('frame_reset', image uint8, X 3xn, P_rc 2xn, T_W_C 4x4)   (main_demo.m:268-303, 342-344)
+        if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
+        if (!mxIsUint8(in[0])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
+        check(vohip_frame_reset(g_frame, mxGetUint8s(in[0]), 0, dbl(in[1], "X"), nullptr, dbl(in[2], "P"), cols(in[1]),
+                                dbl(in[3], "T_W_C")));
+    } else if (op == "frame_step") {
+        // [T_W_C, info, status] = vohip_mex('frame_step', image uint8, u3 3xh, u8 8x500 or [], next_image or [])
+        // u3 / u8: uniform draws (rand); status 0 = done, VOHIP_SAMPLES_EXHAUSTED = call 'frame_retry' with a
+        // longer u3 that starts with the same columns (info.num_iterations says how many are wanted).
+        if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
+        if (!mxIsUint8(in[0])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
+        const bool have_u8 = nrhs > 3 && !mxIsEmpty(in[2]);
+        const bool have_next = nrhs > 4 && !mxIsEmpty(in[3]);
+        if (have_next && !mxIsUint8(in[3])) mexErrMsgIdAndTxt("vohip:type", "next image must be uint8");
+        vohip_frame_pose pose;
+        vohip_frame_counts counts;
+        const int st = vohip_frame_step_ahead(g_frame, mxGetUint8s(in[0]), 0, have_next ? mxGetUint8s(in[3]) : nullptr, 0,
+                                              dbl(in[1], "u3"), cols(in[1]), have_u8 ? dbl(in[2], "u8") : nullptr, &pose,
+                                              &counts);
+        if (st != VOHIP_OK && st != VOHIP_SAMPLES_EXHAUSTED) check(st);
+        frame_outputs(nlhs, plhs, pose, counts, st);
+    } else if (op == "frame_retry") {
+        // [T_W_C, info, status] = vohip_mex('frame_retry', u3 3xh)
+        if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
+        vohip_frame_pose pose;
+        vohip_frame_counts counts;
+        const int st = vohip_frame_retry(g_frame, dbl(in[0], "u3"), cols(in[0]), &pose, &counts);
+        if (st != VOHIP_OK && st != VOHIP_SAMPLES_EXHAUSTED) check(st);
+        frame_outputs(nlhs, plhs, pose, counts, st);
+    } else if (op == "frame_state") {
+        // [P, X, C, F, T] = vohip_mex('frame_state'): S.P 2xn, S.X 4xn (ids in row 4), S.C, S.F 2xm, S.T 12xm
+        if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
+        int nL = 0, nC = 0;
+        check(vohip_frame_sizes(g_frame, &nL, &nC));
+        plhs[0] = mxCreateDoubleMatrix(2, nL, mxREAL);
+        mxArray *X3 = mxCreateDoubleMatrix(3, nL, mxREAL), *ids = mxCreateDoubleMatrix(1, nL, mxREAL);
+        mxArray *C = mxCreateDoubleMatrix(2, nC, mxREAL), *Fm = mxCreateDoubleMatrix(2, nC, mxREAL);
+        mxArray *T = mxCreateDoubleMatrix(12, nC, mxREAL);
+        check(vohip_frame_state(g_frame, mxGetDoubles(plhs[0]), mxGetDoubles(X3), mxGetDoubles(ids), mxGetDoubles(C),
+                                mxGetDoubles(Fm), mxGetDoubles(T)));
+        plhs[1] = mxCreateDoubleMatrix(4, nL, mxREAL);
+        for (int k = 0; k < nL; ++k) {
+            std::memcpy(mxGetDoubles(plhs[1]) + 4 * (size_t)k, mxGetDoubles(X3) + 3 * (size_t)k, sizeof(double) * 3);
+            mxGetDoubles(plhs[1])[4 * (size_t)k + 3] = mxGetDoubles(ids)[k];
+        }
+        mxDestroyArray(X3);
+        mxDestroyArray(ids);
+        plhs[2] = C;
+        plhs[3] = Fm;
+        plhs[4] = T;
+    } else if (op == "frame_destroy") {
+        if (g_frame) vohip_frame_destroy(g_frame);
+        g_frame = nullptr;
     } else {
         mexErrMsgIdAndTxt("vohip:usage", "unknown opcode '%s'", op.c_str());
     }
