@@ -120,7 +120,7 @@ def test_device_loop_accepts_device_images_and_reports_errors(vo, ctx, oracle, s
         vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, ctx=ctx, cap_landmarks=64)
 
 
-@pytest.mark.parametrize("on_device", [False, True])
+@pytest.mark.parametrize("on_device", [False, True, "pinned"])
 def test_preparing_the_next_frame_ahead_changes_nothing(vo, ctx, oracle, sequence, on_device):
     """vohip_frame_step_ahead: with the next image in hand its pyramid and corners are prepared beside
     the current frame's localisation.  Bar: every pose, count and state array bit-identical to the
@@ -129,7 +129,11 @@ def test_preparing_the_next_frame_ahead_changes_nothing(vo, ctx, oracle, sequenc
     scene, poses, frames = sequence
     X0, xy = _start(vo, oracle, sequence)
     hp = vo.default_hyper_paras("kitti")
-    imgs = [torch.from_numpy(f).cuda() for f in frames] if on_device else frames
+    if on_device == "pinned":   # host images in pinned memory are fetched by a kernel, pageable ones by a copy
+        keep = [torch.from_numpy(f).pin_memory() for f in frames]
+        imgs = [t.numpy() for t in keep]
+    else:
+        imgs = [torch.from_numpy(f).cuda() for f in frames] if on_device else frames
     plain = vo.VOPipelineDevice(K, imgs[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(1), ctx=ctx)
     ahead = vo.VOPipelineDevice(K, imgs[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(1), ctx=ctx)
     last = len(frames) - 1
