@@ -97,6 +97,50 @@ def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barr
     return elapsed, info
 
 
+def bench_frames_concurrent(vo, torch, scene, frames, poses, steps, warmup, n_seq):
+    """Batch evaluation on one GPU (main_eval.m:22-23 runs independent sequences): n_seq sequences at the same
+    time, one host thread, context and stream set per sequence; returns the aggregate frames/s.  A single
+    sequence leaves most of the GPU idle (every stage is latency-bound), so independent sequences overlap."""
+    import threading
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_frames = [torch.from_numpy(f).to(dev) for f in frames[:warmup + steps + 2]]
+    seconds = [0.0] * n_seq
+    gate = threading.Barrier(n_seq)
+    errors = []
+
+    def worker(idx):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                ctx = vo.Context(dev.index, stream=stream.cuda_stream)
+                X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
+                pipe = vo.VOPipelineDevice(vo.synth.K_KITTI, d_frames[0], X0, xy0, poses[0],
+                                           hyper_paras=vo.default_hyper_paras("kitti", is_BA=False),
+                                           rng=np.random.default_rng(1000 + idx), ctx=ctx)
+                for i in range(1, warmup + 1):
+                    pipe.process_frame(d_frames[i], next_image=d_frames[i + 1])
+                gate.wait()
+                t0 = time.perf_counter()
+                for i in range(warmup + 1, warmup + steps + 1):
+                    pipe.process_frame(d_frames[i], next_image=d_frames[i + 1])
+                seconds[idx] = time.perf_counter() - t0
+                gate.wait()
+                pipe.close()
+                ctx.close()
+        except Exception as e:   # a failed worker must not leave the others at the barrier
+            errors.append(e)
+            gate.abort()
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_seq)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return n_seq * steps / max(seconds)
+
+
 def bench_ransac(vo, torch, ctx, n, h, steps, warmup, seed):
     """RANSAC stress: h P3P hypotheses scored against n correspondences per step."""
     lib = vo._lib.load()
@@ -363,6 +407,7 @@ def main():
         klt_frame = bench_klt(vo, torch, ctx, d2, xy0, len(xy0))
         klt_stress = bench_klt(vo, torch, ctx, d2, xy0, 8192)
         image_kernels = bench_image_kernels(vo, torch, ctx, d2[0])
+        fps_4seq = bench_frames_concurrent(vo, torch, scene, frames, poses, args.steps, args.warmup, 4) if world == 1 else None
         ba_runs = bench_ba(vo, ctx, with_cpu=not args.no_cpu_baseline and world == 1) if rank == 0 else None
 
         n, h = args.points, args.hypotheses
@@ -398,6 +443,7 @@ def main():
                                         "(MATLAB, Ryzen 7 5800H, real KITTI 05, Harris)"},
             "frames_per_s_pcie_inclusive": args.steps / elapsed_h2d,
             "frames_per_s_without_lookahead": args.steps / elapsed_plain,
+            "frames_per_s_4_sequences_at_once": fps_4seq,   # batch evaluation: independent sequences share the GPU
             "ransac_hypotheses_per_s": hyps_per_s,
             "ransac_config": {"workload": "RANSAC stress: %d P3P hypotheses x %d correspondences per step" % (h, n)},
             "roofline": {"bound": "valu_fp64", "kernel": "p3p_score_kernel (RANSAC stress)", "achieved": achieved,
