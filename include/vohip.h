@@ -256,6 +256,15 @@ int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose 
 int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
                            int next_on_device, const double *u3, int h, const double *u8, vohip_frame_pose *pose,
                            vohip_frame_counts *counts);
+/* vohip_frame_step_ahead in two halves, for a host that has work of its own to do while the GPU
+ * processes the frame (the next frame's draws, bookkeeping of the previous one): vohip_frame_begin
+ * enqueues the frame and returns at once, vohip_frame_finish waits for it and reports exactly as
+ * vohip_frame_step does (including VOHIP_SAMPLES_EXHAUSTED, answered with vohip_frame_retry).  u3 and
+ * u8 are copied before vohip_frame_begin returns; the images are read until vohip_frame_finish (the
+ * following image until the next frame's) returns. */
+int vohip_frame_begin(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
+                      int next_on_device, const double *u3, int h, const double *u8);
+int vohip_frame_finish(vohip_frame *f, vohip_frame_pose *pose, vohip_frame_counts *counts);
 int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates);
 /* Copies of S.P (2xn), S.X(1:3,:) (3xn), S.X(4,:), S.C, S.F (2xm), S.T (12xm); any pointer may be NULL. */
 int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc, double *T12);

@@ -72,6 +72,9 @@ SIGNATURES = {
     "vohip_frame_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_double_p, C.c_int, c_double_p,
                                     C.POINTER(FramePose), C.POINTER(FrameCounts)]),
     "vohip_frame_retry": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.POINTER(FramePose), C.POINTER(FrameCounts)]),
+    "vohip_frame_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_double_p, C.c_int,
+                                     c_double_p]),
+    "vohip_frame_finish": (C.c_int, [C.c_void_p, C.POINTER(FramePose), C.POINTER(FrameCounts)]),
     "vohip_frame_step_ahead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_double_p, C.c_int,
                                           c_double_p, C.POINTER(FramePose), C.POINTER(FrameCounts)]),
     "vohip_frame_sizes": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),

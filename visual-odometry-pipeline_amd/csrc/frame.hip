@@ -660,7 +660,9 @@ struct vohip_frame {
     bool ahead = false;          // the previous call left this image's pyramid and corners on the device
     int n_L = 0, n_C = 0;        // counts at the start of the frame (known to the host)
     int evaluated = 0;           // hypotheses scored in the current frame
-    int stage = 0;               // 0 = between frames, 1 = a frame waits for more hypotheses
+    int stage = 0;               // 0 = between frames, 1 = a frame waits for more hypotheses, 2 = a frame is enqueued
+    int h_cur = 0;               // hypotheses supplied with the enqueued frame
+    double enqueue_us = 0.0;     // host time the enqueue of the current frame took
     bool have_map = false;       // the frame started with candidates (update_landmarks runs)
     std::chrono::steady_clock::time_point t_entry;   // host-side timing of the current call
 };
@@ -895,7 +897,7 @@ int enqueue_tail(vohip_frame *f)
 int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_counts *out)
 {
     vohip_ctx *ctx = f->ctx;
-    const auto t_enq = std::chrono::steady_clock::now();
+    const auto t_wait = std::chrono::steady_clock::now();
     VOHIP_TRY(fetch_summary(f));
     const auto t_done = std::chrono::steady_clock::now();
     const int *hc = pin_cnt(f);
@@ -925,8 +927,8 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     out->n_candidates_inliers = f->have_map ? hc[N_CI] : 0;
     out->fm_trials_run = f->have_map ? hc[F_TRIALS] : 0;
     out->overflow = hc[OVERFLOW];
-    out->host_enqueue_us = std::chrono::duration<double, std::micro>(t_enq - f->t_entry).count();
-    out->host_wait_us = std::chrono::duration<double, std::micro>(t_done - t_enq).count();
+    out->host_enqueue_us = f->enqueue_us;
+    out->host_wait_us = std::chrono::duration<double, std::micro>(t_done - t_wait).count();
     if (f->trace) {
         float ms[8] = {0};
         for (int q = 1; q < 8; ++q) (void)hipEventElapsedTime(&ms[q], f->tr[0], f->tr[q]);
@@ -1164,8 +1166,28 @@ int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_de
                            vohip_frame_counts *counts)
 {
     if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(f->ctx, pose && counts, "NULL argument");
+    VOHIP_TRY(vohip_frame_begin(f, image, image_on_device, next_image, next_on_device, u3, h, u8));
+    return vohip_frame_finish(f, pose, counts);
+}
+
+int vohip_frame_finish(vohip_frame *f, vohip_frame_pose *pose, vohip_frame_counts *counts)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
     vohip_ctx *ctx = f->ctx;
-    VOHIP_REQUIRE(ctx, image && u3 && pose && counts, "NULL argument");
+    VOHIP_REQUIRE(ctx, pose && counts, "NULL argument");
+    VOHIP_REQUIRE(ctx, f->stage == 2, "no frame is enqueued (vohip_frame_begin)");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    f->stage = 1;
+    return complete_frame(f, f->h_cur, pose, counts);
+}
+
+int vohip_frame_begin(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
+                      int next_on_device, const double *u3, int h, const double *u8)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, image && u3, "NULL argument");
     VOHIP_REQUIRE(ctx, f->stage == 0, "a frame is still waiting for vohip_frame_retry");
     VOHIP_REQUIRE(ctx, h >= 1 && h <= f->hmax, "hypothesis count outside 1..max_hypotheses");
     VOHIP_REQUIRE(ctx, f->n_C == 0 || u8, "candidates exist: the fundamental-matrix draws are needed");
@@ -1234,7 +1256,10 @@ int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_de
     if (f->trace) (void)hipEventRecord(f->tr[2], s);   // pose refined
     VOHIP_TRY(enqueue_side_filter(f, u8));
     VOHIP_TRY(enqueue_tail(f));
-    return complete_frame(f, h, pose, counts);
+    f->h_cur = h;
+    f->stage = 2;
+    f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
+    return VOHIP_OK;
 }
 
 int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *counts)
@@ -1248,6 +1273,7 @@ int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose 
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     VOHIP_TRY(enqueue_localize(f, u3, h, 0));
     VOHIP_TRY(enqueue_tail(f));
+    f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
     return complete_frame(f, h, pose, counts);
 }
 

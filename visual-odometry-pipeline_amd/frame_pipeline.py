@@ -73,6 +73,8 @@ class VOPipelineDevice:
         self.ctx.check(lib.vohip_frame_reset(self._h, ptr, on_dev, dptr(X), None, dptr(P_rc), X.shape[0],
                                              dptr(colmajor(T))))
         self._keep_images = (keep, None)
+        self._next_image = None
+        self._u8_ahead = None
         self.est_trans = [T[:3, 3].copy()]
         self.est_rot = [T[:3, :3].reshape(-1, order="F").copy()]
         self.num_X, self.num_C, self.num_new = [X.shape[0]], [0], [0]
@@ -98,16 +100,28 @@ class VOPipelineDevice:
         caller already holds it (a stored sequence): its transfer, pyramid and corner detection then run
         beside this frame's localisation; the results do not change, and the next call must pass that image."""
         lib = _lib.load()
-        ptr, on_dev, keep = self._image_ptr(image)
+        if self._next_image is not None and image is self._next_image[0]:
+            ptr, on_dev, keep = self._next_image[1]          # handed over ahead by the previous call
+        else:
+            ptr, on_dev, keep = self._image_ptr(image)
         nptr, non_dev, nkeep = self._image_ptr(next_image) if next_image is not None else (None, 0, None)
+        self._next_image = (next_image, (nptr, non_dev, nkeep)) if next_image is not None else None
         pose, counts = _lib.FramePose(), _lib.FrameCounts()
         have_map = self.num_C[-1] > 0                                                       # :406
-        u8 = self.rng_map.random((self.params.fm_trials, 8)) if have_map else None          # update_landmarks.m:13
+        u8 = None
+        if have_map:                                                                        # update_landmarks.m:13
+            u8 = self._u8_ahead if self._u8_ahead is not None else self.rng_map.random((self.params.fm_trials, 8))
+        self._u8_ahead = None
         state = self.rng.bit_generator.state
         have = 104
         u3 = self.rng.random((have, 3))                                                     # :387-388
-        st = lib.vohip_frame_step_ahead(self._h, ptr, on_dev, nptr, non_dev, dptr(u3), have,
-                                        dptr(u8) if have_map else None, C.byref(pose), C.byref(counts))
+        self.ctx.check(lib.vohip_frame_begin(self._h, ptr, on_dev, nptr, non_dev, dptr(u3), have,
+                                             dptr(u8) if have_map else None))
+        # while the GPU works on this frame: the trial draws of the next one (its generator is independent
+        # of the localisation's; they are given back if the next frame turns out to have no candidates)
+        state_map = self.rng_map.bit_generator.state
+        u8_ahead = self.rng_map.random((self.params.fm_trials, 8))
+        st = lib.vohip_frame_finish(self._h, C.byref(pose), C.byref(counts))
         while st == VOHIP_SAMPLES_EXHAUSTED and have < MAX_ITERATIONS:
             have = min(max(8 * have, int(np.ceil(pose.num_iterations)) + 8), MAX_ITERATIONS)
             self.rng.bit_generator.state = state
@@ -117,6 +131,8 @@ class VOPipelineDevice:
         self.rng.bit_generator.state = state
         if pose.n_iter > 0:
             self.rng.random((pose.n_iter, 3))       # the generator as n_iter executed iterations leave it
+        if st != 0:
+            self.rng_map.bit_generator.state = state_map
         if st == VOHIP_NO_MODEL:
             raise RuntimeError("ransacLocalization found no pose (the reference fails here too, main_demo.m:389-391)")
         self.ctx.check(st)
@@ -127,6 +143,10 @@ class VOPipelineDevice:
             self.num_new.append(counts.num_new)                                             # update_landmarks.m:124
         self.num_X.append(counts.n_landmarks)                                               # :426-427
         self.num_C.append(counts.n_candidates)
+        if counts.n_candidates > 0:
+            self._u8_ahead = u8_ahead
+        else:
+            self.rng_map.bit_generator.state = state_map
         self.frames += 1
         self.last_pose, self.last_counts = pose, counts
         return T_W_C
