@@ -83,44 +83,78 @@ __global__ __launch_bounds__(128) void triangulate_refine_kernel(const double *_
 // update_candidate.m:14-24.  One wavefront per new detection; its lanes stride over the existing
 // points (S.C then S.P, rounded to single exactly as MATLAB's single/double comparison does) and a
 // ballot ends the search at the first hit.
-__global__ __launch_bounds__(256) void candidate_filter_kernel(const float *__restrict__ new_xy, int ld, int n_new,
-                                                               const double *__restrict__ C_rc, int nC,
-                                                               const double *__restrict__ P_rc, int nP,
-                                                               const int *__restrict__ counts_dev, float r,
-                                                               uint8_t *__restrict__ keep)
+// update_candidate.m:12-27: a detection is dropped when an existing candidate or landmark lies in the
+// (2r+1)-box around it.  A workgroup of 16 wavefronts serves FILT_DET detections: the existing points
+// are staged in LDS as floats (the comparison is made in single precision, as the reference's
+// single-precision detections make it), FILT_CHUNK at a time; each wavefront then scans them for
+// its detections, one after the other, 64 points per step.
+constexpr int FILT_THREADS = 1024;
+constexpr int FILT_DET = 16;      // detections per workgroup (one per wavefront)
+constexpr int FILT_CHUNK = 4096;  // existing points staged at a time (32 KB)
+
+__global__ __launch_bounds__(FILT_THREADS) void candidate_filter_kernel(const float *__restrict__ new_xy, int ld, int n_new,
+                                                                        const double *__restrict__ C_rc, int nC,
+                                                                        const double *__restrict__ P_rc, int nP,
+                                                                        const int *__restrict__ counts_dev, float r,
+                                                                        uint8_t *__restrict__ keep)
 {
+    __shared__ float2 sP[FILT_CHUNK];   // (col, row) of existing points
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER_WAVE = FILT_DET / (FILT_THREADS / 64);
+    const int first = blockIdx.x * FILT_DET + wave * PER_WAVE;
+    float xs[PER_WAVE], ys[PER_WAVE];
+#pragma unroll
+    for (int d = 0; d < PER_WAVE; ++d) {   // (issued before the counts are known: one round trip less)
+        const int i = first + d < n_new ? first + d : 0;
+        xs[d] = new_xy[i];
+        ys[d] = new_xy[ld + i];
+    }
     if (counts_dev) {  // {n_new, nC, nP} kept on the device (the frame pipeline); n_new is clamped
         n_new = min(counts_dev[0], n_new);
         nC = counts_dev[1];
         nP = counts_dev[2];
     }
-    // one wavefront per new point: the lanes stride over C and then P, 4 loads in flight each
-    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (i >= n_new) return;
-    const float x = new_xy[i], y = new_xy[ld + i];
-    const float u0 = x - r, u1 = x + r, v0 = y - r, v1 = y + r;
-    bool near = false;
-    const int total = nC + nP;
-    for (int base = 0; base < total; base += 256) {
-        double qr[4], qc[4];
+    if (blockIdx.x * FILT_DET >= n_new) return;   // (the whole workgroup)
+    float u0[PER_WAVE], u1[PER_WAVE], v0[PER_WAVE], v1[PER_WAVE];
+    bool near[PER_WAVE];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int g = base + 64 * u + lane;
-            const int gg = g < total ? g : 0;
-            const double *src = gg < nC ? C_rc + 2 * (size_t)gg : P_rc + 2 * (size_t)(gg - nC);
-            qr[u] = src[0];
-            qc[u] = src[1];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float qx = (float)qc[u], qy = (float)qr[u];  // (u = col, v = row)
-            near = near || (base + 64 * u + lane < total && qx >= u0 && qx <= u1 && qy >= v0 && qy <= v1);
-        }
-        if (__ballot(near)) break;
+    for (int d = 0; d < PER_WAVE; ++d) {
+        const float x = xs[d], y = ys[d];
+        u0[d] = x - r;
+        u1[d] = x + r;
+        v0[d] = y - r;
+        v1[d] = y + r;
+        near[d] = false;
     }
-    const bool any = __ballot(near) != 0ull;
-    if (lane == 0) keep[i] = (nC == 0) ? 1 : (any ? 0 : 1);
+    const int total = nC + nP;
+    for (int base = 0; base < total; base += FILT_CHUNK) {
+        const int cnt = min(FILT_CHUNK, total - base);
+        __syncthreads();
+        for (int k = tid; k < cnt; k += FILT_THREADS) {
+            const int g = base + k;
+            const double *src = g < nC ? C_rc + 2 * (size_t)g : P_rc + 2 * (size_t)(g - nC);
+            sP[k] = make_float2((float)src[1], (float)src[0]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < PER_WAVE; ++d) {
+            if (first + d >= n_new || __ballot(near[d])) continue;   // (wave-uniform)
+            for (int k0 = 0; k0 < cnt; k0 += 256) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 64 * u + lane;
+                    const float2 q = sP[k < cnt ? k : 0];
+                    near[d] = near[d] || (k < cnt && q.x >= u0[d] && q.x <= u1[d] && q.y >= v0[d] && q.y <= v1[d]);
+                }
+                if (__ballot(near[d])) break;
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < PER_WAVE; ++d) {
+        const bool any = __ballot(near[d]) != 0ull;
+        if (lane == 0 && first + d < n_new) keep[first + d] = (nC == 0) ? 1 : (any ? 0 : 1);
+    }
 }
 
 struct cand_params {
@@ -252,7 +286,7 @@ int vohip_candidate_filter_dev(vohip_ctx *ctx, const float *d_new_xy, int n_new,
     VOHIP_REQUIRE(ctx, n_new >= 0 && nC >= 0 && nP >= 0 && d_keep, "bad argument");
     VOHIP_REQUIRE(ctx, (n_new == 0 || d_new_xy) && (nC == 0 || d_C_rc) && (nP == 0 || d_P_rc), "NULL array");
     if (n_new == 0) return VOHIP_OK;
-    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new + 3) / 4), dim3(256), 0, ctx->stream, d_new_xy, n_new,
+    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new + FILT_DET - 1) / FILT_DET), dim3(FILT_THREADS), 0, ctx->stream, d_new_xy, n_new,
                        n_new, d_C_rc, nC, d_P_rc, nP, (const int *)nullptr, (float)r, d_keep);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
@@ -266,7 +300,7 @@ int vohip_candidate_filter_enqueue(vohip_ctx *ctx, const float *d_new_xy, int ld
                                    const double *d_P_rc, const int *d_counts3, double r, uint8_t *d_keep)
 {
     if (n_new_cap <= 0) return VOHIP_OK;
-    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new_cap + 3) / 4), dim3(256), 0, ctx->stream, d_new_xy, ld,
+    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new_cap + FILT_DET - 1) / FILT_DET), dim3(FILT_THREADS), 0, ctx->stream, d_new_xy, ld,
                        n_new_cap, d_C_rc, 0, d_P_rc, 0, d_counts3, (float)r, d_keep);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
