@@ -204,12 +204,14 @@ __device__ __forceinline__ int wave_prefix_max(int v, int lane)
 // (:77-101, strict '>'), running maximum (:104-110), adaptive bound (:118-129).  The bound is a
 // function of the running maximum only, so one wavefront replays 64 iterations at a time: prefix
 // maximum, bound per lane, first lane at which the loop condition fails.
-__global__ __launch_bounds__(64) void localize_decide_kernel(const int32_t *__restrict__ counts, int evaluated,
-                                                             const double *__restrict__ Rt_all,
-                                                             const double *__restrict__ M_all,
-                                                             int *__restrict__ cnt, double *__restrict__ dv)
+// Executed by ONE wavefront (all 64 lanes); `publish`: this wavefront also writes the outcome to the
+// device arrays (every workgroup of the selection kernel replays the rule, one of them publishes).
+// Returns the index of the winning pose (4 * hypothesis + solution), or -1, in every lane.
+__device__ int localize_decide(const int32_t *__restrict__ counts, int evaluated, const double *__restrict__ Rt_all,
+                               const double *__restrict__ M_all, int *__restrict__ cnt, double *__restrict__ dv,
+                               bool publish)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int n = cnt[N_V];
     int run_max = 0, best_h = -1, best_s = 0, n_iter = 0;
     double num_iterations = INFINITY;
@@ -259,7 +261,8 @@ __global__ __launch_bounds__(64) void localize_decide_kernel(const int32_t *__re
             }
         }
     }
-    if (lane != 0) return;
+    const int winner = best_h >= 0 ? 4 * best_h + best_s : -1;
+    if (lane != 0 || !publish) return winner;
     cnt[R_ITER] = n_iter;
     cnt[R_FOUND] = best_h >= 0 ? 1 : 0;
     cnt[R_EXHAUSTED] = exhausted ? 1 : 0;
@@ -286,23 +289,35 @@ __global__ __launch_bounds__(64) void localize_decide_kernel(const int32_t *__re
         const double nan = __builtin_nan("");
         for (int q = 0; q < 12; ++q) dv[D_M + q] = nan;   // no point is an inlier of a NaN pose
     }
+    return winner;
 }
 
 // main_demo.m:394-396: S.P, S.X restricted to the inliers of the winning pose (the same test,
 // operation for operation, as the scoring kernel counts with); also the (u, v) copy the refinement reads.
-__global__ __launch_bounds__(256) void select_inliers_kernel(const double *__restrict__ mv_rc,
+__global__ __launch_bounds__(256) void select_inliers_kernel(const int32_t *__restrict__ counts4, int evaluated,
+                                                             const double *__restrict__ Rt_all,
+                                                             const double *__restrict__ M_all,
+                                                             const double *__restrict__ mv_rc,
                                                              const double *__restrict__ Xv,
                                                              const double *__restrict__ idv,
                                                              const int32_t *__restrict__ rowv,
-                                                             const double *__restrict__ dv,
+                                                             double *__restrict__ dv,
                                                              int *__restrict__ cnt, double *__restrict__ L_rc,
                                                              double *__restrict__ L_X, double *__restrict__ L_id,
                                                              int32_t *__restrict__ srcL, double *__restrict__ kp_uv)
 {
     __shared__ int sh[12];
+    __shared__ int s_winner;
     const int n = cnt[N_V];
+    // the stopping rule of the localisation, replayed by the first wavefront of every workgroup (the
+    // scored hypotheses are few: cheaper than a kernel of its own); workgroup 0 publishes the outcome
+    if (threadIdx.x < 64) {
+        const int w = localize_decide(counts4, evaluated, Rt_all, M_all, cnt, dv, blockIdx.x == 0);
+        if (threadIdx.x == 0) s_winner = w;
+    }
+    __syncthreads();
     double m[12];   // K [R | t] of the winning hypothesis (NaN when there is none: nothing is an inlier)
-    for (int q = 0; q < 12; ++q) m[q] = dv[D_M + q];
+    for (int q = 0; q < 12; ++q) m[q] = s_winner >= 0 ? M_all[(size_t)s_winner * 12 + q] : __builtin_nan("");
     auto inlier = [&](int j) {
         return vohip_dev::is_inlier(m, Xv[3 * j], Xv[3 * j + 1], Xv[3 * j + 2], mv_rc[2 * j + 1], mv_rc[2 * j]);
     };
@@ -330,6 +345,24 @@ __global__ __launch_bounds__(256) void select_inliers_kernel(const double *__res
     }
 }
 
+// uniform draws -> a set of 8 distinct indices in [0, n): draw k picks the floor(u_k (n - k))-th
+// index not picked before.
+__device__ __forceinline__ void octet_from_uniforms(const double *u, int n, int32_t *s)
+{
+    int chosen[8];   // sorted
+    for (int k = 0; k < 8; ++k) {
+        int idx = min((int)(u[k] * (double)(n - k)), n - k - 1);
+        for (int m = 0; m < k; ++m) idx += idx >= chosen[m];
+        s[k] = idx;
+        int pos = k;
+        while (pos > 0 && chosen[pos - 1] > idx) {
+            chosen[pos] = chosen[pos - 1];
+            --pos;
+        }
+        chosen[pos] = idx;
+    }
+}
+
 // update_landmarks.m:10-11,20-25: candidates whose track is valid, with their first observation.
 __global__ __launch_bounds__(256) void select_cand_tracked_kernel(const double *__restrict__ out_xy, int ld,
                                                                   const uint8_t *__restrict__ valid,
@@ -339,7 +372,8 @@ __global__ __launch_bounds__(256) void select_cand_tracked_kernel(const double *
                                                                   double *__restrict__ p1_rc, double *__restrict__ m_rc,
                                                                   double *__restrict__ F_t, double *__restrict__ T_t,
                                                                   int row_base, int32_t *__restrict__ row_t,
-                                                                  int *__restrict__ cnt)
+                                                                  int *__restrict__ cnt, const double *__restrict__ u8,
+                                                                  int trials, int32_t *__restrict__ samples8)
 {
     __shared__ int sh[12];
     int total;
@@ -355,28 +389,12 @@ __global__ __launch_bounds__(256) void select_cand_tracked_kernel(const double *
         for (int q = 0; q < 12; ++q) T_t[12 * (size_t)r + q] = T12[12 * (size_t)i + q];
         row_t[r] = row_base + i;   // candidate i is row row_base + i of the track table
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[N_CV] = total;
-}
-
-// uniform draws -> sets of 8 distinct indices in [0, n): draw k picks the floor(u_k (n - k))-th
-// index not picked before.
-__global__ __launch_bounds__(64) void octets_kernel(const double *__restrict__ u, int trials,
-                                                    const int *__restrict__ cnt, int32_t *__restrict__ samples)
-{
-    const int t = blockIdx.x * 64 + threadIdx.x;
-    if (t >= trials) return;
-    const int n = cnt[N_CV];
-    int chosen[8];   // sorted
-    for (int k = 0; k < 8; ++k) {
-        int idx = min((int)(u[8 * (size_t)t + k] * (double)(n - k)), n - k - 1);
-        for (int m = 0; m < k; ++m) idx += idx >= chosen[m];
-        samples[8 * (size_t)t + k] = idx;
-        int pos = k;
-        while (pos > 0 && chosen[pos - 1] > idx) {
-            chosen[pos] = chosen[pos - 1];
-            --pos;
-        }
-        chosen[pos] = idx;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) cnt[N_CV] = total;
+        // the trial samples (update_landmarks.m:13): every thread of this workgroup knows the count already
+        if (total >= 8)
+            for (int t = threadIdx.x; t < trials; t += 256)
+                octet_from_uniforms(u8 + 8 * (size_t)t, total, samples8 + 8 * (size_t)t);
     }
 }
 
@@ -791,8 +809,7 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
     if (f->have_map) {
         hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->U_xy[f->par] + f->capL,
                            f->capU, f->U_live[f->par] + f->capL, f->C_rc, f->F_rc, f->T12, f->n_C, f->p1_rc, f->m_rc, f->F_t,
-                           f->T_t, f->capL, f->row_t, f->cnt);
-        hipLaunchKernelGGL(octets_kernel, dim3((T + 63) / 64), dim3(64), 0, s, f->u8, T, f->cnt, f->samples8);
+                           f->T_t, f->capL, f->row_t, f->cnt, f->u8, T, f->samples8);
         VOHIP_TRY(vohip_fm_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->samples8, T, p.fm_threshold,
                                    f->dv + D_NRM, f->fm_F, f->fm_counts));
         hipLaunchKernelGGL(fm_decide_kernel, dim3(1), dim3(64), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
@@ -852,10 +869,9 @@ int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready)
     VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
                                    f->counts4));
     f->evaluated = h;
-    hipLaunchKernelGGL(localize_decide_kernel, dim3(1), dim3(64), 0, s, f->counts4, h,
-                       (const double *)ctx->bufs[B_RANSAC_RT].ptr, (const double *)ctx->bufs[B_RANSAC_M].ptr, f->cnt,
-                       f->dv);
-    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->mv_rc, f->Xv, f->idv, f->rowv,
+    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->counts4, h,
+                       (const double *)ctx->bufs[B_RANSAC_RT].ptr, (const double *)ctx->bufs[B_RANSAC_M].ptr, f->mv_rc,
+                       f->Xv, f->idv, f->rowv,
                        f->dv, f->cnt, f->L_rc, f->L_X, f->L_id, f->srcL, f->kp_uv);
     VOHIP_HIP(ctx, hipGetLastError());
     if (p.refine_pose)   // main_demo.m:398-400
