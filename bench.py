@@ -446,7 +446,11 @@ def main():
             "frames_per_s_4_sequences_at_once": fps_4seq,   # batch evaluation: independent sequences share the GPU
             "ransac_hypotheses_per_s": hyps_per_s,
             "ransac_config": {"workload": "RANSAC stress: %d P3P hypotheses x %d correspondences per step" % (h, n)},
-            "roofline": {"bound": "valu_fp64", "kernel": "p3p_score_kernel (RANSAC stress)", "achieved": achieved,
+            "roofline": {"bound": "valu_fp64",
+                         "bound_note": "compute roofline: the kernel is fp64 FMA arithmetic on the vector ALUs; on gfx950 the "
+                                       "fp64 vector and matrix (MFMA) peaks are the same 78.6 TFLOP/s, and 72 TFLOP/s is what a "
+                                       "register-only FMA loop sustains (tools/micro/fp64_peak.hip)",
+                         "kernel": "p3p_score_kernel (RANSAC stress)", "achieved": achieved,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS,
                          "traffic": traffic["bytes"] if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
