@@ -4,8 +4,9 @@
 // solveQuartic.m:26-66 and projectPoints.m:1-16 of the reference.
 //
 // Three kernels:
-//   p3p_solve_kernel   one THREAD per hypothesis: sample -> bearings -> Kneip P3P -> the four
-//                      candidate poses [R_C_W | t_C_W] and the fused projection K [R | t].
+//   p3p_solve_kernel   FOUR LANES per hypothesis: sample -> bearings -> Kneip P3P up to the roots of
+//                      the quartic (by each of the four), then one candidate pose per lane:
+//                      [R_C_W | t_C_W] and the fused projection K [R | t].
 //                      Written statement for statement in the reference's evaluation order and
 //                      compiled without FMA contraction, so poses agree with a CPU evaluation
 //                      of the same statements up to the last bits of pow/atan2/sincos.
@@ -170,11 +171,17 @@ __device__ __forceinline__ void camera_frame(v3 f1, v3 f2, v3 f3in, m3 &T, v3 &f
 
 // Kneip P3P, p3p.m:41-217.  out[s][0..2] = C (camera position), out[s][3..11] = R_W_C
 // column-major.  Returns false (and leaves `out` zeroed) for collinear world points.
-__device__ bool p3p_solve(v3 W1, v3 W2, v3 W3, v3 b1, v3 b2, v3 b3, double out[4][12])
-{
-    for (int s = 0; s < 4; ++s)
-        for (int j = 0; j < 12; ++j) out[s][j] = 0.0;
+// What the four solutions of one P3P problem share (p3p.m:41-185): the two intermediate frames, the
+// scalars of the quartic and its four roots.
+struct p3p_shared {
+    v3 P1;
+    m3 T, N;
+    double f_1, f_2, p_1, p_2, d_12, b;
+    double xr[4];
+};
 
+__device__ bool p3p_prepare(v3 W1, v3 W2, v3 W3, v3 b1, v3 b2, v3 b3, p3p_shared &q)
+{
     v3 cr = vcross(vsub(W2, W1), vsub(W3, W1));
     if (sqrt(vdot(cr, cr)) == 0.0) return false;
 
@@ -233,12 +240,26 @@ __device__ bool p3p_solve(v3 W1, v3 W2, v3 W3, v3 b1, v3 b2, v3 b3, double out[4
              2.0 * f_2_pw2 * p_2_pw2 * p_1 * d_12 + p_2_pw2 * f_1_pw2 * p_1_pw2 +
              f_2_pw2 * p_2_pw2 * d_12_pw2 * b_pw2;
 
-    double xr[4];
-    solve_quartic_real(fac, xr);
+    solve_quartic_real(fac, q.xr);
+    q.P1 = P1;
+    q.T = T;
+    q.N = N;
+    q.f_1 = f_1;
+    q.f_2 = f_2;
+    q.p_1 = p_1;
+    q.p_2 = p_2;
+    q.d_12 = d_12;
+    q.b = b;
+    return true;
+}
 
-    // p3p.m:187-215
-    for (int s = 0; s < 4; ++s) {
-        const double x = xr[s];
+// p3p.m:187-215 for the root x: out = [C | R_W_C col-major].
+__device__ void p3p_solution(const p3p_shared &q, double x, double out[12])
+{
+    const v3 P1 = q.P1;
+    const m3 &T = q.T, &N = q.N;
+    const double f_1 = q.f_1, f_2 = q.f_2, p_1 = q.p_1, p_2 = q.p_2, d_12 = q.d_12, b = q.b;
+    {
         const double cot_alpha =
             (-f_1 * p_1 / f_2 - x * p_2 + d_12 * b) / (-f_1 * x * p_2 / f_2 + p_1 - d_12);
         const double cos_theta = x;
@@ -253,9 +274,9 @@ __device__ bool p3p_solve(v3 W1, v3 W2, v3 W3, v3 b1, v3 b2, v3 b3, double out[4
         const v3 Cv = {d_12 * cos_alpha * k, cos_theta * d_12 * sin_alpha * k,
                        sin_theta * d_12 * sin_alpha * k};
         // C = P1 + N' * Cv
-        out[s][0] = P1.x + (N.r0.x * Cv.x + N.r1.x * Cv.y + N.r2.x * Cv.z);
-        out[s][1] = P1.y + (N.r0.y * Cv.x + N.r1.y * Cv.y + N.r2.y * Cv.z);
-        out[s][2] = P1.z + (N.r0.z * Cv.x + N.r1.z * Cv.y + N.r2.z * Cv.z);
+        out[0] = P1.x + (N.r0.x * Cv.x + N.r1.x * Cv.y + N.r2.x * Cv.z);
+        out[1] = P1.y + (N.r0.y * Cv.x + N.r1.y * Cv.y + N.r2.y * Cv.z);
+        out[2] = P1.z + (N.r0.z * Cv.x + N.r1.z * Cv.y + N.r2.z * Cv.z);
 
         const m3 Rm = {{-cos_alpha, -sin_alpha * cos_theta, -sin_alpha * sin_theta},
                        {sin_alpha, -cos_alpha * cos_theta, -cos_alpha * sin_theta},
@@ -267,11 +288,21 @@ __device__ bool p3p_solve(v3 W1, v3 W2, v3 W3, v3 b1, v3 b2, v3 b3, double out[4
             const double c0 = nr.x * T.r0.x + nr.y * T.r1.x + nr.z * T.r2.x;
             const double c1 = nr.x * T.r0.y + nr.y * T.r1.y + nr.z * T.r2.y;
             const double c2 = nr.x * T.r0.z + nr.y * T.r1.z + nr.z * T.r2.z;
-            out[s][3 + r] = c0;      // column 0 of R_W_C
-            out[s][6 + r] = c1;      // column 1
-            out[s][9 + r] = c2;      // column 2
+            out[3 + r] = c0;      // column 0 of R_W_C
+            out[6 + r] = c1;      // column 1
+            out[9 + r] = c2;      // column 2
         }
     }
+}
+
+// p3p.m:41-217: all four solutions (zeros for a degenerate world triangle, p3p.m:59-62).
+__device__ bool p3p_solve(v3 W1, v3 W2, v3 W3, v3 b1, v3 b2, v3 b3, double out[4][12])
+{
+    for (int s = 0; s < 4; ++s)
+        for (int j = 0; j < 12; ++j) out[s][j] = 0.0;
+    p3p_shared q;
+    if (!p3p_prepare(W1, W2, W3, b1, b2, b3, q)) return false;
+    for (int s = 0; s < 4; ++s) p3p_solution(q, q.xr[s], out[s]);
     return true;
 }
 
@@ -308,7 +339,11 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double *__restrict_
                                                        double *__restrict__ Rt_out,
                                                        double *__restrict__ M_out)
 {
-    const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
+    // four lanes per hypothesis: the part the four solutions share is computed by each of them (same
+    // operations, same bits), then every lane finishes ONE solution -- the dependent chain of a lane is
+    // what this launch lasts, and the four back-substitutions were more than half of it
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int hyp = t >> 2, sol = t & 3;
     if (hyp >= h) return;
     if (n_dev) n = *n_dev;  // point count kept on the device (the frame pipeline)
     v3 W[3], bearing[3];
@@ -322,16 +357,19 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double *__restrict_
         W[c] = {X[3 * id], X[3 * id + 1], X[3 * id + 2]};
         bearing[c] = unit_bearing(K, kp_rc[2 * id + 1], kp_rc[2 * id]);
     }
-    double poses[4][12];
-    p3p_solve(W[0], W[1], W[2], bearing[0], bearing[1], bearing[2], poses);
+    double pose[12];
+    for (int j = 0; j < 12; ++j) pose[j] = 0.0;
+    p3p_shared q;
+    if (p3p_prepare(W[0], W[1], W[2], bearing[0], bearing[1], bearing[2], q)) {
+        const double x = sol == 0 ? q.xr[0] : sol == 1 ? q.xr[1] : sol == 2 ? q.xr[2] : q.xr[3];
+        p3p_solution(q, x, pose);
+    }
     const double nan = __builtin_nan("");
-    for (int s = 0; s < 4; ++s) {
-        double Rt[12], M[12];
-        decode_pose(K, poses[s], Rt, M);
-        for (int j = 0; j < 12; ++j) {
-            Rt_out[(size_t)hyp * 48 + 12 * s + j] = ok ? Rt[j] : nan;
-            M_out[(size_t)hyp * 48 + 12 * s + j] = ok ? M[j] : nan;
-        }
+    double Rt[12], M[12];
+    decode_pose(K, pose, Rt, M);
+    for (int j = 0; j < 12; ++j) {
+        Rt_out[(size_t)hyp * 48 + 12 * sol + j] = ok ? Rt[j] : nan;
+        M_out[(size_t)hyp * 48 + 12 * sol + j] = ok ? M[j] : nan;
     }
 }
 
@@ -558,7 +596,7 @@ int launch_solve(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n
     VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_RANSAC_M], (size_t)h * 48 * sizeof(double)));
     ctx->ransac_h = h;
     const vohip_K Kv = vohip_make_K(K);
-    hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n,
+    hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n,
                        (const int *)nullptr, Kv, d_samples, h, (double *)ctx->bufs[B_RANSAC_RT].ptr,
                        (double *)ctx->bufs[B_RANSAC_M].ptr);
     VOHIP_HIP(ctx, hipGetLastError());
@@ -611,7 +649,7 @@ int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
     double *d_Rt = (double *)ctx->bufs[B_RANSAC_RT].ptr + (size_t)first * 48;
     double *d_M = (double *)ctx->bufs[B_RANSAC_M].ptr + (size_t)first * 48;
     const vohip_K Kv = vohip_make_K(K);
-    hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 63) / 64), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n, d_n, Kv,
+    hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n, d_n, Kv,
                        d_samples + 3 * (size_t)first, h, d_Rt, d_M);
     VOHIP_TRY(launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, h, d_counts + 4 * (size_t)first, d_n));
     if (ctx->ransac_h < first + h) ctx->ransac_h = first + h;
@@ -745,7 +783,7 @@ int vohip_ransac_p3p(vohip_ctx *ctx, const double *kp_rc, const double *X, int n
             if (want < 64) want = 64;
             want = (want + SCORE_WAVES - 1) / SCORE_WAVES * SCORE_WAVES;
             if (want > hcap - evaluated) want = hcap - evaluated;
-            hipLaunchKernelGGL(p3p_solve_kernel, dim3((want + 63) / 64), dim3(64), 0, st, d_kp, d_X, n,
+            hipLaunchKernelGGL(p3p_solve_kernel, dim3((want + 15) / 16), dim3(64), 0, st, d_kp, d_X, n,
                                (const int *)nullptr, Kv, d_samples + 3 * (size_t)evaluated, want, d_Rt + (size_t)evaluated * 48,
                                d_M + (size_t)evaluated * 48);
             VOHIP_TRY(launch_score_variant(ctx, d_kp, d_X, n, d_M + (size_t)evaluated * 48, want,
