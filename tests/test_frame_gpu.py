@@ -153,3 +153,39 @@ def test_preparing_the_next_frame_ahead_changes_nothing(vo, ctx, oracle, sequenc
     assert ahead.rng.bit_generator.state == plain.rng.bit_generator.state
     plain.close()
     ahead.close()
+
+
+def test_one_call_entry_points_match_the_two_halves(vo, ctx, oracle, sequence):
+    """vohip_frame_step / vohip_frame_step_ahead (one call per frame) against vohip_frame_begin +
+    vohip_frame_finish, which VOPipelineDevice uses: same draws in, identical poses and counts out; and
+    the state machine refuses a finish without a begin."""
+    import ctypes as C
+    lib = vo._lib.load()
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    a = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(5), ctx=ctx)
+    b = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(5), ctx=ctx)
+    pose, counts = vo._lib.FramePose(), vo._lib.FrameCounts()
+    assert lib.vohip_frame_finish(b._h, C.byref(pose), C.byref(counts)) != 0      # nothing was begun
+    n_C = 0
+    for i in range(1, 6):
+        Ta = a.process_frame(frames[i])
+        # the same frame through the one-call entry points, with the draws process_frame makes
+        u8 = b.rng_map.random((b.params.fm_trials, 8)) if n_C > 0 else None
+        state = b.rng.bit_generator.state
+        u3 = b.rng.random((104, 3))
+        img = np.ascontiguousarray(frames[i])
+        args = (vo._lib.dptr(u3), 104, vo._lib.dptr(u8) if u8 is not None else None, C.byref(pose), C.byref(counts))
+        if i % 2:
+            st = lib.vohip_frame_step(b._h, C.c_void_p(img.ctypes.data), 0, *args)
+        else:
+            st = lib.vohip_frame_step_ahead(b._h, C.c_void_p(img.ctypes.data), 0, None, 0, *args)
+        assert st == 0, (i, st, vo._lib.load().vohip_last_error(ctx.handle))
+        b.rng.bit_generator.state = state
+        b.rng.random((pose.n_iter, 3))
+        n_C = counts.n_candidates
+        np.testing.assert_array_equal(np.array(pose.T_W_C).reshape(4, 4).T, Ta)
+        assert (counts.n_landmarks, counts.n_candidates) == (a.num_X[-1], a.num_C[-1])
+    a.close()
+    b.close()
