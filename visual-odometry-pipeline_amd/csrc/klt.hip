@@ -106,6 +106,49 @@ struct klt_cfg {
     static constexpr int SJ = W + 2 * MARG + 2;
 };
 
+// Stages the S x S patch of a level image (A x B, replicated border) whose first pixel is (a0, b0) in
+// LDS, row-major with row length S.  All loads are issued before the first LDS store so that their
+// latencies overlap.  For S <= 32 a load instruction takes two patch rows (32 lanes each): the
+// clamped column is computed once, a row costs a clamp and a multiply-add; wider patches fall back
+// to a linear walk over the patch.
+template <int S>
+__device__ __forceinline__ void stage_patch(const float *__restrict__ img, int A, int B, int a0, int b0, float *dst)
+{
+    const int lane = threadIdx.x;
+    if constexpr (S <= 32) {
+        constexpr int NLD = (S + 1) / 2;
+        const int col = lane & 31, half = lane >> 5;
+        const int a = min(max(a0 + col, 0), A - 1);
+        float tmp[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int b = min(max(b0 + 2 * k + half, 0), B - 1);
+            tmp[k] = img[(size_t)b * A + a];   // columns / rows past the patch are clamped reads, never stored
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int rb = 2 * k + half;
+            if (col < S && rb < S) dst[rb * S + col] = tmp[k];
+        }
+    } else {
+        constexpr int NLD = (S * S + 63) / 64;
+        float tmp[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int q = lane + 64 * k;
+            const int rb = q / S, ra = q - rb * S;
+            const int a = min(max(a0 + ra, 0), A - 1);
+            const int b = min(max(b0 + rb, 0), B - 1);
+            tmp[k] = img[(size_t)b * A + a];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int q = lane + 64 * k;
+            if (q < S * S) dst[q] = tmp[k];
+        }
+    }
+}
+
 // Tracks (pa, pb) from pyramid P to pyramid Q.  sI / sJ: this wavefront's LDS.
 template <int W>
 __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, double pa, double pb,
@@ -135,25 +178,8 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
         const float fa = (float)(ca - fca), fb = (float)(cb - fcb);
 
         // stage the template neighbourhood: raw pixels at offsets -(HALF+1) .. HALF+2
-        // (all loads are issued before the first LDS store so that their latencies overlap)
         __syncthreads();
-        {
-            constexpr int NLD = (C::SI * C::SI + 63) / 64;
-            float tmp[NLD];
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int q = lane + 64 * k;
-                const int rb = q / C::SI, ra = q - rb * C::SI;
-                const int a = min(max(ia - C::HALF - 1 + ra, 0), A - 1);
-                const int b = min(max(ib - C::HALF - 1 + rb, 0), B - 1);
-                tmp[k] = Pl[(size_t)b * A + a];   // rows past the patch are clamped reads, never stored
-            }
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int q = lane + 64 * k;
-                if (q < C::SI * C::SI) sI[q] = tmp[k];
-            }
-        }
+        stage_patch<C::SI>(Pl, A, B, ia - C::HALF - 1, ib - C::HALF - 1, sI);
         __syncthreads();
 
         float T[C::RPL], GX[C::RPL], GY[C::RPL];
@@ -231,23 +257,7 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                         cjb = jb;
                         staged = true;
                         __syncthreads();
-                        {
-                            constexpr int NLD = (C::SJ * C::SJ + 63) / 64;
-                            float tmp[NLD];
-#pragma unroll
-                            for (int k = 0; k < NLD; ++k) {
-                                const int q = lane + 64 * k;
-                                const int rb = q / C::SJ, ra = q - rb * C::SJ;
-                                const int a = min(max(cja - C::HALF - C::MARG + ra, 0), A - 1);
-                                const int b = min(max(cjb - C::HALF - C::MARG + rb, 0), B - 1);
-                                tmp[k] = Ql[(size_t)b * A + a];
-                            }
-#pragma unroll
-                            for (int k = 0; k < NLD; ++k) {
-                                const int q = lane + 64 * k;
-                                if (q < C::SJ * C::SJ) sJ[q] = tmp[k];
-                            }
-                        }
+                        stage_patch<C::SJ>(Ql, A, B, cja - C::HALF - C::MARG, cjb - C::HALF - C::MARG, sJ);
                         __syncthreads();
                     }
                     const float *org = sJ + (jb - cjb + C::MARG) * C::SJ + (ja - cja + C::MARG) + offJ;
