@@ -30,6 +30,8 @@
 
 namespace {
 
+constexpr int STAGE_FAILED = 3;
+
 // slots of the device counter array
 enum {
     N_V = 0,      // landmarks tracked successfully
@@ -678,7 +680,8 @@ struct vohip_frame {
     bool ahead = false;          // the previous call left this image's pyramid and corners on the device
     int n_L = 0, n_C = 0;        // counts at the start of the frame (known to the host)
     int evaluated = 0;           // hypotheses scored in the current frame
-    int stage = 0;               // 0 = between frames, 1 = a frame waits for more hypotheses, 2 = a frame is enqueued
+    int stage = 0;               // 0 = between frames, 1 = a frame waits for more hypotheses, 2 = a frame is enqueued,
+                                 // STAGE_FAILED = an enqueue failed half-way (only reset and destroy are accepted)
     int h_cur = 0;               // hypotheses supplied with the enqueued frame
     double enqueue_us = 0.0;     // host time the enqueue of the current frame took
     bool have_map = false;       // the frame started with candidates (update_landmarks runs)
@@ -914,7 +917,10 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
 {
     vohip_ctx *ctx = f->ctx;
     const auto t_wait = std::chrono::steady_clock::now();
-    VOHIP_TRY(fetch_summary(f));
+    if (const int st = fetch_summary(f)) {
+        f->stage = STAGE_FAILED;
+        return st;
+    }
     const auto t_done = std::chrono::steady_clock::now();
     const int *hc = pin_cnt(f);
     const double *hd = pin_dv(f);
@@ -974,6 +980,9 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
         return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "landmark or candidate capacity exceeded (flags %d)", hc[OVERFLOW]);
     return VOHIP_OK;
 }
+
+int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
+                  int next_on_device, const double *u3, int h, const double *u8);
 
 }  // namespace
 
@@ -1146,7 +1155,7 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
         for (int i = 0; i < n; ++i) mx = ids[i] > mx ? ids[i] : mx;
         hd[16] = mx + 1.0;
     } else {
-        // 1..n, staged through the (still unused) tracker output buffer
+        // 1..n (main_demo.m:275)
         double *tmp = (double *)std::malloc(sizeof(double) * n);
         if (!tmp) return vohip_fail(ctx, VOHIP_ERR_HIP, "out of host memory");
         for (int i = 0; i < n; ++i) tmp[i] = (double)(i + 1);
@@ -1204,9 +1213,24 @@ int vohip_frame_begin(vohip_frame *f, const uint8_t *image, int image_on_device,
     if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
     vohip_ctx *ctx = f->ctx;
     VOHIP_REQUIRE(ctx, image && u3, "NULL argument");
-    VOHIP_REQUIRE(ctx, f->stage == 0, "a frame is still waiting for vohip_frame_retry");
+    VOHIP_REQUIRE(ctx, f->stage != STAGE_FAILED, "an earlier call failed half-way: vohip_frame_reset starts over");
+    VOHIP_REQUIRE(ctx, f->stage == 0, "a frame is still waiting for vohip_frame_retry or vohip_frame_finish");
     VOHIP_REQUIRE(ctx, h >= 1 && h <= f->hmax, "hypothesis count outside 1..max_hypotheses");
     VOHIP_REQUIRE(ctx, f->n_C == 0 || u8, "candidates exist: the fundamental-matrix draws are needed");
+    const int st = begin_enqueue(f, image, image_on_device, next_image, next_on_device, u3, h, u8);
+    // a failure between the first and the last enqueue leaves streams and state half-way through a frame
+    if (st != VOHIP_OK) f->stage = STAGE_FAILED;
+    return st;
+}
+
+}  // extern "C"
+
+namespace {
+
+int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
+                  int next_on_device, const double *u3, int h, const double *u8)
+{
+    vohip_ctx *ctx = f->ctx;
     f->t_entry = std::chrono::steady_clock::now();
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1278,6 +1302,10 @@ int vohip_frame_begin(vohip_frame *f, const uint8_t *image, int image_on_device,
     return VOHIP_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *counts)
 {
     if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
@@ -1287,8 +1315,12 @@ int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose 
     VOHIP_REQUIRE(ctx, h > f->evaluated && h <= f->hmax, "hypothesis count must grow and stay within max_hypotheses");
     f->t_entry = std::chrono::steady_clock::now();
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
-    VOHIP_TRY(enqueue_localize(f, u3, h, 0));
-    VOHIP_TRY(enqueue_tail(f));
+    int st = enqueue_localize(f, u3, h, 0);
+    if (st == VOHIP_OK) st = enqueue_tail(f);
+    if (st != VOHIP_OK) {
+        f->stage = STAGE_FAILED;
+        return st;
+    }
     f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
     return complete_frame(f, h, pose, counts);
 }
