@@ -225,3 +225,29 @@ def test_device_loop_matches_cpu_restatement_at_kitti_shape(vo, ctx, oracle):
     np.testing.assert_array_equal(dev.S.X[3], ref.S.X[3])
     assert dev.rng.bit_generator.state == ref.rng.bit_generator.state
     dev.close()
+
+
+@pytest.mark.parametrize("lookahead", [False, True])
+def test_more_hypotheses_on_demand(vo, ctx, oracle, sequence, lookahead):
+    """vohip_frame_retry: a frame that was handed fewer hypotheses than the adaptive bound wants (here 16,
+    so every frame) is localised again with more of the same stream.  Bar: poses, counts and state
+    bit-identical to frames that had enough from the start; with the look-ahead the following frame's
+    trackers, enqueued behind the first attempt, are run again from the final lists."""
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    a = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(2), ctx=ctx)
+    b = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(2), ctx=ctx)
+    b.first_hypotheses = 16
+    last = len(frames) - 1
+    for i in range(1, len(frames)):
+        Ta = a.process_frame(frames[i])
+        Tb = b.process_frame(frames[i], next_image=frames[i + 1] if lookahead and i < last else None)
+        np.testing.assert_array_equal(Ta, Tb)
+        assert b.last_pose.n_iter == a.last_pose.n_iter >= 99   # ransacLocalization.m:42,128: at least 99 iterations
+        assert (a.num_X[-1], a.num_C[-1]) == (b.num_X[-1], b.num_C[-1]), i
+    for k in ("X", "P", "C", "F", "T"):
+        np.testing.assert_array_equal(getattr(a.S, k), getattr(b.S, k), err_msg=k)
+    assert a.rng.bit_generator.state == b.rng.bit_generator.state
+    a.close()
+    b.close()

@@ -654,9 +654,11 @@ struct vohip_frame {
     int rows = 0, cols = 0, colmajor = 0;
     int capL = 0, capC = 0, capK = 0, hmax = 0;
     hipStream_t side = nullptr, side2 = nullptr, trk = nullptr;
-    hipEvent_t ev_pyr = nullptr, ev_side = nullptr, ev_img = nullptr, ev_adv = nullptr, ev_next = nullptr, ev_draws = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_side = nullptr, ev_img = nullptr, ev_next = nullptr, ev_draws = nullptr, ev_tail = nullptr;
     hipEvent_t ev_det[2] = {nullptr, nullptr};
+    hipEvent_t ev_adv[2] = {nullptr, nullptr};   // after the trackers INTO the table of that parity
     hipEvent_t tr[8] = {nullptr};   // timing events of the trace option
+    hipEvent_t tr_trk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // ... around the trackers into table [parity]
     bool trace = false;
     void *block = nullptr;       // one device allocation, carved up below
     void *pinned = nullptr;      // host mirror of the counters and doubles
@@ -677,7 +679,8 @@ struct vohip_frame {
     int slot_prev = 0, slot_cur = 0, slot_next = 0;   // pyramids of the previous, the current and the following image
     int par = 0;                 // parity of the frame being processed
     bool ahead_launched = false; // this call prepares the next image
-    bool ahead = false;          // the previous call left this image's pyramid and corners on the device
+    bool ahead = false;          // the previous call left this image's pyramid and corners on the device and
+                                 // enqueued this frame's trackers behind its own last kernel
     int n_L = 0, n_C = 0;        // counts at the start of the frame (known to the host)
     int evaluated = 0;           // hypotheses scored in the current frame
     int stage = 0;               // 0 = between frames, 1 = a frame waits for more hypotheses, 2 = a frame is enqueued,
@@ -770,8 +773,9 @@ inline double *pin_u8(vohip_frame *f) { return pin_u3(f) + 3 * (size_t)f->hmax; 
 int fetch_summary(vohip_frame *f)
 {
     vohip_ctx *ctx = f->ctx;
-    // (the last kernel of the frame wrote the summary into the pinned mirror)
-    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // (the last kernel of the frame wrote the summary into the pinned mirror; the stream itself may
+    // already hold the next frame's trackers, which are not waited for)
+    VOHIP_HIP(ctx, hipEventSynchronize(f->ev_tail));
     return VOHIP_OK;
 }
 
@@ -807,7 +811,7 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
     (void)u8;   // already on its way up (the caller's stream order)
     stream_swap sw(ctx, f->side);
     hipStream_t s = f->side;
-    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_adv, 0));
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_adv[f->par], 0));
     if (f->trace) (void)hipEventRecord(f->tr[3], s);
     if (f->have_map) {
         hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->U_xy[f->par] + f->capL,
@@ -908,7 +912,44 @@ int enqueue_tail(vohip_frame *f)
                        f->keep, f->cnt, f->dv, f->capC, f->capL + f->capC, f->C_rc, f->F_rc, f->T12, f->srcC, pin_dv(f),
                        pin_cnt(f));
     VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_tail, s));     // what the frame's single synchronisation waits for
     if (f->trace) (void)hipEventRecord(f->tr[6], s);   // tail done
+    return VOHIP_OK;
+}
+
+// The landmark tracker (main_demo.m:380) and the candidate tracker (update_landmarks.m:10) in one
+// launch -- it lasts as long as its slowest track however many tracks it carries -- from the rows of
+// table par ^ 1 that the frame before kept (srcL, srcC) into the landmark / candidate rows of table
+// par, between the pyramids of slot_from and slot_to.  counts_on_device: nL and nC only bound the
+// grid and the counts are the ones the frame before left in device memory (that frame may still be
+// running: this is how the trackers of the following frame are enqueued behind a frame's last kernel).
+int enqueue_trackers(vohip_frame *f, int par, int slot_from, int slot_to, int nL, int nC, bool counts_on_device)
+{
+    vohip_ctx *ctx = f->ctx;
+    const vohip_frame_params &p = f->prm;
+    const int *dL = counts_on_device ? f->cnt + N_L_END : nullptr, *dC = counts_on_device ? f->cnt + N_C_END : nullptr;
+    const vohip_klt_set sets[2] = {
+        {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcL, nullptr, dL, f->capU, nL, 0, 0},
+        {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcC, nullptr, dC, f->capU, nC, 0, f->capL}};
+    if (f->trace) (void)hipEventRecord(f->tr_trk[par][0], ctx->stream);
+    VOHIP_TRY(vohip_klt_enqueue_sets(ctx, slot_from, slot_to, sets, 2, p.klt_block, p.klt_max_iter, p.klt_max_bidir_error));
+    if (f->trace) (void)hipEventRecord(f->tr_trk[par][1], ctx->stream);
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_adv[par], ctx->stream));   // the other streams start from here
+    return VOHIP_OK;
+}
+
+// With the following image's pyramid on its way (the look-ahead), that frame's trackers go behind this
+// frame's last kernel: they need nothing from the host, so the GPU starts them while the host still
+// collects this frame's results and prepares the next call.
+int enqueue_trackers_ahead(vohip_frame *f)
+{
+    vohip_ctx *ctx = f->ctx;
+    hipStream_t s = ctx->stream;
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_img, 0));   // the following image's pyramid
+    // landmarks only come from candidates; candidates grow by the detections that are kept
+    const long long nLb = (long long)f->n_L + f->n_C, nCb = (long long)f->n_C + f->capK;
+    VOHIP_TRY(enqueue_trackers(f, f->par ^ 1, f->slot_cur, f->slot_next, (int)(nLb < f->capL ? nLb : f->capL),
+                               (int)(nCb < f->capC ? nCb : f->capC), true));
     return VOHIP_OK;
 }
 
@@ -953,7 +994,10 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     out->host_wait_us = std::chrono::duration<double, std::micro>(t_done - t_wait).count();
     if (f->trace) {
         float ms[8] = {0};
-        for (int q = 1; q < 8; ++q) (void)hipEventElapsedTime(&ms[q], f->tr[0], f->tr[q]);
+        for (int q = 2; q < 7; ++q) (void)hipEventElapsedTime(&ms[q], f->tr[0], f->tr[q]);
+        // (negative when the previous call enqueued this frame's trackers behind its own last kernel)
+        (void)hipEventElapsedTime(&ms[7], f->tr[0], f->tr_trk[f->par][0]);
+        (void)hipEventElapsedTime(&ms[1], f->tr[0], f->tr_trk[f->par][1]);
         std::fprintf(stderr, "vohip frame trace (us from start): tracks %.0f-%.0f  refined %.0f  filter %.0f-%.0f  detect %.0f  tail %.0f | host enqueue %.0f wait %.0f",
                      1e3 * ms[7], 1e3 * ms[1], 1e3 * ms[2], 1e3 * ms[3], 1e3 * ms[4], 1e3 * ms[5], 1e3 * ms[6], out->host_enqueue_us,
                      out->host_wait_us);
@@ -1060,7 +1104,9 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->trk, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_adv, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_adv[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_adv[1], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_next, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_draws, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
@@ -1075,6 +1121,7 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     if (std::getenv("VOHIP_FRAME_TRACE")) {   // per-stage GPU timeline of every frame, for tuning
         f->trace = true;
         for (int q = 0; q < 8; ++q) (void)hipEventCreate(&f->tr[q]);
+        for (int q = 0; q < 4; ++q) (void)hipEventCreate(&f->tr_trk[q >> 1][q & 1]);
     }
     // the pose buffers of the hypothesis solver must hold every hypothesis of a frame
     int st = vohip_reserve(ctx, ctx->bufs[B_RANSAC_RT], (size_t)f->hmax * 48 * sizeof(double));
@@ -1105,13 +1152,17 @@ int vohip_frame_destroy(vohip_frame *f)
     }
     for (int q = 0; q < 2; ++q)
         if (f->ev_det[q]) (void)hipEventDestroy(f->ev_det[q]);
-    if (f->ev_adv) (void)hipEventDestroy(f->ev_adv);
+    for (int q = 0; q < 2; ++q)
+        if (f->ev_adv[q]) (void)hipEventDestroy(f->ev_adv[q]);
+    if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
     if (f->ev_next) (void)hipEventDestroy(f->ev_next);
     if (f->ev_draws) (void)hipEventDestroy(f->ev_draws);
     if (f->ctx) (void)hipStreamSynchronize(f->ctx->stream);
     if (f->ev_pyr) (void)hipEventDestroy(f->ev_pyr);
     for (int q = 0; q < 8; ++q)
         if (f->tr[q]) (void)hipEventDestroy(f->tr[q]);
+    for (int q = 0; q < 4; ++q)
+        if (f->tr_trk[q >> 1][q & 1]) (void)hipEventDestroy(f->tr_trk[q >> 1][q & 1]);
     if (f->ev_side) (void)hipEventDestroy(f->ev_side);
     if (f->ev_img) (void)hipEventDestroy(f->ev_img);
     if (f->block) (void)hipFree(f->block);
@@ -1255,25 +1306,12 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     const uint8_t *d_img = image_on_device ? image : f->img[par];
     const uint8_t *d_next = next_image ? (next_on_device ? next_image : f->img[par ^ 1]) : nullptr;
     if (!f->ahead) {
-        // nothing was done ahead: this image, its pyramid and its corners
+        // nothing was done ahead: this image, its pyramid, the trackers from the previous image
         if (!image_on_device) VOHIP_TRY(enqueue_image_transfer(f, image, f->img[par], s));
         VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));
         VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
-    } else {
-        VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_img, 0));   // the pyramid the previous call built
-    }
-    // the trackers from the previous image (main_demo.m:380, update_landmarks.m:10) over the rows the
-    // last frame kept, in one launch: it lasts as long as its slowest track however many tracks it carries
-    if (f->trace) (void)hipEventRecord(f->tr[7], s);
-    {
-        const vohip_klt_set sets[2] = {
-            {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcL, nullptr, nullptr, f->capU, f->n_L, 0, 0},
-            {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcC, nullptr, nullptr, f->capU,
-             f->have_map ? f->n_C : 0, 0, f->capL}};
-        VOHIP_TRY(vohip_klt_enqueue_sets(ctx, f->slot_prev, f->slot_cur, sets, 2, p.klt_block, p.klt_max_iter,
-                                         p.klt_max_bidir_error));
-    }
-    VOHIP_HIP(ctx, hipEventRecord(f->ev_adv, s));      // the other streams start from here
+        VOHIP_TRY(enqueue_trackers(f, par, f->slot_prev, f->slot_cur, f->n_L, f->have_map ? f->n_C : 0, false));
+    }   // (else the previous call enqueued all of that, the trackers behind its own last kernel)
     if (next_image) {
         // streams of their own, beside the trackers (which leave most of the GPU idle): the next image,
         // its pyramid (third slot) and its corners, so that the next call starts with its trackers
@@ -1283,10 +1321,9 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
         VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_next, d_next, f->rows, f->cols, f->colmajor, p.klt_levels));
         VOHIP_HIP(ctx, hipEventRecord(f->ev_img, f->trk));
     }
-    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, f->ev_next, f->ev_adv));
+    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, f->ev_next, f->ev_adv[par]));
     if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, f->ev_pyr, nullptr));
     VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_draws, 0));
-    if (f->trace) (void)hipEventRecord(f->tr[1], s);   // trackers done
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
     // the selection of the valid landmark tracks (main_demo.m:381, :387)
     hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->U_xy[par], f->capU, f->U_live[par],
@@ -1296,6 +1333,7 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     if (f->trace) (void)hipEventRecord(f->tr[2], s);   // pose refined
     VOHIP_TRY(enqueue_side_filter(f, u8));
     VOHIP_TRY(enqueue_tail(f));
+    if (next_image) VOHIP_TRY(enqueue_trackers_ahead(f));
     f->h_cur = h;
     f->stage = 2;
     f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
@@ -1317,6 +1355,8 @@ int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose 
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     int st = enqueue_localize(f, u3, h, 0);
     if (st == VOHIP_OK) st = enqueue_tail(f);
+    // (the trackers enqueued ahead started from the lists of the first attempt: once more, from the final ones)
+    if (st == VOHIP_OK && f->ahead_launched) st = enqueue_trackers_ahead(f);
     if (st != VOHIP_OK) {
         f->stage = STAGE_FAILED;
         return st;

@@ -79,6 +79,7 @@ class VOPipelineDevice:
         self.est_rot = [T[:3, :3].reshape(-1, order="F").copy()]
         self.num_X, self.num_C, self.num_new = [X.shape[0]], [0], [0]
         self.frames = 0
+        self.first_hypotheses = 104   # supplied with the frame; the adaptive bound asks for more when it needs them
         self.last_pose = None
         self.last_counts = None
 
@@ -113,7 +114,7 @@ class VOPipelineDevice:
             u8 = self._u8_ahead if self._u8_ahead is not None else self.rng_map.random((self.params.fm_trials, 8))
         self._u8_ahead = None
         state = self.rng.bit_generator.state
-        have = 104
+        have = int(self.first_hypotheses)
         u3 = self.rng.random((have, 3))                                                     # :387-388
         self.ctx.check(lib.vohip_frame_begin(self._h, ptr, on_dev, nptr, non_dev, dptr(u3), have,
                                              dptr(u8) if have_map else None))
