@@ -654,7 +654,7 @@ struct vohip_frame {
     int rows = 0, cols = 0, colmajor = 0;
     int capL = 0, capC = 0, capK = 0, hmax = 0;
     hipStream_t side = nullptr, side2 = nullptr, trk = nullptr;
-    hipEvent_t ev_pyr = nullptr, ev_side = nullptr, ev_img = nullptr, ev_next = nullptr, ev_draws = nullptr, ev_tail = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_side = nullptr, ev_img = nullptr, ev_next = nullptr, ev_tail = nullptr;
     hipEvent_t ev_det[2] = {nullptr, nullptr};
     hipEvent_t ev_adv[2] = {nullptr, nullptr};   // after the trackers INTO the table of that parity
     hipEvent_t tr[8] = {nullptr};   // timing events of the trace option
@@ -666,7 +666,7 @@ struct vohip_frame {
     double *L_rc, *L_X, *L_id, *C_rc, *F_rc, *T12;
     double *mv_rc, *Xv, *idv, *kp_uv;
     double *p1_rc, *m_rc, *F_t, *T_t, *m2_rc, *F2, *T2, *Xnew;
-    double *u3, *u8, *fm_F, *dv;
+    double *u8, *fm_F, *dv;
     double *U_xy[2];             // the track tables of even and odd frames
     uint8_t *U_live[2];
     int32_t *srcL, *srcC;        // table row of every landmark / candidate the next frame starts with
@@ -727,7 +727,6 @@ size_t layout(vohip_frame *f, char *base)
     f->F2 = carve<double>(p, 2 * C);
     f->T2 = carve<double>(p, 12 * C);
     f->Xnew = carve<double>(p, 3 * C);
-    f->u3 = carve<double>(p, 3 * H);
     f->u8 = carve<double>(p, 8 * T);
     f->fm_F = carve<double>(p, 9 * T);
     for (int q = 0; q < 2; ++q) {
@@ -865,13 +864,11 @@ int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready)
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
     const int first = f->evaluated, more = h - first;
-    if (ready == 0) {
+    // (the kernels read the draws from the pinned staging block itself: a few KB, no copy command)
+    if (ready == 0)
         std::memcpy(pin_u3(f) + 3 * (size_t)first, u3 + 3 * (size_t)first, sizeof(double) * 3 * (size_t)more);
-        VOHIP_HIP(ctx, hipMemcpyAsync(f->u3 + 3 * (size_t)first, pin_u3(f) + 3 * (size_t)first,
-                                      sizeof(double) * 3 * (size_t)more, hipMemcpyHostToDevice, s));
-    }
     if (more > ready)
-        hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more - ready)), dim3(256), 0, s, f->u3, first + ready,
+        hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more - ready)), dim3(256), 0, s, pin_u3(f), first + ready,
                            more - ready, f->cnt, f->samples3);
     VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
                                    f->counts4));
@@ -1108,7 +1105,6 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_adv[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_next, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_draws, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_pyr, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_side, hipEventDisableTiming);
@@ -1156,7 +1152,6 @@ int vohip_frame_destroy(vohip_frame *f)
         if (f->ev_adv[q]) (void)hipEventDestroy(f->ev_adv[q]);
     if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
     if (f->ev_next) (void)hipEventDestroy(f->ev_next);
-    if (f->ev_draws) (void)hipEventDestroy(f->ev_draws);
     if (f->ctx) (void)hipStreamSynchronize(f->ctx->stream);
     if (f->ev_pyr) (void)hipEventDestroy(f->ev_pyr);
     for (int q = 0; q < 8; ++q)
@@ -1294,15 +1289,14 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     // The order of the enqueues follows the critical paths: what feeds the trackers first, then the
     // context's stream (localisation), the short kernels of the other streams while those run.
     if (f->trace) (void)hipEventRecord(f->tr[0], s);
-    // the draws go up on the second stream while the trackers run
+    // the P3P draws stay in the pinned block (the kernels read them there); the trial draws go up on
+    // the second stream
     std::memcpy(pin_u3(f), u3, sizeof(double) * 3 * (size_t)h);
-    VOHIP_HIP(ctx, hipMemcpyAsync(f->u3, pin_u3(f), sizeof(double) * 3 * (size_t)h, hipMemcpyHostToDevice, f->side));
-    if (f->have_map) {
+    if (f->have_map) {   // (the second stream's kernels follow this copy in stream order)
         const size_t T8 = 8 * (size_t)p.fm_trials;
         std::memcpy(pin_u8(f), u8, sizeof(double) * T8);
         VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, pin_u8(f), sizeof(double) * T8, hipMemcpyHostToDevice, f->side));
     }
-    VOHIP_HIP(ctx, hipEventRecord(f->ev_draws, f->side));
     const uint8_t *d_img = image_on_device ? image : f->img[par];
     const uint8_t *d_next = next_image ? (next_on_device ? next_image : f->img[par ^ 1]) : nullptr;
     if (!f->ahead) {
@@ -1323,11 +1317,10 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     }
     if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, f->ev_next, f->ev_adv[par]));
     if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, f->ev_pyr, nullptr));
-    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_draws, 0));
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
     // the selection of the valid landmark tracks (main_demo.m:381, :387)
     hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->U_xy[par], f->capU, f->U_live[par],
-                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->rowv, f->cnt, f->dv, f->u3, h0, f->samples3);
+                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->rowv, f->cnt, f->dv, pin_u3(f), h0, f->samples3);
     VOHIP_HIP(ctx, hipGetLastError());
     VOHIP_TRY(enqueue_localize(f, u3, h, h0));
     if (f->trace) (void)hipEventRecord(f->tr[2], s);   // pose refined
