@@ -41,11 +41,15 @@ __device__ inline void triangulate_point(const double p1[3], const double p2[3],
                     be += A[r][j] * A[r][j];
                     ga += A[r][i] * A[r][j];
                 }
-                if (ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {
+                if (ga * ga > 1e-30 * (al * be)) {   // |ga| > 1e-15 sqrt(al be)
                     rotated = true;
-                    const double zeta = (be - al) / (2.0 * ga);
-                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                    // tangent of the rotation angle, t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)) with
+                    // zeta = (be - al) / (2 ga), multiplied through by |2 ga|: one square root and one
+                    // division per rotation (they are most of its dependent chain), then a reciprocal root
+                    const double d = be - al, g2 = 2.0 * ga;
+                    const double sg = (d == 0.0 || (d > 0.0) == (ga > 0.0)) ? fabs(g2) : -fabs(g2);
+                    const double t = sg / (fabs(d) + sqrt(__builtin_fma(d, d, g2 * g2)));
+                    const double c = rsqrt(__builtin_fma(t, t, 1.0)), s = c * t;
 #pragma unroll
                     for (int r = 0; r < 6; ++r) {
                         const double ai = A[r][i], aj = A[r][j];
