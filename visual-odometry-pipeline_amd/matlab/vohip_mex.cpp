@@ -120,6 +120,11 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     } else if (op == "homog2twist") {
         plhs[0] = mxCreateDoubleMatrix(6, 1, mxREAL);
         check(vohip_homog2twist(c, dbl(in[0], "H"), 1, mxGetDoubles(plhs[0])));
+    } else if (op == "p3p") {
+        // poses = vohip_mex('p3p', worldPoints 3x3, imageVectors 3x3): 3x16 [C1 R1 C2 R2 C3 R3 C4 R4] (p3p.m:41)
+        if (numel(in[0]) != 9 || numel(in[1]) != 9) mexErrMsgIdAndTxt("vohip:size", "p3p takes two 3x3 matrices");
+        plhs[0] = mxCreateDoubleMatrix(3, 16, mxREAL);
+        check(vohip_p3p(c, dbl(in[0], "worldPoints"), dbl(in[1], "imageVectors"), 1, mxGetDoubles(plhs[0])));
     } else if (op == "triangulate") {
         // P = vohip_mex('triangulate', p1 3xn, p2 3xn, M1 3x4 or 3x4xn, M2 3x4 or 3x4xn)
         const int n = cols(in[0]);
