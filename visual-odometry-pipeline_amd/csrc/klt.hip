@@ -90,6 +90,10 @@ __device__ __forceinline__ int bounded_int(double t)
     return min(max(j, -1000000), 1000000);
 }
 
+#ifndef KLT_WAVES_21
+#define KLT_WAVES_21 3   // wavefronts per SIMD the 21 x 21 kernel is compiled for (register budget)
+#endif
+
 template <int W>
 struct klt_cfg {
     static constexpr int HALF = W / 2;
@@ -321,7 +325,7 @@ struct klt_sets {
 };
 
 template <int W>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 21 ? 3 : 2, W <= 21 ? 3 : 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 21 ? KLT_WAVES_21 : 2, W <= 21 ? KLT_WAVES_21 : 2)))
 void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_iter, double max_bidir,
                       unsigned long long *__restrict__ stats)
 {
