@@ -1306,16 +1306,6 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
         VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
         VOHIP_TRY(enqueue_trackers(f, par, f->slot_prev, f->slot_cur, f->n_L, f->have_map ? f->n_C : 0, false));
     }   // (else the previous call enqueued all of that, the trackers behind its own last kernel)
-    if (next_image) {
-        // streams of their own, beside the trackers (which leave most of the GPU idle): the next image,
-        // its pyramid (third slot) and its corners, so that the next call starts with its trackers
-        stream_swap sw(ctx, f->trk);
-        if (!next_on_device) VOHIP_TRY(enqueue_image_transfer(f, next_image, f->img[par ^ 1], f->trk));
-        VOHIP_HIP(ctx, hipEventRecord(f->ev_next, f->trk));
-        VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_next, d_next, f->rows, f->cols, f->colmajor, p.klt_levels));
-        VOHIP_HIP(ctx, hipEventRecord(f->ev_img, f->trk));
-    }
-    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, f->ev_next, f->ev_adv[par]));
     if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, f->ev_pyr, nullptr));
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
     // the selection of the valid landmark tracks (main_demo.m:381, :387)
@@ -1325,8 +1315,19 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     VOHIP_TRY(enqueue_localize(f, u3, h, h0));
     if (f->trace) (void)hipEventRecord(f->tr[2], s);   // pose refined
     VOHIP_TRY(enqueue_side_filter(f, u8));
+    if (next_image) {
+        // streams of their own, beside the trackers (which leave most of the GPU idle): the next image,
+        // its pyramid (third slot) and its corners, so that the next call starts with its trackers
+        stream_swap sw(ctx, f->trk);
+        if (!next_on_device) VOHIP_TRY(enqueue_image_transfer(f, next_image, f->img[par ^ 1], f->trk));
+        VOHIP_HIP(ctx, hipEventRecord(f->ev_next, f->trk));
+        VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_next, d_next, f->rows, f->cols, f->colmajor, p.klt_levels));
+        VOHIP_HIP(ctx, hipEventRecord(f->ev_img, f->trk));
+    }
     VOHIP_TRY(enqueue_tail(f));
     if (next_image) VOHIP_TRY(enqueue_trackers_ahead(f));
+    // (last: nothing waits for the following image's corners before the next call's final kernels)
+    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, f->ev_next, f->ev_adv[par]));
     f->h_cur = h;
     f->stage = 2;
     f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
