@@ -249,8 +249,10 @@ int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, 
 int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *counts);
 /* vohip_frame_step for a caller that already holds the following image (a stored sequence, as the
  * loop of main_demo.m:352-375 reads it): while this frame is localised and mapped, `next_image` is
- * transferred, its pyramid is built and its corners are detected on streams of their own, so that the
- * next call starts with its trackers.  The results are those of vohip_frame_step, bit for bit; the
+ * transferred, its pyramid is built and its corners are detected on streams of their own, and the
+ * following frame's trackers are enqueued behind this frame's last kernel (the call returns without
+ * waiting for them; the context's stream may still be busy with them afterwards).  The results are
+ * those of vohip_frame_step, bit for bit; the
  * next call must pass `next_image` as its `image` (it is not transferred again), and a host
  * `next_image` must stay readable until that call returns.  next_image = NULL: exactly vohip_frame_step. */
 int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
