@@ -286,7 +286,8 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                     baf = __builtin_fmaf(e, GX[k], baf);
                     bbf = __builtin_fmaf(e, GY[k], bbf);
                 }
-                const double ba = (double)vohip_dev::wave_sum_f32(baf), bb = (double)vohip_dev::wave_sum_f32(bbf);
+                vohip_dev::wave_sum2_f32(baf, bbf);
+                const double ba = (double)baf, bb = (double)bbf;
                 const double sa = (gyy * ba - gxy * bb) * inv_det;
                 const double sb = (gxx * bb - gxy * ba) * inv_det;
                 da += sa;

@@ -48,6 +48,26 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Two independent sums at once, step by step in turn: each DPP step has to wait for the result of the
+// one before it, and the other sum's step fills that wait.  Same operations per sum as wave_sum_f32.
+__device__ __forceinline__ void wave_sum2_f32(float &a, float &b)
+{
+    a = dpp_add_f32<0xB1>(a);
+    b = dpp_add_f32<0xB1>(b);
+    a = dpp_add_f32<0x4E>(a);
+    b = dpp_add_f32<0x4E>(b);
+    a = dpp_add_f32<0x141>(a);
+    b = dpp_add_f32<0x141>(b);
+    a = dpp_add_f32<0x140>(a);
+    b = dpp_add_f32<0x140>(b);
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x142, 0xA, 0xF, false));
+    b += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x142, 0xA, 0xF, false));
+    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x143, 0xC, 0xF, false));
+    b += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x143, 0xC, 0xF, false));
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+}
+
 // Sum over each aligned group of 8 lanes (every lane of the group receives it): three DPP steps.
 __device__ __forceinline__ double group8_sum_f64(double v)
 {
