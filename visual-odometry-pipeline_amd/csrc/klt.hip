@@ -79,8 +79,6 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__
 
 #pragma clang fp contract(fast)
 
-__device__ __forceinline__ double wave_sum(double v) { return vohip_dev::wave_sum_f64(v); }
-
 // (int)min(max(t, -1e6), 1e6) for a finite integral t: the conversion instruction saturates, so the
 // bounds can be applied to the integer.
 __device__ __forceinline__ int bounded_int(double t)
@@ -129,10 +127,12 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int A
             const int b = min(max(b0 + 2 * k + half, 0), B - 1);
             tmp[k] = img[(size_t)b * A + a];   // columns / rows past the patch are clamped reads, never stored
         }
+        if (col < S) {   // (one branch: only the last row pair can reach past the patch)
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int rb = 2 * k + half;
-            if (col < S && rb < S) dst[rb * S + col] = tmp[k];
+            for (int k = 0; k < NLD; ++k) {
+                const int rb = 2 * k + half;
+                if (2 * k + 1 < S || rb < S) dst[rb * S + col] = tmp[k];
+            }
         }
     } else {
         constexpr int NLD = (S * S + 63) / 64;
@@ -230,9 +230,7 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                 h_prev[2] = h[2];
             }
         }
-        gxx = wave_sum(gxx);
-        gxy = wave_sum(gxy);
-        gyy = wave_sum(gyy);
+        vohip_dev::wave_sum3_f64(gxx, gxy, gyy);
         const double det = gxx * gyy - gxy * gxy;
         const double lmin = 0.5 * ((gxx + gyy) - sqrt((gxx - gyy) * (gxx - gyy) + 4.0 * gxy * gxy));
         const bool good = (lmin / (double)(W * W) >= KLT_MIN_EIG) && det > 0.0;

@@ -88,4 +88,27 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return ((r0 + r1) + r2) + r3;
 }
 
+// Three independent fp64 sums at once, step by step in turn (same operations per sum as wave_sum_f64).
+__device__ __forceinline__ void wave_sum3_f64(double &a, double &b, double &c)
+{
+    a += dpp_move_f64<0xB1>(a);
+    b += dpp_move_f64<0xB1>(b);
+    c += dpp_move_f64<0xB1>(c);
+    a += dpp_move_f64<0x4E>(a);
+    b += dpp_move_f64<0x4E>(b);
+    c += dpp_move_f64<0x4E>(c);
+    a += dpp_move_f64<0x141>(a);
+    b += dpp_move_f64<0x141>(b);
+    c += dpp_move_f64<0x141>(c);
+    a += dpp_move_f64<0x140>(a);
+    b += dpp_move_f64<0x140>(b);
+    c += dpp_move_f64<0x140>(c);
+    const double a0 = readlane_f64(a, 0), a1 = readlane_f64(a, 16), a2 = readlane_f64(a, 32), a3 = readlane_f64(a, 48);
+    const double b0 = readlane_f64(b, 0), b1 = readlane_f64(b, 16), b2 = readlane_f64(b, 32), b3 = readlane_f64(b, 48);
+    const double c0 = readlane_f64(c, 0), c1 = readlane_f64(c, 16), c2 = readlane_f64(c, 32), c3 = readlane_f64(c, 48);
+    a = ((a0 + a1) + a2) + a3;
+    b = ((b0 + b1) + b2) + b3;
+    c = ((c0 + c1) + c2) + c3;
+}
+
 }  // namespace vohip_dev
