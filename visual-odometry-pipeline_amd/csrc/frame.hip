@@ -410,42 +410,58 @@ __device__ double fm_trial_budget_dev(int inliers, int n, int num_trials, double
 }
 
 // The sequential part of the fundamental-matrix RANSAC: first trial with the largest count inside
-// the shrinking trial budget.  The budget is a function of the running maximum only, so one
-// wavefront replays 64 trials at a time (prefix maximum, budget per lane, first lane at which the
-// loop ends).
-__global__ __launch_bounds__(64) void fm_decide_kernel(const int32_t *__restrict__ counts, int num_trials,
-                                                       double confidence, const double *__restrict__ F_all,
-                                                       int *__restrict__ cnt, double *__restrict__ dv)
+// the shrinking trial budget.  The budget is a function of the running maximum only, so the
+// workgroup replays FM_DECIDE trials at a time: prefix maximum (within each wavefront, then across
+// them), budget per thread, first trial at which the loop ends.
+constexpr int FM_DECIDE = 512;
+
+__global__ __launch_bounds__(FM_DECIDE) void fm_decide_kernel(const int32_t *__restrict__ counts, int num_trials,
+                                                              double confidence, const double *__restrict__ F_all,
+                                                              int *__restrict__ cnt, double *__restrict__ dv)
 {
-    const int lane = threadIdx.x;
+    constexpr int NW = FM_DECIDE / 64;
+    __shared__ int w_max[NW], w_stop[NW], w_hit[NW], s_mlast;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = cnt[N_CV];
     int run_max = 0, best_t = -1, trials = 0;
     if (n >= 8) {
         bool stopped = false;
-        for (int base = 0; base < num_trials && !stopped; base += 64) {
-            const int t = base + lane;
+        for (int base = 0; base < num_trials && !stopped; base += FM_DECIDE) {
+            const int t = base + tid;
             const bool live = t < num_trials;
             const int c = live ? counts[t] : 0;
-            const int m = max(wave_prefix_max(c, lane), run_max);
+            const int pm = wave_prefix_max(c, lane);
+            if (lane == 63) w_max[wave] = pm;
+            __syncthreads();
+            int m = max(pm, run_max);
+            for (int w = 0; w < wave; ++w) m = max(m, w_max[w]);
             const double budget = fm_trial_budget_dev(m, n, num_trials, confidence);
             // after trial t the loop goes on iff t + 1 < budget (and t + 1 < num_trials)
             const unsigned long long stop = __ballot(live && !((double)(t + 1) < budget));
-            int last = min(63, num_trials - 1 - base);
-            if (stop) {
-                last = __ffsll((long long)stop) - 1;
-                stopped = true;
-            }
-            const int m_last = __shfl(m, last, 64);
+            if (lane == 0) w_stop[wave] = stop ? base + 64 * wave + __ffsll((long long)stop) - 1 : 0x7fffffff;
+            __syncthreads();
+            int last = 0x7fffffff;
+            for (int w = 0; w < NW; ++w) last = min(last, w_stop[w]);
+            if (last != 0x7fffffff) stopped = true;
+            else last = min(base + FM_DECIDE, num_trials) - 1;
+            if (t == last) s_mlast = m;
+            __syncthreads();
+            const int m_last = s_mlast;
+            const unsigned long long hit = __ballot(t <= last && c == m_last);
+            if (lane == 0) w_hit[wave] = hit ? base + 64 * wave + __ffsll((long long)hit) - 1 : 0x7fffffff;
+            __syncthreads();
             if (m_last > run_max) {
-                const unsigned long long hit = __ballot(lane <= last && c == m_last);
-                best_t = base + __ffsll((long long)hit) - 1;
+                int first = 0x7fffffff;
+                for (int w = 0; w < NW; ++w) first = min(first, w_hit[w]);
+                best_t = first;
                 run_max = m_last;
             }
-            trials = base + last + 1;
+            trials = last + 1;
+            __syncthreads();   // (the arrays are rewritten by the next round)
         }
     }
-    if (lane < 9) dv[D_F + lane] = best_t >= 0 ? F_all[9 * (size_t)best_t + lane] : 0.0;
-    if (lane != 0) return;
+    if (tid < 9) dv[D_F + tid] = best_t >= 0 ? F_all[9 * (size_t)best_t + tid] : 0.0;
+    if (tid != 0) return;
     cnt[F_BEST_T] = best_t;
     cnt[F_BEST_COUNT] = run_max;
     cnt[F_TRIALS] = trials;
@@ -818,7 +834,7 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
                            f->T_t, f->capL, f->row_t, f->cnt, f->u8, T, f->samples8);
         VOHIP_TRY(vohip_fm_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->samples8, T, p.fm_threshold,
                                    f->dv + D_NRM, f->fm_F, f->fm_counts));
-        hipLaunchKernelGGL(fm_decide_kernel, dim3(1), dim3(64), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
+        hipLaunchKernelGGL(fm_decide_kernel, dim3(1), dim3(FM_DECIDE), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
                            f->dv);
         VOHIP_TRY(vohip_fm_mask_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->dv + D_F, p.fm_threshold,
                                         f->fmask));
