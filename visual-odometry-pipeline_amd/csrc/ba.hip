@@ -706,10 +706,8 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
 #pragma unroll
                 for (int k = 0; k < j; ++k) dd -= A[j * 6 + k] * A[j * 6 + k];
                 if (!(dd > 0.0)) ok = 0;
-                dd = sqrt(dd);
-                const double inv = 1.0 / dd;
+                const double inv = rsqrt(dd);   // (the pivot itself is never needed, only its reciprocal)
                 piv[j] = inv;
-                A[j * 6 + j] = dd;
 #pragma unroll
                 for (int i = j + 1; i < 6; ++i) {
                     double t = A[i * 6 + j];
