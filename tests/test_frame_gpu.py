@@ -112,6 +112,12 @@ def test_device_loop_accepts_device_images_and_reports_errors(vo, ctx, oracle, s
     with pytest.raises((RuntimeError, vo.VohipError)):
         c.process_frame(np.full_like(frames[0], 127))
     c.close()
+    # a frame prepared ahead must be the next one processed
+    d = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(3), ctx=ctx)
+    d.process_frame(frames[1], next_image=frames[2])
+    with pytest.raises(ValueError):
+        d.process_frame(frames[3])
+    d.close()
     hp_ba = vo.default_hyper_paras("kitti", is_BA=True)
     with pytest.raises(NotImplementedError):
         vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp_ba, ctx=ctx)

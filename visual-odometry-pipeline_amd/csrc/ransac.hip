@@ -337,7 +337,8 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double *__restrict_
                                                        const int *__restrict__ n_dev, vohip_K K,
                                                        const int32_t *__restrict__ samples, int h,
                                                        double *__restrict__ Rt_out,
-                                                       double *__restrict__ M_out)
+                                                       double *__restrict__ M_out,
+                                                       int32_t *__restrict__ zero_counts)
 {
     // four lanes per hypothesis: the part the four solutions share is computed by each of them (same
     // operations, same bits), then every lane finishes ONE solution -- the dependent chain of a lane is
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double *__restrict_
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int hyp = t >> 2, sol = t & 3;
     if (hyp >= h) return;
+    if (zero_counts) zero_counts[t] = 0;   // (for a scoring kernel that adds partial counts)
     if (n_dev) n = *n_dev;  // point count kept on the device (the frame pipeline)
     v3 W[3], bearing[3];
     bool ok = true;
@@ -532,6 +534,78 @@ __global__ __launch_bounds__(WAVES * 64) void p3p_score_kernel(
     }
 }
 
+// Few hypotheses (a frame's first 104): one wavefront per hypothesis would leave most of the GPU idle
+// and last as long as one wavefront needs for all the points, so `split` wavefronts share a
+// hypothesis, each tests its share of the points straight from global memory (the point arrays are
+// small and stay in the caches) and adds its four counts to the hypothesis' (integer atomics: the
+// sums do not depend on the order).  counts must be zero on entry (p3p_solve_kernel clears them).
+__global__ __launch_bounds__(256) void p3p_score_split_kernel(const double *__restrict__ kp_rc,
+                                                              const double *__restrict__ X, int n,
+                                                              const int *__restrict__ n_dev,
+                                                              const double *__restrict__ M, int h, int split,
+                                                              int32_t *__restrict__ counts)
+{
+    if (n_dev) n = *n_dev;
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int hyp = gw / split, part = gw - hyp * split;
+    if (hyp >= h) return;
+    const int groups = (n + 63) >> 6, per = (groups + split - 1) / split;
+    const int g0 = part * per, g1 = min(groups, g0 + per);
+    if (g0 >= g1) return;
+    pose_s ms[4];
+    double tv[4][3];
+    {
+        const double *mp = M + (size_t)hyp * 48;  // wave-uniform address: scalar loads
+        const double *mv = M + (size_t)((blockIdx.x * 4 + (threadIdx.x >> 6)) / split) * 48;   // per-lane address
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ms[s].r[3 * i] = mp[12 * s + 4 * i];
+                ms[s].r[3 * i + 1] = mp[12 * s + 4 * i + 1];
+                ms[s].r[3 * i + 2] = mp[12 * s + 4 * i + 2];
+                tv[s][i] = mv[12 * s + 4 * i + 3];
+            }
+        }
+    }
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    const double nan = __builtin_nan("");
+    auto load = [&](int g, double &x, double &y, double &z, double &u, double &v) {
+        const int j = g * 64 + lane;
+        const bool in = j < n;
+        const size_t jj = in ? j : 0;
+        x = X[3 * jj];
+        y = X[3 * jj + 1];
+        z = X[3 * jj + 2];
+        v = kp_rc[2 * jj];       // (row, col) pairs: row = v, col = u
+        u = kp_rc[2 * jj + 1];
+        if (!in) x = nan;        // fails the test
+    };
+    double ax, ay, az, au, av;
+    load(g0, ax, ay, az, au, av);
+    for (int g = g0; g < g1; ++g) {
+        double bx = 0, by = 0, bz = 0, bu = 0, bv = 0;
+        if (g + 1 < g1) load(g + 1, bx, by, bz, bu, bv);   // in flight while this group is tested
+        c0 += __popcll(__ballot(is_inlier_sv(ms[0], tv[0][0], tv[0][1], tv[0][2], ax, ay, az, au, av)));
+        c1 += __popcll(__ballot(is_inlier_sv(ms[1], tv[1][0], tv[1][1], tv[1][2], ax, ay, az, au, av)));
+        c2 += __popcll(__ballot(is_inlier_sv(ms[2], tv[2][0], tv[2][1], tv[2][2], ax, ay, az, au, av)));
+        c3 += __popcll(__ballot(is_inlier_sv(ms[3], tv[3][0], tv[3][1], tv[3][2], ax, ay, az, au, av)));
+        ax = bx;
+        ay = by;
+        az = bz;
+        au = bu;
+        av = bv;
+    }
+    if (lane == 0) {
+        int32_t *c = counts + 4 * (size_t)hyp;
+        if (c0) atomicAdd(c, c0);
+        if (c1) atomicAdd(c + 1, c1);
+        if (c2) atomicAdd(c + 2, c2);
+        if (c3) atomicAdd(c + 3, c3);
+    }
+}
+
 struct pose_m {
     double m[12];
 };
@@ -598,7 +672,7 @@ int launch_solve(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n
     const vohip_K Kv = vohip_make_K(K);
     hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n,
                        (const int *)nullptr, Kv, d_samples, h, (double *)ctx->bufs[B_RANSAC_RT].ptr,
-                       (double *)ctx->bufs[B_RANSAC_M].ptr);
+                       (double *)ctx->bufs[B_RANSAC_M].ptr, (int32_t *)nullptr);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
@@ -649,9 +723,20 @@ int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
     double *d_Rt = (double *)ctx->bufs[B_RANSAC_RT].ptr + (size_t)first * 48;
     double *d_M = (double *)ctx->bufs[B_RANSAC_M].ptr + (size_t)first * 48;
     const vohip_K Kv = vohip_make_K(K);
+    // few hypotheses: several wavefronts share each (their partial counts are added to counts the solve
+    // kernel cleared); many: one wavefront per hypothesis over LDS-staged tiles
+    const bool split_points = h < 512 && ctx->opt_ransac_variant < 0;
     hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n, d_n, Kv,
-                       d_samples + 3 * (size_t)first, h, d_Rt, d_M);
-    VOHIP_TRY(launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, h, d_counts + 4 * (size_t)first, d_n));
+                       d_samples + 3 * (size_t)first, h, d_Rt, d_M,
+                       split_points ? d_counts + 4 * (size_t)first : (int32_t *)nullptr);
+    if (split_points) {
+        const int split = 1024 / h < 1 ? 1 : (1024 / h > 16 ? 16 : 1024 / h);
+        hipLaunchKernelGGL(p3p_score_split_kernel, dim3((h * split + 3) / 4), dim3(256), 0, ctx->stream, d_kp_rc, d_X, n,
+                           d_n, d_M, h, split, d_counts + 4 * (size_t)first);
+        VOHIP_HIP(ctx, hipGetLastError());
+    } else {
+        VOHIP_TRY(launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, h, d_counts + 4 * (size_t)first, d_n));
+    }
     if (ctx->ransac_h < first + h) ctx->ransac_h = first + h;
     return VOHIP_OK;
 }
@@ -785,7 +870,7 @@ int vohip_ransac_p3p(vohip_ctx *ctx, const double *kp_rc, const double *X, int n
             if (want > hcap - evaluated) want = hcap - evaluated;
             hipLaunchKernelGGL(p3p_solve_kernel, dim3((want + 15) / 16), dim3(64), 0, st, d_kp, d_X, n,
                                (const int *)nullptr, Kv, d_samples + 3 * (size_t)evaluated, want, d_Rt + (size_t)evaluated * 48,
-                               d_M + (size_t)evaluated * 48);
+                               d_M + (size_t)evaluated * 48, (int32_t *)nullptr);
             VOHIP_TRY(launch_score_variant(ctx, d_kp, d_X, n, d_M + (size_t)evaluated * 48, want,
                                            d_counts + 4 * (size_t)evaluated));
             VOHIP_HIP(ctx, hipMemcpyAsync(h_counts + 4 * (size_t)evaluated, d_counts + 4 * (size_t)evaluated,

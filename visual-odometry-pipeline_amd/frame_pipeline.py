@@ -101,7 +101,10 @@ class VOPipelineDevice:
         caller already holds it (a stored sequence): its transfer, pyramid and corner detection then run
         beside this frame's localisation; the results do not change, and the next call must pass that image."""
         lib = _lib.load()
-        if self._next_image is not None and image is self._next_image[0]:
+        if self._next_image is not None:
+            if image is not self._next_image[0]:
+                # the library has that image's pyramid, corners and trackers under way already
+                raise ValueError("the previous call prepared its next_image ahead: pass that same object as image")
             ptr, on_dev, keep = self._next_image[1]          # handed over ahead by the previous call
         else:
             ptr, on_dev, keep = self._image_ptr(image)
