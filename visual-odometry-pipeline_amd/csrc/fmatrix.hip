@@ -12,6 +12,7 @@
 // Kernels: fm_normalise_kernel (one workgroup, two block reductions), fm_solve_kernel (one
 // group of 8 lanes per trial), fm_count_kernel (one wavefront per trial, ballot/popcount), fm_mask_kernel.
 #include "vohip_internal.h"
+#include "sampson_test.h"
 
 #include <cmath>
 
@@ -263,16 +264,7 @@ __global__ __launch_bounds__(64) void fm_solve_kernel(const double *__restrict__
     for (int q = 0; q < 9; ++q) F_out[9 * (size_t)t + q] = F[q];
 }
 
-__device__ __forceinline__ bool sampson_inlier(const double F[9], double x1, double y1, double x2, double y2,
-                                               double thr)
-{
-    const double a0 = F[0] * x1 + F[1] * y1 + F[2], a1 = F[3] * x1 + F[4] * y1 + F[5],
-                 a2 = F[6] * x1 + F[7] * y1 + F[8];
-    const double b0 = F[0] * x2 + F[3] * y2 + F[6], b1 = F[1] * x2 + F[4] * y2 + F[7];
-    const double e = x2 * a0 + y2 * a1 + a2;
-    const double d = e * e / (a0 * a0 + a1 * a1 + b0 * b0 + b1 * b1);
-    return d <= thr;
-}
+using vohip_dev::sampson_inlier;   // sampson_test.h
 
 // One wavefront per trial, 4 trials per workgroup.
 __global__ __launch_bounds__(256) void fm_count_kernel(const double *__restrict__ p1, const double *__restrict__ p2,

@@ -22,6 +22,7 @@
 // supplied, vohip_frame_retry re-runs the context-stream part from the hypotheses onwards.
 #include "vohip_internal.h"
 #include "inlier_test.h"
+#include "sampson_test.h"
 
 #include <chrono>
 #include <cmath>
@@ -467,11 +468,13 @@ __global__ __launch_bounds__(FM_DECIDE) void fm_decide_kernel(const int32_t *__r
     cnt[F_TRIALS] = trials;
 }
 
-// update_landmarks.m:15,20-25: the epipolar inliers.  An all-zero matrix (no model) flags nothing.
-__global__ __launch_bounds__(256) void select_f_inliers_kernel(const double *__restrict__ m_rc,
+// update_landmarks.m:15,20-25: the epipolar inliers of the winning matrix (the test the counting kernel
+// applied, evaluated here instead of in a mask kernel of its own).  No model (an all-zero matrix) flags nothing.
+__global__ __launch_bounds__(256) void select_f_inliers_kernel(const double *__restrict__ p1_rc,
+                                                               const double *__restrict__ m_rc,
                                                                const double *__restrict__ F_t,
                                                                const double *__restrict__ T_t,
-                                                               const uint8_t *__restrict__ fmask,
+                                                               const double *__restrict__ F9, double thr,
                                                                const int32_t *__restrict__ row_t,
                                                                int *__restrict__ cnt, double *__restrict__ m2_rc,
                                                                double *__restrict__ F2, double *__restrict__ T2,
@@ -479,10 +482,15 @@ __global__ __launch_bounds__(256) void select_f_inliers_kernel(const double *__r
 {
     __shared__ int sh[12];
     const int n = cnt[F_BEST_T] >= 0 ? cnt[N_CV] : 0;
+    double F[9];
+    for (int q = 0; q < 9; ++q) F[q] = F9[q];
+    auto inlier = [&](int j) {
+        return vohip_dev::sampson_inlier(F, p1_rc[2 * j], p1_rc[2 * j + 1], m_rc[2 * j], m_rc[2 * j + 1], thr);
+    };
     int total;
-    const int r = ordered_rank(fmask, n, is_set(), total, sh);
+    const int r = ordered_rank_if(n, inlier, total, sh);
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && fmask[i]) {
+    if (i < n && inlier(i)) {
         m2_rc[2 * r] = m_rc[2 * i];
         m2_rc[2 * r + 1] = m_rc[2 * i + 1];
         F2[2 * r] = F_t[2 * i];
@@ -690,7 +698,7 @@ struct vohip_frame {
     float *corner_xy[2], *corner_metric[2];   // detections, by frame parity
     int32_t *samples3, *counts4, *samples8, *fm_counts;
     int *cnt;
-    uint8_t *mask, *fmask, *status, *keep;
+    uint8_t *mask, *status, *keep;
     int capU = 0;                // rows of the track table
     int slot_prev = 0, slot_cur = 0, slot_next = 0;   // pyramids of the previous, the current and the following image
     int par = 0;                 // parity of the frame being processed
@@ -761,7 +769,6 @@ size_t layout(vohip_frame *f, char *base)
     f->U_live[0] = carve<uint8_t>(p, U);
     f->U_live[1] = carve<uint8_t>(p, U);
     f->mask = carve<uint8_t>(p, L);
-    f->fmask = carve<uint8_t>(p, C);
     f->status = carve<uint8_t>(p, C);
     f->keep = carve<uint8_t>(p, Kc);
     for (int q = 0; q < 2; ++q) f->img[q] = carve<uint8_t>(p, (size_t)f->rows * f->cols);
@@ -836,10 +843,8 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
                                    f->dv + D_NRM, f->fm_F, f->fm_counts));
         hipLaunchKernelGGL(fm_decide_kernel, dim3(1), dim3(FM_DECIDE), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
                            f->dv);
-        VOHIP_TRY(vohip_fm_mask_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->dv + D_F, p.fm_threshold,
-                                        f->fmask));
-        hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->m_rc, f->F_t, f->T_t,
-                           f->fmask, f->row_t, f->cnt, f->m2_rc, f->F2, f->T2, f->row2);
+        hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->p1_rc, f->m_rc, f->F_t,
+                           f->T_t, f->dv + D_F, p.fm_threshold, f->row_t, f->cnt, f->m2_rc, f->F2, f->T2, f->row2);
         VOHIP_HIP(ctx, hipGetLastError());
     }
     VOHIP_HIP(ctx, hipEventRecord(f->ev_side, s));
