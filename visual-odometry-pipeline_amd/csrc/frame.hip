@@ -352,17 +352,20 @@ __global__ __launch_bounds__(256) void select_inliers_kernel(const int32_t *__re
 // index not picked before.
 __device__ __forceinline__ void octet_from_uniforms(const double *u, int n, int32_t *s)
 {
-    int chosen[8];   // sorted
+    int chosen[8];   // sorted; every index below is a compile-time constant, so the array stays in registers
+#pragma unroll
     for (int k = 0; k < 8; ++k) {
         int idx = min((int)(u[k] * (double)(n - k)), n - k - 1);
+#pragma unroll
         for (int m = 0; m < k; ++m) idx += idx >= chosen[m];
         s[k] = idx;
-        int pos = k;
-        while (pos > 0 && chosen[pos - 1] > idx) {
-            chosen[pos] = chosen[pos - 1];
-            --pos;
+        chosen[k] = idx;
+#pragma unroll
+        for (int m = k; m > 0; --m) {   // one insertion pass from the end
+            const int lo = min(chosen[m - 1], chosen[m]), hi = max(chosen[m - 1], chosen[m]);
+            chosen[m - 1] = lo;
+            chosen[m] = hi;
         }
-        chosen[pos] = idx;
     }
 }
 
@@ -392,13 +395,11 @@ __global__ __launch_bounds__(256) void select_cand_tracked_kernel(const double *
         for (int q = 0; q < 12; ++q) T_t[12 * (size_t)r + q] = T12[12 * (size_t)i + q];
         row_t[r] = row_base + i;   // candidate i is row row_base + i of the track table
     }
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) cnt[N_CV] = total;
-        // the trial samples (update_landmarks.m:13): every thread of this workgroup knows the count already
-        if (total >= 8)
-            for (int t = threadIdx.x; t < trials; t += 256)
-                octet_from_uniforms(u8 + 8 * (size_t)t, total, samples8 + 8 * (size_t)t);
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[N_CV] = total;
+    // the trial samples (update_landmarks.m:13): every thread of the grid knows the count already
+    if (total >= 8)
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < trials; t += gridDim.x * 256)
+            octet_from_uniforms(u8 + 8 * (size_t)t, total, samples8 + 8 * (size_t)t);
 }
 
 __device__ double fm_trial_budget_dev(int inliers, int n, int num_trials, double confidence)
