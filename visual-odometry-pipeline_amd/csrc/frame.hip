@@ -4,17 +4,19 @@
 // tracker, ransacLocalization.m, T_refinement.m, update_landmarks.m, update_candidate.m and the
 // tracker re-initialisation -- as ONE call and ONE synchronisation per frame (vohip_frame_step,
 // vohip_frame_step_ahead):
-//   context stream  [image -> pyramid, unless prepared ahead] -> landmark AND candidate tracking (one
-//                   launch, from the rows of the previous frame's track table into this frame's)
-//                   -> ordered selection (+ sample triples from the caller's uniform draws) -> P3P
-//                   solve -> scoring -> the adaptive stopping rule replayed by one wavefront ->
-//                   inlier selection -> pose refinement -> [join] -> triangulation of the filtered
-//                   candidates -> landmark append -> redundancy filter -> candidate append (+ the
-//                   frame's summary into the caller's pinned mirror)
-//   second stream   the caller's draws go up; (after the trackers) ordered selection of the tracked
+//   context stream  [image -> pyramid -> landmark AND candidate tracking (one launch, from the rows of
+//                   the previous frame's track table into this frame's), unless the previous call
+//                   enqueued them ahead] -> ordered selection (+ sample triples from the caller's
+//                   uniform draws) -> P3P solve -> scoring -> the adaptive stopping rule replayed by
+//                   one wavefront -> inlier selection -> pose refinement -> [join] -> triangulation of
+//                   the filtered candidates -> landmark append -> redundancy filter -> candidate
+//                   append (+ the frame's summary into the caller's pinned mirror; the call waits on
+//                   an event recorded here) -> [step_ahead] the FOLLOWING frame's trackers, with their
+//                   counts read from device memory
+//   second stream   the trial draws go up; (after the trackers) ordered selection of the tracked
 //                   candidates -> fundamental-matrix RANSAC -> inlier selection
 //   third stream    corner detection; the detections become rows of the track table
-//   fourth stream   (step_ahead) the following image and its pyramid, beside the trackers
+//   fourth stream   (step_ahead) the following image and its pyramid
 // S.P, S.X, S.C, S.F, S.T never leave the device; every count between the stages stays in device
 // memory (kernels are launched over capacity-sized grids and read the count themselves), and
 // selections are ordered, so the state is element for element the one the stage-by-stage entry
