@@ -34,6 +34,7 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector fp32
 LDS_PEAK_TBS = 78.6            # 256 CU x 128 B/clk x 2.4 GHz
 MATLAB_KITTI_HARRIS_FPS = 3.817  # the reference's published figure (Ryzen 7 5800H, MATLAB, real KITTI 05)
 CACHE = os.environ.get("VOHIP_CACHE", "/tmp/vohip_cache")
+STRESS_MIN_QUALITY = 2e-5   # Harris MinQuality of the stress configuration (2e-4 in the KITTI configuration)
 
 
 def thin_by_grid(xy, metric, cell=14.0):
@@ -51,17 +52,24 @@ def make_sequence(vo, n_frames):
     return scene, frames, poses
 
 
-def init_points(vo, ctx, scene, frame0, pose0):
-    _, kp = vo.genKeypoints(frame0, "Harris", ["MinQuality", 2e-4], ctx=ctx)
-    keep = thin_by_grid(kp.Location.astype(np.float64), kp.Metric)
-    xy = kp.Location[keep].astype(np.float64)
+def init_points(vo, ctx, scene, frame0, pose0, thin=True, min_quality=2e-4, limit=None):
+    _, kp = vo.genKeypoints(frame0, "Harris", ["MinQuality", min_quality], ctx=ctx)
+    xy = kp.Location.astype(np.float64)
+    if thin:
+        xy = xy[thin_by_grid(xy, kp.Metric)]
+    elif limit and len(xy) > limit:   # the strongest `limit` corners, in detection order
+        xy = xy[np.sort(np.argsort(-kp.Metric, kind="stable")[:limit])]
     return scene.backproject(pose0, xy), xy
 
 
-def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barrier, gather, resident=True, ahead=True):
+def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barrier, gather, resident=True, ahead=True,
+                 stress_hypotheses=0):
     """ahead: every call also hands over the following frame of the stored sequence, whose pyramid and corners
     are then prepared beside the localisation of the current one (same results; the sequence holds one frame
-    more than is processed)."""
+    more than is processed).
+    stress_hypotheses > 0: the stress configuration -- every corner of the first frame starts as a landmark
+    (about 6k, no thinning) and that many P3P hypotheses are solved and scored in every frame (the adaptive
+    rule still picks the winner among the iterations it would have executed)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     if resident:
         d_frames = [torch.from_numpy(f).to(dev) for f in frames[:warmup + steps + 2]]
@@ -72,10 +80,16 @@ def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barr
             t.to(dev)
         torch.cuda.synchronize()
         d_frames = [t.numpy() for t in keep]
-    X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
     hp = vo.default_hyper_paras("kitti", is_BA=False)
+    if stress_hypotheses:   # denser corners and a narrower exclusion radius: about 8k points tracked per frame
+        hp.feature_extract_options = ["MinQuality", STRESS_MIN_QUALITY]
+        hp.r_discard_redundant = 5.0
+    X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0], thin=not stress_hypotheses,
+                          min_quality=STRESS_MIN_QUALITY if stress_hypotheses else 2e-4, limit=8192)
     pipe = vo.VOPipelineDevice(vo.synth.K_KITTI, d_frames[0], X0, xy0, poses[0], hyper_paras=hp,
                                rng=np.random.default_rng(seed), ctx=ctx)
+    if stress_hypotheses:
+        pipe.first_hypotheses = stress_hypotheses
     for i in range(1, warmup + 1):
         pipe.process_frame(d_frames[i], next_image=d_frames[i + 1] if ahead else None)
     barrier()
@@ -396,6 +410,15 @@ def main():
                                       gather, resident=False)
         elapsed_plain, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
                                         gather, ahead=False)
+        stress = None
+        if world == 1:   # the whole loop at the stress sizes (the kernel-level stress figures follow below)
+            el_s, info_s = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
+                                        gather, stress_hypotheses=args.hypotheses)
+            stress = {"workload": "the strongest 8192 corners of the first frame (Harris MinQuality %g) start as landmarks, "
+                                  "exclusion radius 5 px, %d P3P hypotheses solved and scored per frame"
+                                  % (STRESS_MIN_QUALITY, args.hypotheses),
+                      "frames_per_s": args.steps / el_s, "tracked_landmarks": info_s["n_landmarks"],
+                      "candidates": info_s["n_candidates"], "final_position_error_m": info_s["final_position_error_m"]}
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -444,6 +467,7 @@ def main():
             "frames_per_s_pcie_inclusive": args.steps / elapsed_h2d,
             "frames_per_s_without_lookahead": args.steps / elapsed_plain,
             "frames_per_s_4_sequences_at_once": fps_4seq,   # batch evaluation: independent sequences share the GPU
+            "frame_loop_stress_config": stress,
             "ransac_hypotheses_per_s": hyps_per_s,
             "ransac_config": {"workload": "RANSAC stress: %d P3P hypotheses x %d correspondences per step" % (h, n)},
             "roofline": {"bound": "valu_fp64",
