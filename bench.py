@@ -414,7 +414,7 @@ def main():
         if world == 1:   # the whole loop at the stress sizes (the kernel-level stress figures follow below)
             el_s, info_s = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
                                         gather, stress_hypotheses=args.hypotheses)
-            stress = {"workload": "the strongest 8192 corners of the first frame (Harris MinQuality %g) start as landmarks, "
+            stress = {"workload": "up to 8192 of the strongest corners of the first frame (Harris MinQuality %g) start as landmarks, "
                                   "exclusion radius 5 px, %d P3P hypotheses solved and scored per frame"
                                   % (STRESS_MIN_QUALITY, args.hypotheses),
                       "frames_per_s": args.steps / el_s, "tracked_landmarks": info_s["n_landmarks"],

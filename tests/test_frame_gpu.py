@@ -197,9 +197,11 @@ def test_one_call_entry_points_match_the_two_halves(vo, ctx, oracle, sequence):
     b.close()
 
 
-def test_device_loop_matches_cpu_restatement_at_kitti_shape(vo, ctx, oracle):
-    """The benchmark's configuration -- 1241x376 frames, KITTI camera, about 2k tracked points, the
-    following frame prepared ahead -- against the CPU restatement of the loop on the same frames and
+@pytest.mark.parametrize("stress", [False, True])
+def test_device_loop_matches_cpu_restatement_at_kitti_shape(vo, ctx, oracle, stress):
+    """The benchmark's configurations -- 1241x376 frames, KITTI camera, the following frame prepared
+    ahead; about 2k tracked points, or (stress) the strongest 8192 corners at MinQuality 2e-5 with 4096
+    hypotheses solved per frame -- against the CPU restatement of the loop on the same frames and
     draws.  Bar: identical counts (landmarks, candidates, RANSAC iterations) and landmark ids every
     frame; poses within 1e-5 m / 1e-5 rad."""
     from oracle import pipeline_oracle as po
@@ -207,21 +209,30 @@ def test_device_loop_matches_cpu_restatement_at_kitti_shape(vo, ctx, oracle):
     poses = vo.synth.corridor_trajectory(7)
     frames = [scene.render(T) for T in poses]
     assert frames[0].shape == (376, 1241)
-    ab, metric, _ = oracle.detect_corners(frames[0], min_quality=2e-4, border=16)
-    xy = (ab + 1.0).astype(np.float64)
-    # strongest corner per 14 px cell: about 2k starting points, as the benchmark thins them
-    key = (np.floor(xy[:, 1] / 14.0).astype(np.int64) << 20) + np.floor(xy[:, 0] / 14.0).astype(np.int64)
-    order = np.lexsort((-metric, key))
-    first = np.ones(len(order), dtype=bool)
-    first[1:] = key[order][1:] != key[order][:-1]
-    xy = xy[np.sort(order[first])]
-    assert 1500 < len(xy) < 3000
-    X0 = scene.backproject(poses[0], xy)
     hp = vo.default_hyper_paras("kitti")
+    if stress:
+        hp.feature_extract_options = ["MinQuality", 2e-5]
+        hp.r_discard_redundant = 5.0
+    ab, metric, _ = oracle.detect_corners(frames[0], min_quality=hp.feature_extract_options[1], border=16)
+    xy = (ab + 1.0).astype(np.float64)
+    if stress:
+        xy = xy[np.sort(np.argsort(-metric, kind="stable")[:8192])]
+        assert 6000 < len(xy) <= 8192
+    else:
+        # strongest corner per 14 px cell: about 2k starting points, as the benchmark thins them
+        key = (np.floor(xy[:, 1] / 14.0).astype(np.int64) << 20) + np.floor(xy[:, 0] / 14.0).astype(np.int64)
+        order = np.lexsort((-metric, key))
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = key[order][1:] != key[order][:-1]
+        xy = xy[np.sort(order[first])]
+        assert 1500 < len(xy) < 3000
+    X0 = scene.backproject(poses[0], xy)
     ref = po.OraclePipeline(scene.K, frames[0], X0, xy, poses[0], hp, 3, 2, np.random.default_rng(11), vo.draw_triples,
                             vo.draw_octets)
     dev = vo.VOPipelineDevice(scene.K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(11), ctx=ctx)
-    for i in range(1, 6):
+    if stress:
+        dev.first_hypotheses = 4096
+    for i in range(1, 4 if stress else 6):
         Tr = ref.process_frame(frames[i])
         Td = dev.process_frame(frames[i], next_image=frames[i + 1])
         assert dev.num_X[-1] == ref.S.num_X[-1] and dev.num_C[-1] == ref.S.num_C[-1], i
