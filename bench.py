@@ -470,10 +470,12 @@ def main():
             "frame_loop_stress_config": stress,
             "ransac_hypotheses_per_s": hyps_per_s,
             "ransac_config": {"workload": "RANSAC stress: %d P3P hypotheses x %d correspondences per step" % (h, n)},
-            "roofline": {"bound": "valu_fp64",
-                         "bound_note": "compute roofline: the kernel is fp64 FMA arithmetic on the vector ALUs; on gfx950 the "
-                                       "fp64 vector and matrix (MFMA) peaks are the same 78.6 TFLOP/s, and 72 TFLOP/s is what a "
-                                       "register-only FMA loop sustains (tools/micro/fp64_peak.hip)",
+            "roofline": {"bound": "mfma",
+                         "bound_note": "compute-bound, priced against the dense fp64 matrix peak, 78.6 TFLOP/s, which on gfx950 "
+                                       "is also the fp64 vector peak; the kernel's arithmetic is fp64 FMA on the vector ALUs "
+                                       "(a 3x4 projection per point is no matrix-core shape, and running both pipes would add "
+                                       "nothing at equal peaks); 72 TFLOP/s is what a register-only FMA loop sustains "
+                                       "(tools/micro/fp64_peak.hip)",
                          "kernel": "p3p_score_kernel (RANSAC stress)", "achieved": achieved,
                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS,
                          "traffic": traffic["bytes"] if traffic else None,
