@@ -182,18 +182,21 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
                 const int bands = 64 / W, rpl = (W + bands - 1) / bands;
                 float pa_[64], pb_[64];
                 for (int grp = 0; grp < 64; ++grp) {
-                    float baf = 0.f, bbf = 0.f;
+                    /* sum (T - J) G formed as sum T G - sum J G within the group (both sums in float with
+                     * fmaf down the column): the first one does not depend on the iteration */
+                    float ctx = 0.f, cty = 0.f, sjx = 0.f, sjy = 0.f;
                     const int band = grp / W, col = grp % W;
                     for (int row = band * rpl; grp < bands * W && row < (band + 1) * rpl && row < W; ++row) {
                         int k = row * W + col;
                         int wb = k / W - half, wa = k % W - half;
                         float j = bilinear(Q[l], A, B, ja + wa, jb + wb, ga, gb);
-                        float e = T[k] - j;
-                        baf = fmaf(e, GX[k], baf);
-                        bbf = fmaf(e, GY[k], bbf);
+                        ctx = fmaf(T[k], GX[k], ctx);
+                        cty = fmaf(T[k], GY[k], cty);
+                        sjx = fmaf(j, GX[k], sjx);
+                        sjy = fmaf(j, GY[k], sjy);
                     }
-                    pa_[grp] = baf;
-                    pb_[grp] = bbf;
+                    pa_[grp] = ctx - sjx;
+                    pb_[grp] = cty - sjy;
                 }
                 const double ba = (double)tree64(pa_), bb = (double)tree64(pb_);
                 const double sa = (gyy * ba - gxy * bb) * inv_det;

@@ -231,6 +231,14 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
             }
         }
         vohip_dev::wave_sum3_f64(gxx, gxy, gyy);
+        // sum (T - J) G = sum T G - sum J G: the first sum does not change during the iterations, so the
+        // lane keeps its part of it (fp32, rows in increasing order) and an iteration only forms sum J G
+        float ctx_ = 0.f, cty_ = 0.f;
+#pragma unroll
+        for (int k = 0; k < C::RPL; ++k) {
+            ctx_ = __builtin_fmaf(T[k], GX[k], ctx_);
+            cty_ = __builtin_fmaf(T[k], GY[k], cty_);
+        }
         const double det = gxx * gyy - gxy * gxy;
         const double lmin = 0.5 * ((gxx + gyy) - sqrt((gxx - gyy) * (gxx - gyy) + 4.0 * gxy * gxy));
         const bool good = (lmin / (double)(W * W) >= KLT_MIN_EIG) && det > 0.0;
@@ -274,16 +282,16 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                 }
                 // per-lane partial sums in fp32 (RPL fused multiply-adds, rows in increasing order), then
                 // a fixed fp32 tree across the wavefront
-                float h[C::RPL + 1], baf = 0.f, bbf = 0.f;
+                float h[C::RPL + 1], sjx = 0.f, sjy = 0.f;
 #pragma unroll
                 for (int r = 0; r <= C::RPL; ++r) h[r] = __builtin_fmaf(ga, dt[r], t0[r]);
 #pragma unroll
                 for (int k = 0; k < C::RPL; ++k) {
                     const float j = __builtin_fmaf(gb, h[k + 1] - h[k], h[k]);
-                    const float e = T[k] - j;
-                    baf = __builtin_fmaf(e, GX[k], baf);
-                    bbf = __builtin_fmaf(e, GY[k], bbf);
+                    sjx = __builtin_fmaf(j, GX[k], sjx);
+                    sjy = __builtin_fmaf(j, GY[k], sjy);
                 }
+                float baf = ctx_ - sjx, bbf = cty_ - sjy;
                 vohip_dev::wave_sum2_f32(baf, bbf);
                 const double ba = (double)baf, bb = (double)bbf;
                 const double sa = (gyy * ba - gxy * bb) * inv_det;
