@@ -169,6 +169,7 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
         const int good = (lmin / (double)(W * W) >= KLT_MIN_EIG) && det > 0.0;
         if (l == 0) ok0 = good;
         const double inv_det = 1.0 / det;
+        const double iaa = gyy * inv_det, iab = gxy * inv_det, ibb = gxx * inv_det;
         if (good) {
             double psa = 0.0, psb = 0.0;
             for (int it = 0; it < max_iter; ++it) {
@@ -199,8 +200,9 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
                     pb_[grp] = cty - sjy;
                 }
                 const double ba = (double)tree64(pa_), bb = (double)tree64(pb_);
-                const double sa = (gyy * ba - gxy * bb) * inv_det;
-                const double sb = (gxx * bb - gxy * ba) * inv_det;
+                /* the inverse of the gradient matrix is formed once per level; a - b c as fma(-b, c, a) */
+                const double sa = fma(-iab, bb, iaa * ba);
+                const double sb = fma(-iab, ba, ibb * bb);
                 da += sa;
                 db += sb;
                 if (sa * sa + sb * sb < KLT_EPS_STEP * KLT_EPS_STEP) break;

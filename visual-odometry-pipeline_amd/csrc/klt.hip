@@ -243,6 +243,9 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
         const double lmin = 0.5 * ((gxx + gyy) - sqrt((gxx - gyy) * (gxx - gyy) + 4.0 * gxy * gxy));
         const bool good = (lmin / (double)(W * W) >= KLT_MIN_EIG) && det > 0.0;
         const double inv_det = 1.0 / det;
+        // the inverse of the gradient matrix, formed once per level: a step is then two products and two
+        // fused multiply-adds
+        const double iaa = gyy * inv_det, iab = gxy * inv_det, ibb = gxx * inv_det;
         if (l == 0) ok0 = good;
         if (good) {
             int cja = 0, cjb = 0;
@@ -294,8 +297,8 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                 float baf = ctx_ - sjx, bbf = cty_ - sjy;
                 vohip_dev::wave_sum2_f32(baf, bbf);
                 const double ba = (double)baf, bb = (double)bbf;
-                const double sa = (gyy * ba - gxy * bb) * inv_det;
-                const double sb = (gxx * bb - gxy * ba) * inv_det;
+                const double sa = __builtin_fma(-iab, bb, iaa * ba);
+                const double sb = __builtin_fma(-iab, ba, ibb * bb);
                 da += sa;
                 db += sb;
                 ++iters;
