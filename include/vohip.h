@@ -100,6 +100,17 @@ int vohip_ransac_p3p_score_dev(vohip_ctx *ctx, const double *d_kp_rc, const doub
                                const double K[9], const int32_t *d_samples, int h,
                                int32_t *d_counts);
 
+/* vohip_ransac_p3p_score_dev for callers that cannot allocate (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments,
+ * same kernels and bit-identical counts, but the candidate poses go to a static 3 MB device array
+ * instead of context buffers, so the call makes no hipMalloc / hipFree: h <= 4096, else
+ * VOHIP_ERR_INVALID_ARGUMENT.  Every call on one GPU shares that GPU's array (whatever the context):
+ * calls that overlap on one GPU race, and the poses are not retrievable (vohip_ransac_p3p_poses and
+ * _count_dev keep referring to the last _solve_dev / _score_dev call).  Asynchronous. */
+int vohip_ransac_p3p_score_noalloc(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
+                                   const double K[9], const int32_t *d_samples, int h,
+                                   int32_t *d_counts);
+
 /* First half of _score_dev: sample -> bearings -> p3p -> 4 candidate poses per hypothesis
  * (ransacLocalization.m:46-68, p3p.m, solveQuartic.m), kept in the context. */
 int vohip_ransac_p3p_solve_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,

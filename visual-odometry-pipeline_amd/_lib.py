@@ -92,6 +92,8 @@ SIGNATURES = {
                                     c_int_p]),
     "vohip_ransac_p3p_score_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
                                               C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_ransac_p3p_score_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
+                                                  C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_ransac_p3p_solve_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
                                               C.c_void_p, C.c_int]),
     "vohip_ransac_p3p_count_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

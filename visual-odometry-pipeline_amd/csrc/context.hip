@@ -95,6 +95,13 @@ int vohip_create(vohip_ctx **out, int device_id, void *hip_stream)
         }
         ctx->owns_stream = true;
     }
+    // the static scratch of the allocation-free entry point: its address on this device
+    if (const int st = vohip_ransac_scratch_init(ctx)) {
+        vohip_fail(nullptr, st, "%s", ctx->err);
+        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return st;
+    }
     *out = ctx;
     return VOHIP_OK;
 }

@@ -57,7 +57,19 @@
 #include "inlier_test.h"
 
 #include <cmath>
+#include <mutex>
 #include <vector>
+
+// Scratch of the allocation-free entry point (vohip_ransac_p3p_score_noalloc): the candidate poses of
+// up to NOALLOC_MAX_H hypotheses, [R_C_W | t_C_W] for all of them, then K [R | t] for all of them
+// (2 x 4096 x 48 doubles = 3 MB).  Every GPU the library runs on holds its own copy until the process
+// ends.  In host code the array's name is only a stand-in: the device address is taken once per
+// device with hipGetSymbolAddress (vohip_ransac_scratch_init) and that pointer is what kernels get.
+constexpr int NOALLOC_MAX_H = 4096;
+static __device__ __align__(256) double scratch[2 * (size_t)NOALLOC_MAX_H * 48];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static double *g_scratch_ptr[NOALLOC_MAX_DEVICES] = {nullptr};
+static std::mutex g_scratch_mutex;
 
 namespace {
 
@@ -782,6 +794,20 @@ int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const doubl
 
 double vohip_ransac_adaptive_iterations(int max_num_inliers, int n) { return adaptive_num_iterations(max_num_inliers, n); }
 
+// Device address of this GPU's copy of `scratch`, taken once per device (called by vohip_create with
+// the context's device current).
+int vohip_ransac_scratch_init(vohip_ctx *ctx)
+{
+    VOHIP_REQUIRE(ctx, ctx->device >= 0 && ctx->device < NOALLOC_MAX_DEVICES, "device index beyond the scratch table");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[ctx->device]) return VOHIP_OK;
+    double *ptr = nullptr;
+    VOHIP_HIP(ctx, hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    VOHIP_REQUIRE(ctx, ptr != nullptr, "hipGetSymbolAddress returned no address for the scratch array");
+    g_scratch_ptr[ctx->device] = ptr;
+    return VOHIP_OK;
+}
+
 extern "C" {
 
 int vohip_ransac_p3p_solve_dev(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
@@ -812,6 +838,31 @@ int vohip_ransac_p3p_score_dev(vohip_ctx *ctx, const double *d_kp_rc, const doub
     VOHIP_REQUIRE(ctx, d_counts, "NULL argument");
     VOHIP_TRY(vohip_ransac_p3p_solve_dev(ctx, d_kp_rc, d_X, n, K, d_samples, h));
     return launch_count(ctx, d_kp_rc, d_X, n, h, d_counts);
+}
+
+int vohip_ransac_p3p_score_noalloc(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n,
+                                   const double K[9], const int32_t *d_samples, int h, int32_t *d_counts)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, d_kp_rc && d_X && K && d_samples && d_counts, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 3, "need at least 3 points");
+    VOHIP_REQUIRE(ctx, h >= 1, "need at least 1 hypothesis");
+    if (h > NOALLOC_MAX_H)
+        return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT,
+                          "%d hypotheses exceed the %d the static scratch holds (use vohip_ransac_p3p_score_dev)", h,
+                          NOALLOC_MAX_H);
+    VOHIP_REQUIRE(ctx, ctx->device >= 0 && ctx->device < NOALLOC_MAX_DEVICES && g_scratch_ptr[ctx->device],
+                  "the scratch address of this device was not taken (vohip_create does it)");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    // every hypothesis [0, h) is written by the solve kernel before the scoring kernel reads it, so
+    // nothing of an earlier call's contents has to be cleared
+    double *d_Rt = g_scratch_ptr[ctx->device];
+    double *d_M = d_Rt + (size_t)NOALLOC_MAX_H * 48;
+    const vohip_K Kv = vohip_make_K(K);
+    hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n,
+                       (const int *)nullptr, Kv, d_samples, h, d_Rt, d_M, (int32_t *)nullptr);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, h, d_counts);
 }
 
 int vohip_ransac_p3p_poses(vohip_ctx *ctx, int first, int count, double *Rt)

@@ -128,6 +128,7 @@ int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
 int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                               const double *d_M12, uint8_t *d_mask);
 double vohip_ransac_adaptive_iterations(int max_num_inliers, int n);
+int vohip_ransac_scratch_init(vohip_ctx *ctx);   // once per device, with that device current
 int vohip_fm_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int *d_n,
                      const int32_t *d_samples, int num_trials, double threshold, double *d_nrm, double *d_F,
                      int32_t *d_counts);
