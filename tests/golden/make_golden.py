@@ -92,9 +92,16 @@ def klt_frames(h=240, w=320, seed=31):
 
 
 def make_klt():
+    """The tracks come from tests/ref_klt.py -- a plain float64 numpy statement of the tracker that shares
+    no arithmetic structure (accumulator types, lane banding, reduction tree) with the HIP kernel or the C
+    oracle -- so this fixture does not move when the kernel's summation order is changed, and must NOT be
+    regenerated for such a change.  Only the pyramid levels (a float32 tap formula, bit-exact by definition)
+    come from the C oracle."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import ref_klt
     I0, I1, pts = klt_frames()
-    # row-major image: fast axis a = x, slow axis b = y; 0-based coordinates for the oracle
-    out, valid, fb = orc.klt_track(I0, I1, pts - 1.0, block=21, levels=5, max_iter=20, max_bidir_error=6.0)
+    # row-major image: x is the fast axis; 0-based coordinates
+    out, valid, fb = ref_klt.track(I0, I1, pts - 1.0, block=21, levels=5, max_iter=20, max_bidir_error=6.0)
     lv = [orc.pyramid_level(I0, l) for l in range(5)]
     np.savez_compressed(os.path.join(HERE, "klt_320x240.npz"), I0=I0, I1=I1, pts=pts, out=out + 1.0, valid=valid,
                         fb_err=fb, level1=lv[1], level3=lv[3], level4=lv[4])

@@ -2,9 +2,13 @@
 implementations, and the committed golden vectors.  (The reference itself has no tests or
 fixtures and cannot be run, so parity against MATLAB is unpinned; these tests pin the oracle.)"""
 import os
+import sys
 
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_p3p  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -152,3 +156,17 @@ def test_draw_triples_distinct_and_streamed(vo):
     # every index reachable, roughly uniform
     t = vo.draw_triples(np.random.default_rng(1), 3, 3000)
     assert set(map(tuple, np.sort(t, axis=1))) == {(0, 1, 2)}
+
+
+def test_golden_counts_match_independent_p3p():
+    """The 256 golden hypotheses scored by tests/ref_p3p.py -- numpy.roots instead of the Ferrari closed
+    form, numpy complex arithmetic with the real part taken at the end, divide-then-compare scoring --
+    give the same four inlier counts per hypothesis (as a set: numpy.roots orders the roots differently)."""
+    g = np.load(os.path.join(GOLD, "ransac_n2000_h256.npz"))
+    kp_uv = g["kp_rc"][::-1].T.copy()
+    X = g["X"].T.copy()
+    for i, s in enumerate(g["samples"]):
+        counts, errs, _ = ref_p3p.hypothesis_counts(kp_uv, X, g["K"], s)
+        got = sorted(counts) if counts else [0, 0, 0, 0]
+        assert got == sorted(g["counts"][i].tolist()), i
+        assert all(np.sum(np.abs(e - 100.0) < 1e-6) == 0 for e in errs)   # no point sits on the threshold

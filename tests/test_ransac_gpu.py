@@ -6,10 +6,14 @@ the kernel tests (x-uz)^2+(y-vz)^2 < 100 z^2 with FMAs instead of dividing first
 1e-9 relative (they differ only through the last bits of pow/atan2/sincos)."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_p3p  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -67,6 +71,32 @@ def test_score_counts_match_golden(vo, ctx):
     ok = np.isfinite(want).all(1)
     scale = np.maximum(1.0, np.abs(want[ok]))
     assert np.max(np.abs(got[ok] - want[ok]) / scale) < 1e-9
+
+
+def test_score_counts_match_independent_p3p(vo, ctx):
+    """HIP counts and poses of the 256 golden hypotheses against tests/ref_p3p.py, which shares neither
+    the Ferrari closed form nor the hand-rolled complex helpers nor the division-free inlier test with
+    the kernel: per hypothesis the four counts agree as a set (numpy.roots orders the roots differently),
+    outside the tie band, and every finite HIP pose has a reference pose next to it."""
+    g = np.load(os.path.join(GOLD, "ransac_n2000_h256.npz"))
+    counts, Rt, _ = _score_dev(vo, ctx, g["kp_rc"], g["X"], g["K"], g["samples"])
+    kp_uv = g["kp_rc"][::-1].T.copy()
+    X = g["X"].T.copy()
+    worst = 0.0
+    for i, s in enumerate(g["samples"]):
+        want, errs, poses = ref_p3p.hypothesis_counts(kp_uv, X, g["K"], s)
+        want = sorted(want) if want else [0, 0, 0, 0]
+        got = sorted(counts[i].tolist())
+        near = max([int(np.sum(np.abs(e - 100.0) < TIE_BAND)) for e in errs] + [0])
+        assert max(abs(a - b) for a, b in zip(got, want)) <= near, (i, got, want)
+        for sol in range(4):
+            if counts[i, sol] < 30:
+                continue   # (poses of root pairs that are complex in exact arithmetic are ill-conditioned)
+            R = Rt[i, sol, :9].reshape(3, 3).T
+            t = Rt[i, sol, 9:]
+            dist = min(np.abs(R - Rr).max() + np.abs(t - tr).max() / max(1.0, np.abs(tr).max()) for Rr, tr in poses)
+            worst = max(worst, dist)
+    assert worst < 1e-8, worst
 
 
 def test_p3p_matches_golden(vo, ctx):
