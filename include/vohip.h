@@ -190,11 +190,13 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
                                     double *d_angles);
 
 /* ---- the frame loop with device-resident state -------------------------------------------------
- * The loop body main_demo.m:377-427 (is_BA = false) as one call per frame.  S.P, S.X, S.C, S.F
+ * The loop body main_demo.m:377-427 as one call per frame.  S.P, S.X, S.C, S.F
  * and S.T (main_demo.m:272-279) stay in GPU memory between frames; the stages are the kernels behind
  * the entry points above, chained through device-side counts, so the state after each frame is the
  * one the stage-by-stage calls produce (genKeypoints.m, ransacLocalization.m, T_refinement.m,
- * update_landmarks.m, update_candidate.m).  Bundle adjustment is not part of this path.
+ * update_landmarks.m, update_candidate.m).  With is_BA the caller keeps VO_bundle_adjust.m's window
+ * bookkeeping and calls runBA itself between frames (vohip_frame_state, vohip_ba_run,
+ * vohip_frame_apply_ba).
  *
  * Random numbers: the caller passes uniform draws in [0, 1) instead of index sets, because the
  * sizes they index are only known on the device: 3 per P3P hypothesis (mapped to 3 distinct
@@ -222,6 +224,8 @@ typedef struct vohip_frame_params {
     int cap_landmarks, cap_candidates, cap_corners;   /* capacities of the device arrays */
     int max_hypotheses;                        /* 15000, ransacLocalization.m:128 */
     int slot_a, slot_b, slot_c;                /* the three pyramid slots of the context this loop uses */
+    int is_BA;                                 /* hyper_paras.is_BA: update_landmarks.m:78-88 then also asks for
+                                                  reprojection errors below 100 px in both views */
 } vohip_frame_params;
 
 typedef struct vohip_frame_pose {
@@ -281,6 +285,16 @@ int vohip_frame_finish(vohip_frame *f, vohip_frame_pose *pose, vohip_frame_count
 int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates);
 /* Copies of S.P (2xn), S.X(1:3,:) (3xn), S.X(4,:), S.C, S.F (2xm), S.T (12xm); any pointer may be NULL. */
 int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc, double *T12);
+
+/* The device-side half of VO_bundle_adjust.m:53-70 for a loop whose state lives on the GPU.  The
+ * keyframe bookkeeping and the runBA call stay with the caller (which reads S.P, S.X with
+ * vohip_frame_state after each frame); when a window was optimised, this call puts the result back:
+ * X 3xn replaces S.X(1:3,:) (n = size(S.X, 2); :62-70, landmarks the depth test rejected keep their old
+ * column) and T_W_C (4x4 column-major), the optimised pose of the current keyframe (:53-57), replaces the
+ * pose that update_candidate.m:57 stamped on the candidates added by the frame just finished.  Call it
+ * between frames (after vohip_frame_finish, before the next vohip_frame_begin).  Synchronises a side
+ * stream only: trackers already enqueued for the following frame keep running. */
+int vohip_frame_apply_ba(vohip_frame *f, const double *X, int n, const double T_W_C[16]);
 
 /* ---- trajectory alignment (evaluation) ---------------------------------------------------------
  * utils/exe9_BA/alignEstimateToGroundTruth.m:1-27 with the residual of alignError.m:1-17, as

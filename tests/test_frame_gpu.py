@@ -118,9 +118,6 @@ def test_device_loop_accepts_device_images_and_reports_errors(vo, ctx, oracle, s
     with pytest.raises(ValueError):
         d.process_frame(frames[3])
     d.close()
-    hp_ba = vo.default_hyper_paras("kitti", is_BA=True)
-    with pytest.raises(NotImplementedError):
-        vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp_ba, ctx=ctx)
     # capacity is checked
     with pytest.raises(vo.VohipError):
         vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, ctx=ctx, cap_landmarks=64)

@@ -1,8 +1,10 @@
 """ctypes binding of libvohip.so -- the one place the C ABI of include/vohip.h is declared to
 Python.  There is no CPU fallback: if the library is missing or no GPU is visible, calls fail.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -41,7 +43,7 @@ class FrameParams(C.Structure):
                 ("refine_pose", C.c_int), ("refine_max_iter", C.c_int), ("fm_trials", C.c_int),
                 ("fm_threshold", C.c_double), ("fm_confidence", C.c_double), ("cap_landmarks", C.c_int),
                 ("cap_candidates", C.c_int), ("cap_corners", C.c_int), ("max_hypotheses", C.c_int),
-                ("slot_a", C.c_int), ("slot_b", C.c_int), ("slot_c", C.c_int)]
+                ("slot_a", C.c_int), ("slot_b", C.c_int), ("slot_c", C.c_int), ("is_BA", C.c_int)]
 
 
 class FramePose(C.Structure):
@@ -80,6 +82,7 @@ SIGNATURES = {
     "vohip_frame_sizes": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
     "vohip_frame_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]),
+    "vohip_frame_apply_ba": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
     "vohip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "vohip_destroy": (C.c_int, [C.c_void_p]),
     "vohip_last_error": (C.c_char_p, [C.c_void_p]),
@@ -194,6 +197,22 @@ def colmajor(mat):
     return np.ascontiguousarray(np.asarray(mat, dtype=np.float64).T)
 
 
+# Objects that own GPU resources, closed in order (frame loops before their contexts) when the
+# interpreter exits: a destructor that runs after the HIP runtime has shut down would abort the process.
+_live_frames = weakref.WeakSet()
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    for group in (_live_frames, _live_contexts):
+        for obj in list(group):
+            try:
+                obj.close()
+            except Exception:
+                pass
+
+
 class Context:
     """One GPU + one HIP stream.  `stream` is a raw hipStream_t (int) or None."""
 
@@ -205,6 +224,7 @@ class Context:
             raise VohipError(st, lib.vohip_last_error(None).decode())
         self._h = h
         self.device = device
+        _live_contexts.add(self)
 
     @property
     def handle(self):

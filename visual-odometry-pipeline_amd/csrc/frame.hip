@@ -1,6 +1,7 @@
 // The continuous-operation loop body with the state resident on the GPU (gfx950).
 //
-// Restates main_demo.m:377-427 with is_BA = false -- detection (genKeypoints.m), the landmark
+// Restates main_demo.m:377-427 (VO_bundle_adjust's window bookkeeping at :409-411 stays with the caller,
+// see vohip_frame_apply_ba) -- detection (genKeypoints.m), the landmark
 // tracker, ransacLocalization.m, T_refinement.m, update_landmarks.m, update_candidate.m and the
 // tracker re-initialisation -- as ONE call and ONE synchronisation per frame (vohip_frame_step,
 // vohip_frame_step_ahead):
@@ -627,6 +628,23 @@ __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__r
     }
 }
 
+// VO_bundle_adjust.m:53-57 rewrites the pose of the current keyframe before update_candidate.m:57
+// stamps it on the candidates the frame adds: here the frame has already added them (with the pose
+// the localisation gave), so the optimised pose replaces it in dv and in the T columns of exactly
+// those candidates, [N_C_MID, N_C_END).
+__global__ __launch_bounds__(256) void restamp_pose_kernel(const double *__restrict__ T_new, const int *__restrict__ cnt,
+                                                           double *__restrict__ dv, double *__restrict__ T12)
+{
+    const int first = cnt[N_C_MID], last = cnt[N_C_END];
+    double o[12];   // [R_W_C(:); t_W_C]
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) o[3 * c + r] = T_new[4 * c + r];
+    for (int r = 0; r < 3; ++r) o[9 + r] = T_new[12 + r];
+    for (int d = first + blockIdx.x * 256 + threadIdx.x; d < last; d += gridDim.x * 256)
+        for (int q = 0; q < 12; ++q) T12[12 * (size_t)d + q] = o[q];
+    if (blockIdx.x == 0 && threadIdx.x < 16) dv[D_T + threadIdx.x] = T_new[threadIdx.x];
+}
+
 // The track tables, one for even and one for odd frames.  Row r holds a point of that frame's image
 // which the tracker can follow into the next image: rows [0, capL) the landmarks in the order the
 // frame starts with, rows [capL, capL + capC) the candidates, rows [capL + capC, capL + capC + capK)
@@ -927,8 +945,8 @@ int enqueue_tail(vohip_frame *f)
     const int *n_det = f->cnt + N_DET + f->par;
     if (f->have_map) {
         VOHIP_TRY(vohip_candidate_triangulate_enqueue(ctx, f->m2_rc, f->F2, f->T2, f->n_C, f->cnt + N_CI, f->dv + D_T,
-                                                      f->K, p.angle_threshold_deg, p.min_depth, p.max_depth, 0,
-                                                      f->status, f->Xnew));
+                                                      f->K, p.angle_threshold_deg, p.min_depth, p.max_depth,
+                                                      p.is_BA ? 1 : 0, f->status, f->Xnew));
         hipLaunchKernelGGL(split_candidates_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->status, f->m2_rc, f->F2,
                            f->T2, f->Xnew, f->row2, f->cnt, n_det, f->dv, f->capL, f->capK, f->L_rc, f->L_X, f->L_id,
                            f->srcL, f->C_rc, f->F_rc, f->T12, f->srcC);
@@ -1105,6 +1123,7 @@ void vohip_frame_default_params(vohip_frame_params *p)
     p->slot_a = 6;
     p->slot_b = 7;
     p->slot_c = 5;
+    p->is_BA = 0;
 }
 
 int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor,
@@ -1429,13 +1448,35 @@ int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, doub
     VOHIP_REQUIRE(ctx, f->stage == 0, "the state is complete only between frames");
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nL = f->n_L, nC = f->n_C;
-    if (P_rc) VOHIP_TRY(vohip_download(ctx, P_rc, f->L_rc, sizeof(double) * 2 * nL));
-    if (X) VOHIP_TRY(vohip_download(ctx, X, f->L_X, sizeof(double) * 3 * nL));
-    if (ids) VOHIP_TRY(vohip_download(ctx, ids, f->L_id, sizeof(double) * nL));
-    if (C_rc) VOHIP_TRY(vohip_download(ctx, C_rc, f->C_rc, sizeof(double) * 2 * nC));
-    if (F_rc) VOHIP_TRY(vohip_download(ctx, F_rc, f->F_rc, sizeof(double) * 2 * nC));
-    if (T12) VOHIP_TRY(vohip_download(ctx, T12, f->T12, sizeof(double) * 12 * nC));
-    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // The state is final once the frame's last kernel has run (vohip_frame_finish waited for it); the
+    // copies go on the second stream, which is idle between frames, because the context's stream may
+    // already hold the following frame's trackers (which touch none of these arrays).
+    hipStream_t s = f->side;
+    if (P_rc && nL) VOHIP_HIP(ctx, hipMemcpyAsync(P_rc, f->L_rc, sizeof(double) * 2 * nL, hipMemcpyDeviceToHost, s));
+    if (X && nL) VOHIP_HIP(ctx, hipMemcpyAsync(X, f->L_X, sizeof(double) * 3 * nL, hipMemcpyDeviceToHost, s));
+    if (ids && nL) VOHIP_HIP(ctx, hipMemcpyAsync(ids, f->L_id, sizeof(double) * nL, hipMemcpyDeviceToHost, s));
+    if (C_rc && nC) VOHIP_HIP(ctx, hipMemcpyAsync(C_rc, f->C_rc, sizeof(double) * 2 * nC, hipMemcpyDeviceToHost, s));
+    if (F_rc && nC) VOHIP_HIP(ctx, hipMemcpyAsync(F_rc, f->F_rc, sizeof(double) * 2 * nC, hipMemcpyDeviceToHost, s));
+    if (T12 && nC) VOHIP_HIP(ctx, hipMemcpyAsync(T12, f->T12, sizeof(double) * 12 * nC, hipMemcpyDeviceToHost, s));
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    return VOHIP_OK;
+}
+
+int vohip_frame_apply_ba(vohip_frame *f, const double *X, int n, const double T_W_C[16])
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, f->stage == 0, "the state can be changed only between frames");
+    VOHIP_REQUIRE(ctx, X && T_W_C, "NULL argument");
+    VOHIP_REQUIRE(ctx, n == f->n_L, "X must hold one column per landmark of the state");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = f->side;   // (idle between frames; see vohip_frame_state)
+    double *stage = pin_u3(f);  // the draws of the finished frame are no longer needed
+    std::memcpy(stage, T_W_C, sizeof(double) * 16);
+    if (n) VOHIP_HIP(ctx, hipMemcpyAsync(f->L_X, X, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(restamp_pose_kernel, dim3(8), dim3(256), 0, s, stage, f->cnt, f->dv, f->T12);
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
     return VOHIP_OK;
 }
 

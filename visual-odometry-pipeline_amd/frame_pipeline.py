@@ -1,6 +1,11 @@
-"""The continuous-operation loop (main_demo.m:377-427, is_BA = false) with its state resident on the
-GPU: a thin driver over the vohip_frame_* entry points of libvohip.so.  Same constructor and
+"""The continuous-operation loop (main_demo.m:377-427, main_BA.m:261-305) with its state resident on
+the GPU: a thin driver over the vohip_frame_* entry points of libvohip.so.  Same constructor and
 methods as pipeline.VOPipeline; the state S is downloaded only when asked for.
+
+With hyper_paras.is_BA the window bookkeeping of VO_bundle_adjust.m stays on the host, as in the
+reference: after each frame S.P and S.X come down in one copy, pipeline.VO_bundle_adjust runs (runBA
+and the normal-frame re-refinements on the GPU), and when a window was optimised the landmarks and
+the keyframe's pose go back up in one copy (vohip_frame_apply_ba).
 
 Per frame the host does one library call (one synchronisation) and draws the random numbers the two
 RANSAC stages consume, from the same two generators as VOPipeline: `rng` gives 3 uniforms per P3P
@@ -14,18 +19,17 @@ import numpy as np
 
 from . import _lib
 from ._lib import VOHIP_NO_MODEL, VOHIP_SAMPLES_EXHAUSTED, colmajor, dptr
-from .pipeline import default_hyper_paras
+from .pipeline import VO_bundle_adjust, default_hyper_paras, init_state
 from .ransac import MAX_ITERATIONS
 
 
 class VOPipelineDevice:
     def __init__(self, K, first_image, p_W_landmarks, keypoints_xy, T_init_WC, hyper_paras=None, rng=None, ctx=None,
-                 tracker_options=None, rng_map=None, cap_landmarks=8192, cap_candidates=8192, cap_corners=16384):
+                 tracker_options=None, rng_map=None, cap_landmarks=8192, cap_candidates=8192, cap_corners=16384,
+                 window_size=3, keyframe_d=2):
         self.ctx = ctx or _lib.default_context()
         self.K = np.asarray(K, dtype=np.float64)
         self.hp = hyper_paras or default_hyper_paras()
-        if self.hp.is_BA:
-            raise NotImplementedError("the device-resident loop has no bundle adjustment; use VOPipeline")
         if self.hp.feature_extract not in ("Harris", "MinEigen"):
             raise NotImplementedError("detector '%s' is not built" % self.hp.feature_extract)
         self.rng = rng or np.random.default_rng()
@@ -49,6 +53,7 @@ class VOPipelineDevice:
         prm.min_depth = float(self.hp.min_depth)
         prm.max_depth = float(self.hp.max_depth)
         prm.refine_pose = int(bool(self.hp.is_refine_pose))
+        prm.is_BA = int(bool(self.hp.is_BA))
         prm.cap_landmarks, prm.cap_candidates, prm.cap_corners = int(cap_landmarks), int(cap_candidates), int(cap_corners)
         free = self.ctx.__dict__.setdefault("_free_pyr_slots", list(range(16)))
         if len(free) < 3:
@@ -66,6 +71,7 @@ class VOPipelineDevice:
         self.ctx.check(lib.vohip_frame_create(self.ctx.handle, dptr(colmajor(self.K)), shape[0], shape[1], self._colmajor,
                                               C.byref(prm), C.byref(h)))
         self._h = h
+        _lib._live_frames.add(self)
         X = np.ascontiguousarray(np.asarray(p_W_landmarks, dtype=np.float64).reshape(-1, 3))
         P_rc = np.ascontiguousarray(np.asarray(keypoints_xy, dtype=np.float64).reshape(-1, 2)[:, ::-1])
         T = np.asarray(T_init_WC, dtype=np.float64)
@@ -80,6 +86,10 @@ class VOPipelineDevice:
         self.num_X, self.num_C, self.num_new = [X.shape[0]], [0], [0]
         self.frames = 0
         self.first_hypotheses = 104   # supplied with the frame; the adaptive bound asks for more when it needs them
+        self.B = None
+        self.ba_runs = 0
+        if self.hp.is_BA:   # main_demo.m:288-303: the window struct (its S is only a container here)
+            _, self.B = init_state(p_W_landmarks, keypoints_xy, T_init_WC, window_size, keyframe_d, ctx=self.ctx)
         self.last_pose = None
         self.last_counts = None
 
@@ -153,7 +163,44 @@ class VOPipelineDevice:
             self.rng_map.bit_generator.state = state_map
         self.frames += 1
         self.last_pose, self.last_counts = pose, counts
+        if self.hp.is_BA:                                                                   # :409-411
+            self._bundle_adjust(T_W_C)
         return T_W_C
+
+    def _landmarks(self):
+        """S.P (2xn, (row; col)) and S.X (4xn) from the GPU."""
+        lib = _lib.load()
+        n = self.num_X[-1]
+        P, X, ids = np.zeros((max(n, 1), 2)), np.zeros((max(n, 1), 3)), np.zeros(max(n, 1))
+        self.ctx.check(lib.vohip_frame_state(self._h, dptr(P), dptr(X), dptr(ids), None, None, None))
+        return P[:n].T.copy(), np.vstack([X[:n].T, ids[:n]])
+
+    def _bundle_adjust(self, T_W_C):
+        """VO_bundle_adjust.m:1-98 on the host copy of the landmarks; what it changes goes back to the GPU."""
+        B = self.B
+        S = SimpleNamespace()
+        S.P, S.X = self._landmarks()
+        S.est_trans, S.est_rot = self.trajectory()
+        new = S.X[3] >= B.new_idx                     # update_landmarks.m:83-95: B.landmarks grows with S.X
+        k = int(new.sum())
+        if k:
+            B.landmarks = np.hstack([B.landmarks, S.X[:, new]])
+            B.new_idx += k
+        B.m = B.landmarks.shape[1]
+        X_before = S.X[:3].copy()
+        optimise = B.count_frame == B.keyframe_d and B.num_key >= B.window_size   # VO_bundle_adjust.m:3,17
+        S, self.B = VO_bundle_adjust(S, B, T_W_C, self.K, self.hp, ctx=self.ctx)
+        if not optimise:
+            return
+        self.ba_runs += 1
+        self.est_trans = [c.copy() for c in S.est_trans.T]
+        self.est_rot = [c.copy() for c in S.est_rot.T]
+        T_new = np.eye(4)                             # :53-57, the current keyframe's optimised pose
+        T_new[:3, :3] = S.est_rot[:, -1].reshape(3, 3, order="F")
+        T_new[:3, 3] = S.est_trans[:, -1]
+        if not np.array_equal(S.X[:3], X_before) or not np.array_equal(T_new, T_W_C):
+            Xc = np.ascontiguousarray(S.X[:3].T)
+            self.ctx.check(_lib.load().vohip_frame_apply_ba(self._h, dptr(Xc), Xc.shape[0], dptr(colmajor(T_new))))
 
     def trajectory(self):
         """est_trans (3 x T) and est_rot (9 x T), as saved by main_demo.m:473-476."""

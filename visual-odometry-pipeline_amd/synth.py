@@ -7,6 +7,14 @@ K_KITTI = np.array([[718.856, 0.0, 607.1928],
                     [0.0, 718.856, 185.2157],
                     [0.0, 0.0, 1.0]])
 KITTI_W, KITTI_H = 1241, 376
+# The parking calibration the reference holds, data/epfl_parking/calibration/K.txt:1-3 (1280 x 960 frames,
+# data/epfl_parking/readme.md); the K.txt of the 640 x 480 "parking" set (main_demo.m:100-105) is not in the
+# repository, so synthetic parking sequences use this camera at half resolution.
+K_EPFL_PARKING = np.array([[973.223300, 0.0, 656.959936],
+                           [0.0, 971.330996, 488.683233],
+                           [0.0, 0.0, 1.0]])
+K_PARKING = np.array([[0.5, 0.0, 0.0], [0.0, 0.5, 0.0], [0.0, 0.0, 1.0]]) @ K_EPFL_PARKING
+PARKING_W, PARKING_H = 640, 480
 
 
 def rotation_from_rotvec(w):
