@@ -7,13 +7,16 @@ Workload (N = 1): the per-frame continuous-operation loop on a rendered KITTI-sh
 (1241 x 376, ~2k tracked keypoints, Harris MinQuality 2e-4, 21x21 / 5-level KLT, adaptive P3P
 RANSAC, pose refinement, F-matrix filter, triangulation, candidate filter; no BA) -- one step = one
 frame, frames resident in HBM before the timed region; the loop state stays on the GPU
-(VOPipelineDevice over the vohip_frame_* entry points).  N > 1: every rank runs its own replica of
-that sequence (the reference's batch mode, main_eval.m:22-23, shards independent runs) and the
-trajectory records are gathered with one all_gather (RCCL) inside the timed region.
+(VOPipelineDevice over the vohip_frame_* entry points).  N > 1: the reference's batch mode
+(main_eval.m:22-23) shards independent runs, so every rank runs its own work item of the run grid --
+its own rendered sequence and random seed, dealt by batch.shard -- with no exchange while it runs, and
+the result records are gathered with one all_gather (RCCL) inside the timed region.
 
-Also measured and reported in the same JSON line: the RANSAC stress configuration (4096 P3P
-hypotheses x 8192 correspondences per step) as hypotheses/s, and the roofline of its scoring
-kernel.  The CPU oracle is used only for the cpu_baseline leg.
+Also measured and reported in the same JSON line (N = 1): the same loop over 200 frames, with bundle
+adjustment (main_BA.m's window), in the parking configuration, at stress sizes and for four sequences at
+once; the tracker kernel's roofline (`roofline`: the kernel the headline is bound by); the RANSAC stress
+configuration (4096 P3P hypotheses x 8192 correspondences per step) as hypotheses/s with the roofline of
+its scoring kernel (`roofline_ransac`).  The CPU oracle is used only for the cpu_baseline leg.
 """
 import argparse
 import importlib
@@ -34,10 +37,21 @@ FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X vector fp32
 LDS_PEAK_TBS = 78.6            # 256 CU x 128 B/clk x 2.4 GHz
 MATLAB_KITTI_HARRIS_FPS = 3.817  # the reference's published figure (Ryzen 7 5800H, MATLAB, real KITTI 05)
 CACHE = os.environ.get("VOHIP_CACHE", "/tmp/vohip_cache")
-STRESS_MIN_QUALITY = 2e-5   # Harris MinQuality of the stress configuration (2e-4 in the KITTI configuration)
+MATLAB_PARKING_BA_FPS = 1.681    # ... parking with bundle adjustment (window 5, every 2nd frame), 5-run mean
+MATLAB_PARKING_FPS = 4.559       # ... parking without bundle adjustment, 5-run mean
+# Workload sizes.  KITTI configuration: about 2 000 tracked landmarks and about 2 000 candidates per frame are
+# held with a 10 px thinning cell for the first frame's corners and a 5.5 px exclusion radius for new
+# candidates (the reference's 10 px leaves ~1 100 + ~950 on the rendered corridor); Harris MinQuality stays 2e-4.
+KITTI_THIN_CELL = 10.0
+KITTI_EXCLUSION_RADIUS = 5.5
+# Stress configuration: every corner the rendered frames hold (about 8 250 local maxima at MinQuality 1e-6)
+# with a 2 px exclusion radius: about 6 400 landmarks + 5 400 candidates tracked per frame.
+STRESS_MIN_QUALITY = 1e-6
+STRESS_EXCLUSION_RADIUS = 2.0
+STRESS_CAPACITY = 16384
 
 
-def thin_by_grid(xy, metric, cell=14.0):
+def thin_by_grid(xy, metric, cell=KITTI_THIN_CELL):
     """Strongest corner per cell: brings the first frame's detections to about 2k points."""
     key = (np.floor(xy[:, 1] / cell).astype(np.int64) << 20) + np.floor(xy[:, 0] / cell).astype(np.int64)
     order = np.lexsort((-metric, key))
@@ -46,9 +60,10 @@ def thin_by_grid(xy, metric, cell=14.0):
     return np.sort(order[first])
 
 
-def make_sequence(vo, n_frames):
-    frames, poses = vo.synth.corridor_sequence(n_frames, cache_dir=CACHE)
-    scene = vo.synth.CorridorScene()
+def make_sequence(vo, n_frames, item=0):
+    """Work item `item` of the batch grid: its own rendered corridor (texture seed 5678 + item)."""
+    frames, poses = vo.synth.corridor_sequence(n_frames, seed=5678 + item, cache_dir=CACHE)
+    scene = vo.synth.CorridorScene(seed=5678 + item)
     return scene, frames, poses
 
 
@@ -63,13 +78,14 @@ def init_points(vo, ctx, scene, frame0, pose0, thin=True, min_quality=2e-4, limi
 
 
 def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barrier, gather, resident=True, ahead=True,
-                 stress_hypotheses=0):
+                 stress_hypotheses=0, bundle_adjust=False):
     """ahead: every call also hands over the following frame of the stored sequence, whose pyramid and corners
     are then prepared beside the localisation of the current one (same results; the sequence holds one frame
     more than is processed).
     stress_hypotheses > 0: the stress configuration -- every corner of the first frame starts as a landmark
     (about 6k, no thinning) and that many P3P hypotheses are solved and scored in every frame (the adaptive
-    rule still picks the winner among the iterations it would have executed)."""
+    rule still picks the winner among the iterations it would have executed).
+    bundle_adjust: main_BA.m's configuration (is_BA, window of 5 keyframes, every 2nd frame a keyframe)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     if resident:
         d_frames = [torch.from_numpy(f).to(dev) for f in frames[:warmup + steps + 2]]
@@ -80,14 +96,17 @@ def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barr
             t.to(dev)
         torch.cuda.synchronize()
         d_frames = [t.numpy() for t in keep]
-    hp = vo.default_hyper_paras("kitti", is_BA=False)
-    if stress_hypotheses:   # denser corners and a narrower exclusion radius: about 8k points tracked per frame
+    hp = vo.default_hyper_paras("kitti", is_BA=bundle_adjust)
+    hp.r_discard_redundant = KITTI_EXCLUSION_RADIUS
+    if stress_hypotheses:   # every corner of the frames and a narrow exclusion radius: about 12k points tracked per frame
         hp.feature_extract_options = ["MinQuality", STRESS_MIN_QUALITY]
-        hp.r_discard_redundant = 5.0
+        hp.r_discard_redundant = STRESS_EXCLUSION_RADIUS
     X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0], thin=not stress_hypotheses,
-                          min_quality=STRESS_MIN_QUALITY if stress_hypotheses else 2e-4, limit=8192)
+                          min_quality=STRESS_MIN_QUALITY if stress_hypotheses else 2e-4, limit=STRESS_CAPACITY)
+    cap = STRESS_CAPACITY if stress_hypotheses else 8192
     pipe = vo.VOPipelineDevice(vo.synth.K_KITTI, d_frames[0], X0, xy0, poses[0], hyper_paras=hp,
-                               rng=np.random.default_rng(seed), ctx=ctx)
+                               rng=np.random.default_rng(seed), ctx=ctx, cap_landmarks=cap, cap_candidates=cap,
+                               window_size=5, keyframe_d=1)
     if stress_hypotheses:
         pipe.first_hypotheses = stress_hypotheses
     for i in range(1, warmup + 1):
@@ -106,7 +125,7 @@ def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barr
     T = pipe.est_trans[-1]
     info = dict(n_landmarks=int(np.mean(pipe.num_X[-steps:])), n_candidates=int(np.mean(pipe.num_C[-steps:])),
                 final_position_error_m=float(np.linalg.norm(T - poses[last][:3, 3])), records=len(records),
-                host_enqueue_us_per_frame=enq / steps, host_wait_us_per_frame=wait / steps)
+                host_enqueue_us_per_frame=enq / steps, host_wait_us_per_frame=wait / steps, ba_runs=pipe.ba_runs)
     pipe.close()
     return elapsed, info
 
@@ -128,8 +147,9 @@ def bench_frames_concurrent(vo, torch, scene, frames, poses, steps, warmup, n_se
             with torch.cuda.stream(stream):
                 ctx = vo.Context(dev.index, stream=stream.cuda_stream)
                 X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
-                pipe = vo.VOPipelineDevice(vo.synth.K_KITTI, d_frames[0], X0, xy0, poses[0],
-                                           hyper_paras=vo.default_hyper_paras("kitti", is_BA=False),
+                hp = vo.default_hyper_paras("kitti", is_BA=False)
+                hp.r_discard_redundant = KITTI_EXCLUSION_RADIUS
+                pipe = vo.VOPipelineDevice(vo.synth.K_KITTI, d_frames[0], X0, xy0, poses[0], hyper_paras=hp,
                                            rng=np.random.default_rng(1000 + idx), ctx=ctx)
                 for i in range(1, warmup + 1):
                     pipe.process_frame(d_frames[i], next_image=d_frames[i + 1])
@@ -153,6 +173,37 @@ def bench_frames_concurrent(vo, torch, scene, frames, poses, steps, warmup, n_se
     if errors:
         raise errors[0]
     return n_seq * steps / max(seconds)
+
+
+def bench_parking(vo, torch, ctx, steps, warmup, bundle_adjust):
+    """The reference's parking configuration (main_demo.m:100-112; with bundle_adjust main_BA.m:197-198: window of
+    5 keyframes, every 2nd frame a keyframe) on a rendered 640 x 480 sequence seen through the parking calibration
+    the reference holds (at half resolution), frames resident in HBM; returns frames/s and the mean counts."""
+    K, W, H = vo.synth.K_PARKING, vo.synth.PARKING_W, vo.synth.PARKING_H
+    scene = vo.synth.CorridorScene(K=K, width=W, height=H, half_width=5.0, roof=4.0)
+    poses = vo.synth.corridor_trajectory(warmup + steps + 2, step=0.3)
+    frames = [scene.render(T) for T in poses]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d_frames = [torch.from_numpy(f).to(dev) for f in frames]
+    _, kp = vo.genKeypoints(frames[0], "Harris", ["MinQuality", 2e-4], ctx=ctx)
+    xy = kp.Location.astype(np.float64)
+    xy = xy[thin_by_grid(xy, kp.Metric)]
+    hp = vo.default_hyper_paras("parking", is_BA=bundle_adjust)
+    pipe = vo.VOPipelineDevice(K, d_frames[0], scene.backproject(poses[0], xy), xy, poses[0], hyper_paras=hp,
+                               rng=np.random.default_rng(7), ctx=ctx, window_size=5, keyframe_d=1)
+    for i in range(1, warmup + 1):
+        pipe.process_frame(d_frames[i], next_image=d_frames[i + 1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warmup + 1, warmup + steps + 1):
+        pipe.process_frame(d_frames[i], next_image=d_frames[i + 1])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"frames_per_s": steps / dt, "tracked_landmarks": int(np.mean(pipe.num_X[-steps:])),
+           "candidates": int(np.mean(pipe.num_C[-steps:])), "ba_runs": pipe.ba_runs,
+           "final_position_error_m": float(np.linalg.norm(pipe.est_trans[-1] - poses[warmup + steps][:3, 3]))}
+    pipe.close()
+    return out
 
 
 def bench_ransac(vo, torch, ctx, n, h, steps, warmup, seed):
@@ -239,7 +290,11 @@ def bench_klt(vo, torch, ctx, d_frames, xy, n_points, reps=20):
     iters = it.value
     flop = 11907.0 * passes + 5292.0 * iters          # 441 px x (27 set-up + 12 per iteration) fp32 flop
     lds = 441.0 * 4 * 4 * iters                       # 4 bilinear taps x 4 B per window pixel per iteration
+    # compulsory HBM bytes of a launch: both pyramids once (float, 4/3 of the image each) + 40 B per track
+    rows, cols = d_frames[0].shape
+    hbm = 2 * 4.0 * rows * cols * sum(0.25 ** l for l in range(5)) + 40.0 * n_points
     return dict(kernel="klt_track_kernel<21>", tracks=n_points, kernel_ms=ms, mean_iterations_per_pass=iters / max(passes, 1),
+                algorithmic_flop=flop, algorithmic_lds_bytes=lds, compulsory_hbm_bytes=hbm,
                 valid_fraction=float(d_valid.float().mean().item()), achieved_tflops=flop / (ms * 1e-3) / 1e12,
                 peak_tflops=FP32_VALU_PEAK_TFLOPS, frac_valu=flop / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
                 achieved_lds_tbs=lds / (ms * 1e-3) / 1e12, peak_lds_tbs=LDS_PEAK_TBS,
@@ -342,6 +397,7 @@ def cpu_baseline_frames(vo, scene, frames, poses, X0, xy0, budget_s=12.0):
     from oracle import vo_oracle
     vo_oracle.build()
     hp = vo.default_hyper_paras("kitti", is_BA=False)
+    hp.r_discard_redundant = KITTI_EXCLUSION_RADIUS
     pipe = po.OraclePipeline(vo.synth.K_KITTI, frames[0], X0, xy0, poses[0], hp, 3, 2, np.random.default_rng(0),
                              vo.draw_triples, vo.draw_octets)
     pipe.process_frame(frames[1])  # first frame builds up the candidate set; not timed
@@ -396,53 +452,89 @@ def main():
 
         def gather(pipe, seconds):
             et, er = pipe.trajectory()
-            rec = vo.batch.pack_record(rank, seconds, et, er, pipe.num_X, pipe.num_C, pipe.num_new)
+            rec = vo.batch.pack_record(rank, seconds, et, er, pipe.num_X, pipe.num_C, pipe.num_new,
+                                       timing=dict(toc_ct=seconds, frame_ct=len(pipe.num_X) - 1,
+                                                   fps_ct=(len(pipe.num_X) - 1) / seconds))
             return vo.batch.gather_records([rec], world, device=coll_device if (world > 1 and backend == "nccl") else None)
 
         n_frames = max(args.warmup + args.steps + 2, 8)   # (the priming run below needs 8)
-        # with the CPU baseline leg the sequence is longer, so that its sample is about 10 s of CPU work
-        n_seq = n_frames if (args.no_cpu_baseline or world > 1) else max(n_frames, 200)
-        scene, frames_all, poses_all = make_sequence(vo, n_seq)
+        # with the CPU baseline leg the sequence is longer, so that its sample is about 10 s of CPU work and the
+        # long timed run below has 200 frames
+        n_seq = n_frames if (args.no_cpu_baseline or world > 1) else max(n_frames, 212)
+        # work item of this rank (the batch grid main_eval.m:22-23 shards): its own rendered sequence and seed
+        item = vo.batch.shard(list(range(world)), rank, world)[0]
+        scene, frames_all, poses_all = make_sequence(vo, n_seq, item)
         frames, poses = frames_all[:n_frames], poses_all[:n_frames]
         # set-up, not steps: a throw-away run of a few frames loads every kernel's code object and maps the
         # staging buffers, so that the W warm-up steps below start from a process that has run the path once
         bench_frames(vo, torch, ctx, scene, frames, poses, 4, 2, 99, lambda: torch.cuda.synchronize(),
                      lambda pipe, seconds: [])
-        elapsed, info = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
+        elapsed, info = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + item, barrier,
                                      gather)
-        elapsed_h2d, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
-                                      gather, resident=False)
-        elapsed_plain, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
-                                        gather, ahead=False)
-        stress = None
-        if world == 1:   # the whole loop at the stress sizes (the kernel-level stress figures follow below)
-            el_s, info_s = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + rank, barrier,
-                                        gather, stress_hypotheses=args.hypotheses)
-            stress = {"workload": "up to 8192 of the strongest corners of the first frame (Harris MinQuality %g) start as landmarks, "
-                                  "exclusion radius 5 px, %d P3P hypotheses solved and scored per frame"
-                                  % (STRESS_MIN_QUALITY, args.hypotheses),
-                      "frames_per_s": args.steps / el_s, "tracked_landmarks": info_s["n_landmarks"],
-                      "candidates": info_s["n_candidates"], "final_position_error_m": info_s["final_position_error_m"]}
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         fps = world * args.steps / elapsed
+        extra = {}
+        if world == 1:
+            nosync = lambda: torch.cuda.synchronize()   # noqa: E731
+            nogather = lambda pipe, seconds: []          # noqa: E731
+            el, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync, nogather,
+                                 resident=False)
+            extra["frames_per_s_pcie_inclusive"] = args.steps / el
+            el, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync, nogather,
+                                 ahead=False)
+            extra["frames_per_s_without_lookahead"] = args.steps / el
+            if len(frames_all) >= 212:   # a longer timed region (clocks settled), same workload
+                el, inf = bench_frames(vo, torch, ctx, scene, frames_all, poses_all, 200, 10, 100, nosync, nogather)
+                extra["frames_per_s_200_frames"] = {"value": 200 / el, "tracked_landmarks": inf["n_landmarks"],
+                                                    "candidates": inf["n_candidates"]}
+            # main_BA.m's configuration on the same KITTI-shape sequence: bundle adjustment over a window of 5
+            # keyframes, every 2nd frame a keyframe (runBA and the normal-frame re-refinements on the GPU, the
+            # window bookkeeping on the host, one copy of the landmarks each way)
+            el, inf = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync, nogather,
+                                   bundle_adjust=True)
+            extra["frames_per_s_with_bundle_adjustment"] = {
+                "value": args.steps / el, "ba_runs_in_timed_and_warmup_frames": inf["ba_runs"],
+                "tracked_landmarks": inf["n_landmarks"], "candidates": inf["n_candidates"],
+                "reference_published_fps": MATLAB_PARKING_BA_FPS,
+                "note": "KITTI shape; the reference's only published figure with bundle adjustment is parking, MATLAB"}
+            # the reference's parking configuration (BASELINE config 1 and, with bundle adjustment, config 3)
+            extra["parking_640x480"] = {
+                "no_ba": dict(bench_parking(vo, torch, ctx, args.steps, args.warmup, False),
+                              reference_published_fps=MATLAB_PARKING_FPS),
+                "with_ba_window5_every_2nd_frame": dict(bench_parking(vo, torch, ctx, args.steps, args.warmup, True),
+                                                        reference_published_fps=MATLAB_PARKING_BA_FPS)}
+            # the whole loop at the stress sizes (the kernel-level stress figures follow below)
+            el_s, info_s = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync,
+                                        nogather, stress_hypotheses=args.hypotheses)
+            extra["frame_loop_stress_config"] = {
+                "workload": "every corner of the frames (Harris MinQuality %g: about 8 250 per frame, all of the first "
+                            "frame's start as landmarks), exclusion radius %g px, %d P3P hypotheses solved and scored "
+                            "per frame; the rendered frames hold no more corners than that, so 8 192 + 8 192 distinct "
+                            "tracks do not exist in them (the tracker and RANSAC kernels alone are measured at 8 192 below)"
+                            % (STRESS_MIN_QUALITY, STRESS_EXCLUSION_RADIUS, args.hypotheses),
+                "frames_per_s": args.steps / el_s, "tracked_landmarks": info_s["n_landmarks"],
+                "candidates": info_s["n_candidates"], "final_position_error_m": info_s["final_position_error_m"]}
+            extra["frames_per_s_4_sequences_at_once"] = bench_frames_concurrent(vo, torch, scene, frames, poses, args.steps,
+                                                                                args.warmup, 4)
 
-        d2 = [torch.from_numpy(f).to(torch.device("cuda", local_rank)) for f in frames[:2]]
-        _, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
-        klt_frame = bench_klt(vo, torch, ctx, d2, xy0, len(xy0))
-        klt_stress = bench_klt(vo, torch, ctx, d2, xy0, 8192)
-        image_kernels = bench_image_kernels(vo, torch, ctx, d2[0])
-        fps_4seq = bench_frames_concurrent(vo, torch, scene, frames, poses, args.steps, args.warmup, 4) if world == 1 else None
-        ba_runs = bench_ba(vo, ctx, with_cpu=not args.no_cpu_baseline and world == 1) if rank == 0 else None
-
+        klt_frame = klt_stress = image_kernels = ba_runs = None
         n, h = args.points, args.hypotheses
-        hyps_per_s, score_ms = bench_ransac(vo, torch, ctx, n, h, max(args.steps, 20), args.warmup, 100 + rank)
-        achieved = 116.0 * n * h / (score_ms * 1e-3) / 1e12
+        if rank == 0:
+            d2 = [torch.from_numpy(f).to(torch.device("cuda", local_rank)) for f in frames[:2]]
+            _, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
+            klt_frame = bench_klt(vo, torch, ctx, d2, xy0, info["n_landmarks"] + info["n_candidates"])
+            klt_stress = bench_klt(vo, torch, ctx, d2, xy0, 8192)
+            image_kernels = bench_image_kernels(vo, torch, ctx, d2[0])
+            ba_runs = bench_ba(vo, ctx, with_cpu=not args.no_cpu_baseline and world == 1)
+            hyps_per_s, score_ms = bench_ransac(vo, torch, ctx, n, h, max(args.steps, 20), args.warmup, 100)
+            achieved = 116.0 * n * h / (score_ms * 1e-3) / 1e12
 
     if rank == 0:
         traffic = traffic_from_profile("p3p_score_kernel<16, 1024>") if (n, h) == (8192, 4096) else None
+        klt_traffic = traffic_from_profile("klt_track_kernel<21>")
         out = {
             "metric": METRIC,
             "value": fps,
@@ -461,39 +553,54 @@ def main():
                                    "F-matrix filter, triangulation, candidate filter, no BA; one step = one frame; "
                                    "the sequence is stored, so each call also hands over the following frame, whose pyramid "
                                    "and corners are prepared beside the current localisation (results identical); "
-                                   "per rank one independent replica (batch mode)",
+                                   "every rank runs its own work item of the batch grid (own rendered sequence, own "
+                                   "random seed), records gathered with one all_gather inside the timed region",
                        "tracked_landmarks": info["n_landmarks"], "candidates": info["n_candidates"],
+                       "first_frame_thinning_cell_px": KITTI_THIN_CELL, "candidate_exclusion_radius_px": KITTI_EXCLUSION_RADIUS,
                        "final_position_error_m": info["final_position_error_m"],
                        "host_enqueue_us_per_frame": info["host_enqueue_us_per_frame"],
                        "host_wait_us_per_frame": info["host_wait_us_per_frame"],
                        "baseline_note": "vs_baseline divides by the reference's published 3.817 frames/s "
                                         "(MATLAB, Ryzen 7 5800H, real KITTI 05, Harris)"},
-            "frames_per_s_pcie_inclusive": args.steps / elapsed_h2d,
-            "frames_per_s_without_lookahead": args.steps / elapsed_plain,
-            "frames_per_s_4_sequences_at_once": fps_4seq,   # batch evaluation: independent sequences share the GPU
-            "frame_loop_stress_config": stress,
+            # The kernel the headline is bound by: the tracker (one launch per frame, landmarks + candidates).
+            # One wavefront per track; its hot loop reads the search region from LDS and runs fp32 FMAs, so the
+            # launch is priced against the LDS bandwidth (primary) and the fp32 vector peak; it is not HBM-bound
+            # (both pyramids, 5 MB, stay in L2 / Infinity Cache).
+            "roofline": {"kernel": "klt_track_kernel<21> (frame configuration: the tracks of one frame)",
+                         "bound": "lds",
+                         "bound_note": "neither hbm nor mfma: the binding resource is LDS read bandwidth / fp32 VALU issue, and at "
+                                       "these sizes the latency of the slowest wavefront (a lost track runs all 200 iterations); "
+                                       "achieved = algorithmic LDS bytes (441 px x 4 taps x 4 B per iteration) / kernel time",
+                         "achieved": klt_frame["achieved_lds_tbs"] * 1e3, "peak": LDS_PEAK_TBS * 1e3, "unit": "GB/s",
+                         "frac": klt_frame["frac_lds"],
+                         "frac_fp32_valu": klt_frame["frac_valu"], "achieved_tflops": klt_frame["achieved_tflops"],
+                         "peak_tflops": FP32_VALU_PEAK_TFLOPS,
+                         "kernel_ms": klt_frame["kernel_ms"], "tracks": klt_frame["tracks"],
+                         "mean_iterations_per_pass": klt_frame["mean_iterations_per_pass"],
+                         "traffic": klt_traffic["bytes"] if klt_traffic else None,
+                         "traffic_source": klt_traffic["source"] if klt_traffic else None,
+                         "traffic_note": "FETCH_SIZE + WRITE_SIZE per launch as rocprofv3 reports them (KB x 1024), averaged over the "
+                                         "launches of the profiled bench run (frame and stress legs); the kernel's loads are 4 B per lane, "
+                                         "for which the counter is not calibrated on gfx950",
+                         "compulsory_hbm_bytes": klt_frame["compulsory_hbm_bytes"],
+                         "stress_config_8192_tracks": klt_stress},
             "ransac_hypotheses_per_s": hyps_per_s,
             "ransac_config": {"workload": "RANSAC stress: %d P3P hypotheses x %d correspondences per step" % (h, n)},
-            "roofline": {"bound": "mfma",
-                         "bound_note": "compute-bound, priced against the dense fp64 matrix peak, 78.6 TFLOP/s, which on gfx950 "
-                                       "is also the fp64 vector peak; the kernel's arithmetic is fp64 FMA on the vector ALUs "
-                                       "(a 3x4 projection per point is no matrix-core shape, and running both pipes would add "
-                                       "nothing at equal peaks); 72 TFLOP/s is what a register-only FMA loop sustains "
-                                       "(tools/micro/fp64_peak.hip)",
-                         "kernel": "p3p_score_kernel (RANSAC stress)", "achieved": achieved,
-                         "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS,
-                         "traffic": traffic["bytes"] if traffic else None,
-                         "traffic_source": traffic["source"] if traffic else None,
-                         # 40 B per correspondence once, 4 x 12 doubles of K[R|t] in and 4 counts out per hypothesis
-                         "algorithmic_bytes": 40.0 * n + (384.0 + 16.0) * h,
-                         "kernel_ms": score_ms},
-            "roofline_klt": {"note": "dominant kernel of the frame loop; one wavefront per track, so at ~2k tracks "
-                                     "the launch is bound by the dependent-iteration latency of the slowest track, "
-                                     "not by LDS or VALU throughput; the 8192-track launch is the stress configuration",
-                             "frame_config": klt_frame, "stress_config": klt_stress},
+            "roofline_ransac": {"bound": "valu_fp64",
+                                "bound_note": "compute-bound on the fp64 vector ALUs (no MFMA is issued: a 3x4 projection per "
+                                              "point is no matrix-core shape); 78.6 TFLOP/s is the fp64 vector peak, 72 TFLOP/s "
+                                              "what a register-only FMA loop sustains (tools/micro/fp64_peak.hip)",
+                                "kernel": "p3p_score_kernel<16, 1024> (RANSAC stress)", "achieved": achieved,
+                                "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS,
+                                "traffic": traffic["bytes"] if traffic else None,
+                                "traffic_source": traffic["source"] if traffic else None,
+                                # 40 B per correspondence once, 4 x 12 doubles of K[R|t] in and 4 counts out per hypothesis
+                                "algorithmic_bytes": 40.0 * n + (384.0 + 16.0) * h,
+                                "kernel_ms": score_ms},
             "roofline_image_kernels": image_kernels,
             "bundle_adjustment": ba_runs,
         }
+        out.update(extra)
         if not args.no_cpu_baseline and world == 1:
             X0, xy0 = init_points(vo, ctx, scene, frames_all[0], poses_all[0])
             v, done, dt = cpu_baseline_frames(vo, scene, frames_all, poses_all, X0, xy0)

@@ -51,7 +51,12 @@ def test_record_roundtrip_and_single_process(vo):
     r = b.unpack_record(b.pack_record(3, 2.0, et, er, range(7), range(7), range(7)))
     np.testing.assert_array_equal(r["est_trans"], et)
     np.testing.assert_array_equal(r["est_rot"], er)
-    assert r["fps"] == 3.0 and r["item"] == 3
+    assert r["fps"] == 3.0 and r["item"] == 3 and r["errs"].shape == (3, 0) and r["fps_ct"] == 0.0
+    errs = rng.normal(size=(3, 4))
+    r = b.unpack_record(b.pack_record(3, 2.0, et, er, range(7), range(7), range(7), errs=errs,
+                                      timing=dict(fps_ct=12.5, toc_ct=0.5, frame_ct=6, total_time=0.75)))
+    np.testing.assert_array_equal(r["errs"], errs)
+    assert (r["fps_ct"], r["toc_ct"], r["frame_ct"], r["total_time"], r["toc_param"]) == (12.5, 0.5, 6.0, 0.75, 0.0)
     recs = b.run_batch(["a", "b"], lambda i, it: b.pack_record(i, 1.0, et, er, range(7), range(7), range(7)))
     assert [x["item"] for x in recs] == [0, 1]
     assert b.shard(list(range(7)), 1, 3) == [1, 4]

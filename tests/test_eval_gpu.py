@@ -64,3 +64,41 @@ def test_run_sequence_writes_the_result_file(vo, ctx, tmp_path):
     np.testing.assert_array_equal(back["S"]["est_trans"], out["S"].est_trans)
     np.testing.assert_array_equal(back["errs"], out["errs"])
     assert back["fps_ct"] == pytest.approx(out["fps_ct"]) and back["frame_ct"] == 11.0
+
+
+def test_main_eval_grid_is_independent_of_world_size(vo, ctx, tmp_path):
+    """main_eval.m:22-23 over two sequences x two feature variants, the unit that is sharded over GPUs: the
+    grid run by one process, and then the shares of rank 0 and rank 1 of a two-process job run in turn on
+    this GPU.  Every run's record must be bit-identical (its random numbers depend on the item only), and
+    every run leaves its own '<experiment>_res.mat' with the reference's key set."""
+    import glob
+    K = np.array([[400.0, 0, 320], [0, 400.0, 120], [0, 0, 1]])
+    sequences = []
+    for k in range(2):
+        scene = vo.synth.CorridorScene(seed=100 + k, K=K, width=640, height=240)
+        poses = vo.synth.corridor_trajectory(12, step=0.5)
+        sequences.append(dict(name="corridor%d" % k, images=[scene.render(T) for T in poses], K=K,
+                              ground_truth=np.array([[T[0, 3], T[2, 3]] for T in poses]),
+                              hyper_paras=vo.default_hyper_paras("kitti")))
+    feats = ("Harris", "MinEigen")
+    whole = vo.main_eval(sequences, feats=feats, repetition=1, save_dir=str(tmp_path / "w1"), seed=9, ctx=ctx)
+    assert len(whole) == 4 and all(r is not None for r in whole)
+    parts = [vo.main_eval(sequences, feats=feats, repetition=1, save_dir=str(tmp_path / "w2"), seed=9, ctx=ctx, rank=r,
+                          world=2) for r in range(2)]
+    for k in range(4):
+        assert (parts[0][k] is None) != (parts[1][k] is None)            # exactly one rank ran item k
+        assert (parts[k % 2][k] is not None)                             # round-robin
+        a, b = whole[k], parts[k % 2][k]
+        for key in ("est_trans", "est_rot", "num_X", "num_C", "num_new", "errs"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg="%d %s" % (k, key))
+        assert a["frames"] == 10 and a["frame_ct"] == 9 and a["frame_init"] == 3
+        assert a["fps_ct"] > 0 and a["toc_ct"] > 0 and a["errs"].shape[0] == 3 and a["errs"].shape[1] >= 1
+        assert (a["sequence"], a["feat"]) == ("corridor%d" % (k // 2), feats[k % 2])
+    # the two feature variants are different runs
+    assert not np.array_equal(whole[0]["num_C"], whole[1]["num_C"])
+    for d in ("w1", "w2"):
+        files = sorted(glob.glob(str(tmp_path / d / "*_res.mat")))
+        assert len(files) == 4
+        back = vo.load_results(files[0])
+        assert {"errs", "S", "total_time", "frame_init", "frame_ct", "toc_param", "toc_bootstrap", "toc_ct",
+                "fps_ct"} <= set(back)

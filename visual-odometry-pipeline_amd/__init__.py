@@ -8,8 +8,8 @@ from . import batch, synth
 from .ba import T_refinement, baError, runBA
 from .bootstrap import (bootstrap, compProjMat, matching_init, pose_estimation_init, relativeCameraPose,
                         triangulation_init)
-from .evaluation import (alignError, alignEstimateToGroundTruth, experiment_name, load_results, quantitative_eval,
-                         run_sequence, save_results)
+from .evaluation import (alignError, alignEstimateToGroundTruth, experiment_name, load_results, main_eval,
+                         quantitative_eval, run_sequence, save_results)
 from .fmatrix import draw_octets, estimateFundamentalMatrix, octets_from_uniforms
 from .frame_pipeline import VOPipelineDevice
 from .keypoints import cornerPoints, genKeypoints

@@ -10,7 +10,13 @@ the arrays the evaluation notebook reads from the saved runs.
 import numpy as np
 
 T_MAX = 600           # frames a record can hold (the reference's longest run has 598)
-RECORD_DOUBLES = 4 + 15 * T_MAX   # [item id, frames, seconds, fps] + est_trans 3xT + est_rot 9xT + num_X, num_C, num_new
+HEADER = 16           # [item id, frames, seconds, fps, errs columns, total_time, frame_init, frame_ct, toc_param,
+                      #  toc_bootstrap, toc_ct, fps_ct, 4 spare] -- the scalars main_eval.m:491-494 saves
+ERRS = 18             # errs 3 x 6 (quantitative_eval.m:27), column-major, unused columns NaN
+RECORD_DOUBLES = HEADER + ERRS + 15 * T_MAX   # ... + est_trans 3xT + est_rot 9xT + num_X, num_C, num_new
+
+
+TIMING_KEYS = ("total_time", "frame_init", "frame_ct", "toc_param", "toc_bootstrap", "toc_ct", "fps_ct")
 
 
 def shard(items, rank, world):
@@ -18,15 +24,24 @@ def shard(items, rank, world):
     return [it for k, it in enumerate(items) if k % world == rank]
 
 
-def pack_record(item_id, seconds, est_trans, est_rot, num_X, num_C, num_new):
-    """One run -> a fixed-size float64 record."""
+def pack_record(item_id, seconds, est_trans, est_rot, num_X, num_C, num_new, errs=None, timing=None):
+    """One run -> a fixed-size float64 record.  errs: 3 x k (k <= 6) or None; timing: dict with any of
+    total_time, frame_init, frame_ct, toc_param, toc_bootstrap, toc_ct, fps_ct."""
     T = est_trans.shape[1]
     if T > T_MAX:
         raise ValueError("run has %d frames, records hold %d" % (T, T_MAX))
     rec = np.zeros(RECORD_DOUBLES)
     rec[0], rec[1], rec[2] = item_id, T, seconds
     rec[3] = (T - 1) / seconds if seconds > 0 else 0.0
-    body = rec[4:].reshape(15, T_MAX)
+    e = rec[HEADER:HEADER + ERRS].reshape(6, 3)
+    e[:] = np.nan
+    if errs is not None:
+        errs = np.asarray(errs, dtype=np.float64).reshape(3, -1)
+        rec[4] = errs.shape[1]
+        e[:errs.shape[1]] = errs.T
+    for k, name in enumerate(TIMING_KEYS):
+        rec[5 + k] = float((timing or {}).get(name, 0.0))
+    body = rec[HEADER + ERRS:].reshape(15, T_MAX)
     body[0:3, :T] = est_trans
     body[3:12, :T] = est_rot
     for row, arr in ((12, num_X), (13, num_C), (14, num_new)):
@@ -37,10 +52,13 @@ def pack_record(item_id, seconds, est_trans, est_rot, num_X, num_C, num_new):
 
 def unpack_record(rec):
     T = int(rec[1])
-    body = rec[4:].reshape(15, T_MAX)
-    return dict(item=int(rec[0]), frames=T, seconds=float(rec[2]), fps=float(rec[3]), est_trans=body[0:3, :T].copy(),
-                est_rot=body[3:12, :T].copy(), num_X=body[12, :T].copy(), num_C=body[13, :T].copy(),
-                num_new=body[14, :T].copy())
+    body = rec[HEADER + ERRS:].reshape(15, T_MAX)
+    out = dict(item=int(rec[0]), frames=T, seconds=float(rec[2]), fps=float(rec[3]), est_trans=body[0:3, :T].copy(),
+               est_rot=body[3:12, :T].copy(), num_X=body[12, :T].copy(), num_C=body[13, :T].copy(),
+               num_new=body[14, :T].copy(), errs=rec[HEADER:HEADER + ERRS].reshape(6, 3)[:int(rec[4])].T.copy())
+    for k, name in enumerate(TIMING_KEYS):
+        out[name] = float(rec[5 + k])
+    return out
 
 
 def gather_records(local_records, n_items, device=None):
@@ -72,10 +90,17 @@ def gather_records(local_records, n_items, device=None):
     return out
 
 
-def run_batch(items, runner, device=None):
+def run_batch(items, runner, device=None, rank=None, world=None):
     """Runs `runner(item_id, item) -> record` for this rank's share of `items` and gathers all
-    records on every rank.  `runner` builds and drives one full pipeline run."""
+    records on every rank.  `runner` builds and drives one full pipeline run.
+    rank / world given explicitly (without a process group): only that share is run and returned, the
+    other entries of the result are None -- one GPU can then rehearse every rank's share in turn."""
     import torch.distributed as dist
+    if rank is not None:
+        out = [None] * len(items)
+        for item_id, item in shard(list(enumerate(items)), rank, world):
+            out[item_id] = unpack_record(runner(item_id, item))
+        return out
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
     mine = shard(list(enumerate(items)), rank, world)
     local = [runner(item_id, item) for item_id, item in mine]

@@ -7,6 +7,8 @@
   run_sequence                  the stand-alone run of main_demo.m:249-476 / one item of
                                 main_eval.m:22-23: bootstrap, continuous operation, timing,
                                 evaluation, result file
+  main_eval                     the batch evaluation main_eval.m:20-23,483-494: the grid of independent
+                                runs, sharded over one process per GPU, one result file per run
 
 The alignment's non-linear least squares runs in libvohip.so on the GPU.  The result file is a
 MAT v5 file with the key set the reference saves, which is what its evaluation notebook reads
@@ -127,12 +129,16 @@ def load_results(path):
 
 
 def run_sequence(images, K, hyper_paras, ground_truth=None, bootstrap_frames=(0, 2), dataset="synthetic",
-                 save_dir=None, rng=None, ctx=None, window_size=3, keyframe_d=2, now=None):
+                 save_dir=None, rng=None, ctx=None, window_size=3, keyframe_d=2, now=None, device_loop=True):
     """One full run as main_demo.m:249-476 does it: bootstrap on images[b1..b2], continuous
     operation on the remaining images, timing, evaluation against ground_truth (N-by-2 (x, z) table,
     optional) and, when save_dir is given, the '<experiment>_res.mat' file.
-    Returns a dict with the saved variables plus 'S' (the final state) and 'path'."""
+    Returns a dict with the saved variables plus 'S' (the final state) and 'path'.
+    device_loop: the loop with its state resident on the GPU (one library call per frame, the following
+    image of the stored sequence handed over ahead); False: the stage-by-stage loop, one call per
+    reference function."""
     from .bootstrap import bootstrap
+    from .frame_pipeline import VOPipelineDevice
     from .pipeline import VOPipeline
     ctx = ctx or _lib.default_context()
     rng = rng or np.random.default_rng()
@@ -146,11 +152,17 @@ def run_sequence(images, K, hyper_paras, ground_truth=None, bootstrap_frames=(0,
     p_W_landmarks, keypoints, T_init_WC = bootstrap(img0, img_seqs, K, hyper_paras, rng=rng, ctx=ctx)   # :252-264
     toc_bootstrap = time.perf_counter() - t_boot                            # :266
     t_ct = time.perf_counter()                                              # :270
-    pipe = VOPipeline(K, img_seqs[-1], p_W_landmarks, keypoints, T_init_WC, hyper_paras=hyper_paras,
-                      window_size=window_size, keyframe_d=keyframe_d, rng=rng, ctx=ctx)
     frame_range = range(b2 + 1, len(images))                                # :351
-    for i in frame_range:
-        pipe.process_frame(images[i])
+    if device_loop:
+        pipe = VOPipelineDevice(K, img_seqs[-1], p_W_landmarks, keypoints, T_init_WC, hyper_paras=hyper_paras,
+                                window_size=window_size, keyframe_d=keyframe_d, rng=rng, ctx=ctx)
+        for i in frame_range:
+            pipe.process_frame(images[i], next_image=images[i + 1] if i + 1 < len(images) else None)
+    else:
+        pipe = VOPipeline(K, img_seqs[-1], p_W_landmarks, keypoints, T_init_WC, hyper_paras=hyper_paras,
+                          window_size=window_size, keyframe_d=keyframe_d, rng=rng, ctx=ctx)
+        for i in frame_range:
+            pipe.process_frame(images[i])
     toc_ct = time.perf_counter() - t_ct                                     # :446
     S = pipe.S
     pipe.close()
@@ -169,3 +181,56 @@ def run_sequence(images, K, hyper_paras, ground_truth=None, bootstrap_frames=(0,
         out["path"] = save_results(os.path.join(save_dir, experiment_name(dataset, hyper_paras, now)), errs, S,
                                    total_time, frame_init, frame_ct, toc_param, toc_bootstrap, toc_ct, fps_ct)
     return out
+
+
+EVAL_FEATURE_OPTIONS = {"Harris": ["MinQuality", 2e-4],      # main_eval.m:168-169
+                        "MinEigen": ["MinQuality", 1e-2]}    # genKeypoints.m:18 (no entry in main_eval's switch)
+
+
+def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0, device=None, rank=None, world=None,
+              ctx=None, now=None):
+    """The batch evaluation of main_eval.m: for every sequence, every feature variant (main_eval.m:19,22,
+    165-174) and every repetition (:20,23) one full, independent run (run_sequence: bootstrap, loop,
+    timing, quantitative_eval, '<experiment>_res.mat' as :483-494 saves it).
+
+    sequences: list of dicts with keys name, images, K, and optionally ground_truth (N x 2 (x, z) table),
+    bootstrap_frames, hyper_paras (defaults: default_hyper_paras(name)), window_size, keyframe_d.
+    The runs are the work items of batch.run_batch: dealt round-robin to one process per GPU
+    (torch.distributed), no exchange while they run, one all_gather of the result records at the end, so
+    every rank returns the full list of records (item order: sequence-major, then feature, then
+    repetition).  rank / world without a process group: only that share is run (see batch.run_batch).
+
+    MATLAB's repetitions differ only through the position of its never-seeded global RNG stream
+    (main_eval.m:20-23); here run k draws from numpy.random.default_rng([seed, k]), so a run's result
+    does not depend on how many processes share the grid.  The reference names a result file after the
+    wall-clock second it is saved in; runs here take milliseconds, so run k is stamped `now` + k seconds
+    to keep the names unique and parseable by the evaluation notebook."""
+    import copy
+    import datetime
+    from . import batch
+    from .pipeline import default_hyper_paras
+    ctx = ctx or _lib.default_context()
+    now = now or datetime.datetime.now()
+    items = [(si, feat, rep) for si in range(len(sequences)) for feat in feats for rep in range(repetition)]
+
+    def runner(item_id, item):
+        si, feat, rep = item
+        seq = sequences[si]
+        hp = copy.copy(seq.get("hyper_paras") or default_hyper_paras(seq["name"]))
+        hp.feature_extract = feat                                           # main_eval.m:162-163
+        hp.feature_extract_options = list(EVAL_FEATURE_OPTIONS[feat])       # :165-174
+        t0 = time.perf_counter()
+        out = run_sequence(seq["images"], seq["K"], hp, ground_truth=seq.get("ground_truth"),
+                           bootstrap_frames=seq.get("bootstrap_frames", (0, 2)), dataset=seq["name"], save_dir=save_dir,
+                           rng=np.random.default_rng([seed, item_id]), ctx=ctx,
+                           window_size=seq.get("window_size", 3), keyframe_d=seq.get("keyframe_d", 2),
+                           now=now + datetime.timedelta(seconds=item_id))
+        S = out["S"]
+        return batch.pack_record(item_id, time.perf_counter() - t0, S.est_trans, S.est_rot, S.num_X, S.num_C,
+                                 S.num_new, errs=out["errs"], timing=out)
+
+    records = batch.run_batch(items, runner, device=device, rank=rank, world=world)
+    for (si, feat, rep), r in zip(items, records):
+        if r is not None:
+            r.update(sequence=sequences[si]["name"], feat=feat, repetition=rep)
+    return records

@@ -6,12 +6,13 @@ T_W_C = [reshape(S.est_rot(:, end), [3, 3]), S.est_trans(:, end); 0 0 0 1];
 [pts, valid] = KLT_tracker_C(image);
 matched = fliplr(pts(valid, :));
 p1 = S.C(:, valid)';
-s = rng;                                 % the toolbox call would draw its trials from this stream
+% The toolbox call this replaces (update_landmarks.m:13-14) draws its trials from the global stream; how
+% much of the stream it consumes is not documented, so the stream position after this function is a
+% convention of this drop-in (500 randperm calls), not the toolbox's.
 samples = zeros(8, 500);
 for t = 1:500
     samples(:, t) = randperm(size(p1, 1), 8)';
 end
-rng(s); rand(1);                         % leave the stream advanced, as any RANSAC call would
 [~, inl] = vohip_mex('fmatrix_ransac', double(p1), double(matched), samples, 5e-2, 99);
 matched = matched(inl, :);
 S.F = S.F(:, valid); S.F = S.F(:, inl);

@@ -9,12 +9,14 @@
 // destroyed by mexAtExit.  Every array crosses the boundary exactly as MATLAB stores it
 // (column-major), which is the layout the C ABI is specified in -- no transposes.
 // MATLAB calls MEX functions on its interpreter thread only; the context is never shared.
-// Errors: the C ABI returns status codes; they are turned into mexErrMsgIdAndTxt here, after all
-// C++ objects of the call have been released (mexErrMsgIdAndTxt long-jumps).
+// Errors: the C ABI returns status codes; they are turned into mexErrMsgIdAndTxt here.  That call
+// long-jumps out of the gateway, so no object with a destructor lives in this file: temporaries are
+// mxCalloc blocks, which MATLAB releases itself when a MEX function ends with an error.
+// tests/test_mex_gateway.py compiles this file against a declaration-only mex.h, so a signature that
+// drifts away from vohip.h breaks the build.
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
-#include <string>
-#include <vector>
 
 #include "mex.h"
 #include "vohip.h"
@@ -57,13 +59,31 @@ static int numel(const mxArray *a) { return (int)mxGetNumberOfElements(a); }
 static int cols(const mxArray *a) { return (int)mxGetN(a); }
 static int rows(const mxArray *a) { return (int)mxGetM(a); }
 
+template <class T>
+static T *scratch(size_t n)   // zeroed, owned by MATLAB: freed by mxFree or, after an error, by MATLAB
+{
+    return static_cast<T *>(mxCalloc(n ? n : 1, sizeof(T)));
+}
+
 // 0-based int32 copy of a 1-based MATLAB index matrix
-static std::vector<int32_t> idx0(const mxArray *a)
+static int32_t *idx0(const mxArray *a)
 {
     const double *p = dbl(a, "index matrix");
-    std::vector<int32_t> v((size_t)numel(a));
-    for (size_t i = 0; i < v.size(); ++i) v[i] = (int32_t)p[i] - 1;
+    const size_t n = (size_t)numel(a);
+    int32_t *v = scratch<int32_t>(n);
+    for (size_t i = 0; i < n; ++i) v[i] = (int32_t)p[i] - 1;
     return v;
+}
+
+// n x 2 MATLAB matrix ([x...; y...] in memory) -> 2 x n, the layout the library takes points in
+static double *interleave2(const double *p, int n)
+{
+    double *a = scratch<double>((size_t)2 * n);
+    for (int i = 0; i < n; ++i) {
+        a[2 * i] = p[i];
+        a[2 * i + 1] = p[n + i];
+    }
+    return a;
 }
 
 // [T_W_C, info, status] of the 'frame_step' / 'frame_retry' opcodes
@@ -89,54 +109,58 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("vohip:usage", "vohip_mex('opcode', ...)");
     char opbuf[64];
     mxGetString(prhs[0], opbuf, sizeof(opbuf));
-    const std::string op(opbuf);
     const mxArray **in = prhs + 1;
     vohip_ctx *c = ctx();
+    auto is = [&](const char *name) { return std::strcmp(opbuf, name) == 0; };
 
-    if (op == "ransac_p3p") {
-        // [R, t, mask, max_hist, iter_hist, n_iter, found] = vohip_mex('ransac_p3p', kp_rc 2xN, X 3xN, K, samples 3xH (1-based))
+    if (is("ransac_p3p")) {
+        // [R, t, mask, max_hist, iter_hist, n_iter, status] = vohip_mex('ransac_p3p', kp_rc 2xN, X 3xN, K, samples 3xH (1-based))
+        // status: 0 = a model, VOHIP_NO_MODEL (3) = none reached 30 inliers, VOHIP_SAMPLES_EXHAUSTED (4) = the
+        // adaptive rule wants more than the H triples supplied (call again with more, the first H unchanged)
         const int n = cols(in[0]), h = cols(in[3]);
-        std::vector<int32_t> s = idx0(in[3]);
+        int32_t *s = idx0(in[3]);
         plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
         plhs[1] = mxCreateDoubleMatrix(3, 1, mxREAL);
         mxArray *mask = mxCreateLogicalMatrix(1, n);
-        std::vector<double> mh((size_t)h), ih((size_t)h);
+        double *mh = scratch<double>((size_t)h), *ih = scratch<double>((size_t)h);
         int n_iter = 0;
-        const int st = vohip_ransac_p3p(c, dbl(in[0], "keypoints"), dbl(in[1], "landmarks"), n, dbl(in[2], "K"), s.data(), h,
+        const int st = vohip_ransac_p3p(c, dbl(in[0], "keypoints"), dbl(in[1], "landmarks"), n, dbl(in[2], "K"), s, h,
                                         mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]), (uint8_t *)mxGetLogicals(mask),
-                                        mh.data(), ih.data(), &n_iter);
-        std::vector<int32_t>().swap(s);
-        check(st, true);
+                                        mh, ih, &n_iter);
+        if (st != VOHIP_SAMPLES_EXHAUSTED) check(st, true);
         plhs[2] = mask;
         plhs[3] = mxCreateDoubleMatrix(1, n_iter, mxREAL);
         plhs[4] = mxCreateDoubleMatrix(1, n_iter, mxREAL);
-        std::memcpy(mxGetDoubles(plhs[3]), mh.data(), sizeof(double) * n_iter);
-        std::memcpy(mxGetDoubles(plhs[4]), ih.data(), sizeof(double) * n_iter);
+        std::memcpy(mxGetDoubles(plhs[3]), mh, sizeof(double) * n_iter);
+        std::memcpy(mxGetDoubles(plhs[4]), ih, sizeof(double) * n_iter);
         plhs[5] = mxCreateDoubleScalar(n_iter);
-        plhs[6] = mxCreateLogicalScalar(st == VOHIP_OK);
-    } else if (op == "twist2homog") {
+        plhs[6] = mxCreateDoubleScalar(st);
+        mxFree(s);
+        mxFree(mh);
+        mxFree(ih);
+    } else if (is("twist2homog")) {
         plhs[0] = mxCreateDoubleMatrix(4, 4, mxREAL);
         check(vohip_twist2homog(c, dbl(in[0], "twist"), 1, mxGetDoubles(plhs[0])));
-    } else if (op == "homog2twist") {
+    } else if (is("homog2twist")) {
         plhs[0] = mxCreateDoubleMatrix(6, 1, mxREAL);
         check(vohip_homog2twist(c, dbl(in[0], "H"), 1, mxGetDoubles(plhs[0])));
-    } else if (op == "p3p") {
+    } else if (is("p3p")) {
         // poses = vohip_mex('p3p', worldPoints 3x3, imageVectors 3x3): 3x16 [C1 R1 C2 R2 C3 R3 C4 R4] (p3p.m:41)
         if (numel(in[0]) != 9 || numel(in[1]) != 9) mexErrMsgIdAndTxt("vohip:size", "p3p takes two 3x3 matrices");
         plhs[0] = mxCreateDoubleMatrix(3, 16, mxREAL);
         check(vohip_p3p(c, dbl(in[0], "worldPoints"), dbl(in[1], "imageVectors"), 1, mxGetDoubles(plhs[0])));
-    } else if (op == "triangulate") {
+    } else if (is("triangulate")) {
         // P = vohip_mex('triangulate', p1 3xn, p2 3xn, M1 3x4 or 3x4xn, M2 3x4 or 3x4xn)
         const int n = cols(in[0]);
         plhs[0] = mxCreateDoubleMatrix(4, n, mxREAL);
         check(vohip_triangulate(c, dbl(in[0], "p1"), dbl(in[1], "p2"), dbl(in[2], "M1"), dbl(in[3], "M2"),
                                 numel(in[2]) > 12, numel(in[3]) > 12, n, mxGetDoubles(plhs[0])));
-    } else if (op == "triangulate_refine") {
+    } else if (is("triangulate_refine")) {
         const int n = cols(in[0]);
         plhs[0] = mxCreateDoubleMatrix(4, n, mxREAL);
         check(vohip_triangulate_refine(c, dbl(in[0], "P_init"), dbl(in[1], "p1"), dbl(in[2], "p2"), rows(in[1]),
                                        dbl(in[3], "M1"), dbl(in[4], "M2"), n, mxGetDoubles(plhs[0])));
-    } else if (op == "candidate_filter") {
+    } else if (is("candidate_filter")) {
         // keep = vohip_mex('candidate_filter', Location (n x 2 single), S.C, S.P, r)
         if (!mxIsSingle(in[0])) mexErrMsgIdAndTxt("vohip:type", "Location must be single");
         const int n = rows(in[0]);
@@ -144,109 +168,97 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         check(vohip_candidate_filter(c, mxGetSingles(in[0]), n, dbl(in[1], "S.C"), cols(in[1]), dbl(in[2], "S.P"),
                                      cols(in[2]), mxGetScalar(in[3]), (uint8_t *)mxGetLogicals(keep)));
         plhs[0] = keep;
-    } else if (op == "candidate_triangulate") {
+    } else if (is("candidate_triangulate")) {
         // [status, X, angles] = vohip_mex('candidate_triangulate', cur_rc, first_rc, S.T, T_W_C, K, angle, min_d, max_d, is_BA)
         const int n = cols(in[0]);
-        std::vector<uint8_t> st((size_t)(n ? n : 1));
+        uint8_t *st = scratch<uint8_t>((size_t)n);
         plhs[1] = mxCreateDoubleMatrix(3, n, mxREAL);
         plhs[2] = mxCreateDoubleMatrix(1, n, mxREAL);
         const int rc = vohip_candidate_triangulate(c, dbl(in[0], "cur"), dbl(in[1], "first"), dbl(in[2], "S.T"), n,
                                                    dbl(in[3], "T_W_C"), dbl(in[4], "K"), mxGetScalar(in[5]),
                                                    mxGetScalar(in[6]), mxGetScalar(in[7]), mxGetScalar(in[8]) != 0,
-                                                   st.data(), mxGetDoubles(plhs[1]), mxGetDoubles(plhs[2]));
+                                                   st, mxGetDoubles(plhs[1]), mxGetDoubles(plhs[2]));
+        check(rc);
         plhs[0] = mxCreateDoubleMatrix(1, n, mxREAL);
         for (int i = 0; i < n; ++i) mxGetDoubles(plhs[0])[i] = st[i];
-        std::vector<uint8_t>().swap(st);
-        check(rc);
-    } else if (op == "fmatrix_ransac") {
+        mxFree(st);
+    } else if (is("fmatrix_ransac")) {
         // [F, inliers] = vohip_mex('fmatrix_ransac', p1 (n x 2), p2 (n x 2), samples 8 x T (1-based), threshold, confidence)
         // MATLAB's N-by-2 matrices are [x...; y...] in memory; the library wants 2 x n, so transpose here.
         const int n = rows(in[0]), T = cols(in[2]);
-        std::vector<double> a((size_t)2 * n), b((size_t)2 * n);
-        const double *p1 = dbl(in[0], "p1"), *p2 = dbl(in[1], "p2");
-        for (int i = 0; i < n; ++i) {
-            a[2 * i] = p1[i]; a[2 * i + 1] = p1[n + i];
-            b[2 * i] = p2[i]; b[2 * i + 1] = p2[n + i];
-        }
-        std::vector<int32_t> s = idx0(in[2]);
+        double *a = interleave2(dbl(in[0], "p1"), n), *b = interleave2(dbl(in[1], "p2"), n);
+        int32_t *s = idx0(in[2]);
         mxArray *inl = mxCreateLogicalMatrix(n, 1);
         double F[9];
         int best = 0, trials = 0;
-        const int rc = vohip_fmatrix_ransac(c, a.data(), b.data(), n, s.data(), T, mxGetScalar(in[3]), mxGetScalar(in[4]),
+        const int rc = vohip_fmatrix_ransac(c, a, b, n, s, T, mxGetScalar(in[3]), mxGetScalar(in[4]),
                                             (uint8_t *)mxGetLogicals(inl), &best, &trials, F);
-        std::vector<double>().swap(a); std::vector<double>().swap(b); std::vector<int32_t>().swap(s);
         check(rc, true);
+        mxFree(a);
+        mxFree(b);
+        mxFree(s);
         plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
         for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) mxGetDoubles(plhs[0])[3 * q + r] = F[3 * r + q];
         plhs[1] = inl;
-    } else if (op == "align_sim3") {
+    } else if (is("align_sim3")) {
         // [p_G_C, x] = vohip_mex('align_sim3', pp_G_C 3xN, p_V_C 3xN)
         const int n = cols(in[0]);
         plhs[0] = mxCreateDoubleMatrix(3, n, mxREAL);
         plhs[1] = mxCreateDoubleMatrix(7, 1, mxREAL);
         check(vohip_align_sim3(c, dbl(in[0], "pp_G_C"), dbl(in[1], "p_V_C"), n, 100, 1e-10, 1e-10,
                                mxGetDoubles(plhs[1]), mxGetDoubles(plhs[0]), nullptr));
-    } else if (op == "relative_pose") {
+    } else if (is("relative_pose")) {
         // [orientation, location, validFraction] = vohip_mex('relative_pose', E, K, p1 (n x 2), p2 (n x 2))
         const int n = rows(in[2]);
-        std::vector<double> a((size_t)2 * n), b((size_t)2 * n);
-        const double *p1 = dbl(in[2], "p1"), *p2 = dbl(in[3], "p2");
-        for (int i = 0; i < n; ++i) {
-            a[2 * i] = p1[i]; a[2 * i + 1] = p1[n + i];
-            b[2 * i] = p2[i]; b[2 * i + 1] = p2[n + i];
-        }
+        double *a = interleave2(dbl(in[2], "p1"), n), *b = interleave2(dbl(in[3], "p2"), n);
         plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
         plhs[1] = mxCreateDoubleMatrix(1, 3, mxREAL);
         double frac = 0.0;
-        const int rc = vohip_relative_pose(c, dbl(in[0], "E"), dbl(in[1], "K"), a.data(), b.data(), n,
-                                           mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]), &frac);
-        std::vector<double>().swap(a); std::vector<double>().swap(b);
+        const int rc = vohip_relative_pose(c, dbl(in[0], "E"), dbl(in[1], "K"), a, b, n, mxGetDoubles(plhs[0]),
+                                           mxGetDoubles(plhs[1]), &frac);
         check(rc);
+        mxFree(a);
+        mxFree(b);
         plhs[2] = mxCreateDoubleScalar(frac);
-    } else if (op == "ba_error") {
+    } else if (is("ba_error")) {
         int nobs = 0;
-        std::vector<double> r((size_t)2 * numel(in[1]));
-        const int rc = vohip_ba_error(c, dbl(in[0], "state"), numel(in[0]), dbl(in[1], "observations"), numel(in[1]),
-                                      dbl(in[2], "K"), r.data(), &nobs);
-        if (rc == VOHIP_OK) {
-            plhs[0] = mxCreateDoubleMatrix(2, nobs, mxREAL);
-            std::memcpy(mxGetDoubles(plhs[0]), r.data(), sizeof(double) * 2 * nobs);
-        }
-        std::vector<double>().swap(r);
-        check(rc);
-    } else if (op == "ba_run") {
+        double *r = scratch<double>((size_t)2 * numel(in[1]));
+        check(vohip_ba_error(c, dbl(in[0], "state"), numel(in[0]), dbl(in[1], "observations"), numel(in[1]),
+                             dbl(in[2], "K"), r, &nobs));
+        plhs[0] = mxCreateDoubleMatrix(2, nobs, mxREAL);
+        std::memcpy(mxGetDoubles(plhs[0]), r, sizeof(double) * 2 * nobs);
+        mxFree(r);
+    } else if (is("ba_run")) {
         // state = vohip_mex('ba_run', state, observations, K, max_iter)
         plhs[0] = mxDuplicateArray(in[0]);
         check(vohip_ba_run(c, mxGetDoubles(plhs[0]), numel(in[0]), dbl(in[1], "observations"), numel(in[1]),
                            dbl(in[2], "K"), (int)mxGetScalar(in[3]), 1e-10, 1e-10, nullptr));
-    } else if (op == "pose_refine") {
+    } else if (is("pose_refine")) {
         // T = vohip_mex('pose_refine', T_W_C, keypoints_uv 2xN, landmarks 3xN, K, max_iter)
         plhs[0] = mxDuplicateArray(in[0]);
         check(vohip_pose_refine(c, mxGetDoubles(plhs[0]), dbl(in[1], "keypoints"), dbl(in[2], "landmarks"), cols(in[1]),
                                 dbl(in[3], "K"), (int)mxGetScalar(in[4]), 1e-6, 1e-6, nullptr));   // lsqnonlin's defaults (T_refinement.m:4)
-    } else if (op == "detect_corners") {
+    } else if (is("detect_corners")) {
         // [Location, Metric] = vohip_mex('detect_corners', image uint8, min_quality, filter_size, border, method)
         if (!mxIsUint8(in[0])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
         const int cap = 16384;
-        std::vector<float> xy((size_t)2 * cap), metric((size_t)cap);
+        float *xy = scratch<float>((size_t)2 * cap), *metric = scratch<float>((size_t)cap);
         int n = 0;
-        const int rc = vohip_detect_corners(c, mxGetUint8s(in[0]), rows(in[0]), cols(in[0]), 1, mxGetScalar(in[1]),
-                                            (int)mxGetScalar(in[2]), (int)mxGetScalar(in[3]), (int)mxGetScalar(in[4]),
-                                            xy.data(), metric.data(), cap, &n);
-        if (rc == VOHIP_OK) {
-            plhs[0] = mxCreateNumericMatrix(n, 2, mxSINGLE_CLASS, mxREAL);
-            plhs[1] = mxCreateNumericMatrix(n, 1, mxSINGLE_CLASS, mxREAL);
-            std::memcpy(mxGetSingles(plhs[0]), xy.data(), sizeof(float) * 2 * n);
-            std::memcpy(mxGetSingles(plhs[1]), metric.data(), sizeof(float) * n);
-        }
-        std::vector<float>().swap(xy); std::vector<float>().swap(metric);
-        check(rc);
-    } else if (op == "pyramid_build") {
+        check(vohip_detect_corners(c, mxGetUint8s(in[0]), rows(in[0]), cols(in[0]), 1, mxGetScalar(in[1]),
+                                   (int)mxGetScalar(in[2]), (int)mxGetScalar(in[3]), (int)mxGetScalar(in[4]), xy, metric,
+                                   cap, &n));
+        plhs[0] = mxCreateNumericMatrix(n, 2, mxSINGLE_CLASS, mxREAL);
+        plhs[1] = mxCreateNumericMatrix(n, 1, mxSINGLE_CLASS, mxREAL);
+        std::memcpy(mxGetSingles(plhs[0]), xy, sizeof(float) * 2 * n);   // n x 2, x column then y column
+        std::memcpy(mxGetSingles(plhs[1]), metric, sizeof(float) * n);
+        mxFree(xy);
+        mxFree(metric);
+    } else if (is("pyramid_build")) {
         // vohip_mex('pyramid_build', slot, image uint8, levels)
         if (!mxIsUint8(in[1])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
         check(vohip_pyramid_build(c, (int)mxGetScalar(in[0]), mxGetUint8s(in[1]), rows(in[1]), cols(in[1]), 1,
                                   (int)mxGetScalar(in[2])));
-    } else if (op == "klt_track") {
+    } else if (is("klt_track")) {
         // [points, validity] = vohip_mex('klt_track', slot_prev, slot_cur, points (N x 2), block, max_iter, max_bidir)
         const int n = rows(in[2]);
         plhs[0] = mxCreateDoubleMatrix(n, 2, mxREAL);
@@ -255,7 +267,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                               (int)mxGetScalar(in[3]), (int)mxGetScalar(in[4]), mxGetScalar(in[5]),
                               mxGetDoubles(plhs[0]), (uint8_t *)mxGetLogicals(valid), nullptr));
         plhs[1] = valid;
-    } else if (op == "frame_create") {
+    } else if (is("frame_create")) {
         // vohip_mex('frame_create', K, rows, cols, params struct): the loop body of main_demo.m:377-427 as
         // one call per frame, state resident on the GPU (one loop per MATLAB session).  params fields
         // (all optional): r_discard_redundant, angle_threshold_deg, min_depth, max_depth, min_quality,
@@ -276,15 +288,16 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
             p.filter_size = (int)field("filter_size", p.filter_size);
             p.detector = (int)field("detector", p.detector);
             p.refine_pose = (int)field("refine_pose", p.refine_pose);
+            p.is_BA = (int)field("is_BA", p.is_BA);
         }
         check(vohip_frame_create(c, dbl(in[0], "K"), (int)mxGetScalar(in[1]), (int)mxGetScalar(in[2]), 1, &p, &g_frame));
-    } else if (op == "frame_reset") {
+    } else if (is("frame_reset")) {
         // vohip_mex('frame_reset', image uint8, X 3xn, P_rc 2xn, T_W_C 4x4)   (main_demo.m:268-303, 342-344)
         if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
         if (!mxIsUint8(in[0])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
         check(vohip_frame_reset(g_frame, mxGetUint8s(in[0]), 0, dbl(in[1], "X"), nullptr, dbl(in[2], "P"), cols(in[1]),
                                 dbl(in[3], "T_W_C")));
-    } else if (op == "frame_step") {
+    } else if (is("frame_step")) {
         // [T_W_C, info, status] = vohip_mex('frame_step', image uint8, u3 3xh, u8 8x500 or [], next_image or [])
         // u3 / u8: uniform draws (rand); status 0 = done, VOHIP_SAMPLES_EXHAUSTED = call 'frame_retry' with a
         // longer u3 that starts with the same columns (info.num_iterations says how many are wanted).
@@ -300,7 +313,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                                               &counts);
         if (st != VOHIP_OK && st != VOHIP_SAMPLES_EXHAUSTED) check(st);
         frame_outputs(nlhs, plhs, pose, counts, st);
-    } else if (op == "frame_retry") {
+    } else if (is("frame_retry")) {
         // [T_W_C, info, status] = vohip_mex('frame_retry', u3 3xh)
         if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
         vohip_frame_pose pose;
@@ -308,7 +321,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         const int st = vohip_frame_retry(g_frame, dbl(in[0], "u3"), cols(in[0]), &pose, &counts);
         if (st != VOHIP_OK && st != VOHIP_SAMPLES_EXHAUSTED) check(st);
         frame_outputs(nlhs, plhs, pose, counts, st);
-    } else if (op == "frame_state") {
+    } else if (is("frame_state")) {
         // [P, X, C, F, T] = vohip_mex('frame_state'): S.P 2xn, S.X 4xn (ids in row 4), S.C, S.F 2xm, S.T 12xm
         if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
         int nL = 0, nC = 0;
@@ -329,10 +342,14 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         plhs[2] = C;
         plhs[3] = Fm;
         plhs[4] = T;
-    } else if (op == "frame_destroy") {
+    } else if (is("frame_apply_ba")) {
+        // vohip_mex('frame_apply_ba', X 3xn, T_W_C 4x4): VO_bundle_adjust.m:53-70 put back into the device state
+        if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
+        check(vohip_frame_apply_ba(g_frame, dbl(in[0], "X"), cols(in[0]), dbl(in[1], "T_W_C")));
+    } else if (is("frame_destroy")) {
         if (g_frame) vohip_frame_destroy(g_frame);
         g_frame = nullptr;
     } else {
-        mexErrMsgIdAndTxt("vohip:usage", "unknown opcode '%s'", op.c_str());
+        mexErrMsgIdAndTxt("vohip:usage", "unknown opcode '%s'", opbuf);
     }
 }
