@@ -33,7 +33,8 @@
  *    The displacement doubles between levels.
  *  - A point is valid iff at level 0 G is well conditioned in both directions
  *    (lambda_min(G) / W^2 >= 1e-3), the forward result lies inside the image, and the
- *    forward-backward distance is <= max_bidir_error.
+ *    forward-backward distance is <= max_bidir_error.  A point that is already invalid after the
+ *    forward pass is not tracked back; its forward-backward distance is reported as infinite.
  */
 #include "vo_oracle.h"
 
@@ -239,10 +240,15 @@ void vo_klt_track(const uint8_t *prev, const uint8_t *cur, int A, int B, const d
     for (int i = 0; i < n; ++i) {
         double qa, qb, ra, rb;
         int ok_f = track_one(P, Q, As, Bs, levels, W, max_iter, pts[i], pts[n + i], &qa, &qb);
-        int ok_b = track_one(Q, P, As, Bs, levels, W, max_iter, qa, qb, &ra, &rb);
-        double ea = ra - pts[i], eb = rb - pts[n + i];
-        double err = sqrt(ea * ea + eb * eb);
         int inside = qa >= 0.0 && qa <= (double)(A - 1) && qb >= 0.0 && qb <= (double)(B - 1);
+        /* a track that is invalid after the forward pass is not tracked back (distance: infinite) */
+        int ok_b = 0;
+        double err = INFINITY;
+        if (ok_f && inside) {
+            ok_b = track_one(Q, P, As, Bs, levels, W, max_iter, qa, qb, &ra, &rb);
+            double ea = ra - pts[i], eb = rb - pts[n + i];
+            err = sqrt(ea * ea + eb * eb);
+        }
         out[i] = qa;
         out[n + i] = qb;
         valid[i] = (uint8_t)(ok_f && ok_b && inside && err <= max_bidir_error);

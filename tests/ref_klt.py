@@ -119,9 +119,10 @@ def track(prev, cur, pts, block=21, levels=5, max_iter=20, max_bidir_error=6.0):
     with np.errstate(all="ignore"):
         fwd, ok_f = _track_dir(P, Q, pts, block, max_iter)
         back, ok_b = _track_dir(Q, P, fwd, block, max_iter)
-    err = np.linalg.norm(back - pts, axis=1)
     H, W = np.asarray(prev).shape
     inside = (fwd[:, 0] >= 0.0) & (fwd[:, 0] <= W - 1.0) & (fwd[:, 1] >= 0.0) & (fwd[:, 1] <= H - 1.0)
+    # (a point already invalid after the forward pass has no defined way back: infinite distance)
+    err = np.where(ok_f & inside, np.linalg.norm(back - pts, axis=1), np.inf)
     with np.errstate(invalid="ignore"):
         valid = ok_f & ok_b & inside & (err <= max_bidir_error)
     return fwd, valid, err

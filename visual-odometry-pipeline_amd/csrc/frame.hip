@@ -707,6 +707,8 @@ struct vohip_frame {
     hipEvent_t ev_adv[2] = {nullptr, nullptr};   // after the trackers INTO the table of that parity
     hipEvent_t ev_advC[2] = {nullptr, nullptr};  // ... the candidate tracker, when it runs on the second stream
     hipEvent_t ev_feed = nullptr;                // what a tracker launch of this call waits for
+    hipEvent_t ev_inl = nullptr;                 // after the inlier selection: the landmarks the frame keeps are final
+    hipEvent_t ev_advA[2] = {nullptr, nullptr};  // after the early tracker of the kept landmarks INTO the table of that parity
     hipEvent_t tr[8] = {nullptr};   // timing events of the trace option
     hipEvent_t tr_trk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // ... around the trackers into table [parity]
     bool trace = false;
@@ -928,6 +930,7 @@ int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready)
                        f->Xv, f->idv, f->rowv,
                        f->dv, f->cnt, f->L_rc, f->L_X, f->L_id, f->srcL, f->kp_uv);
     VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_inl, s));   // S.P of the inliers is final: their tracker may start
     if (p.refine_pose)   // main_demo.m:398-400
         VOHIP_TRY(vohip_pose_refine_enqueue(ctx, f->dv + D_T, f->kp_uv, f->L_X, f->n_L, f->cnt + N_IN, f->K,
                                             p.refine_max_iter, 1e-6, 1e-6, f->dv + D_STATS));   // lsqnonlin's default tolerances (T_refinement.m:4)
@@ -976,11 +979,14 @@ int enqueue_trackers(vohip_frame *f, int par, int slot_from, int slot_to, int nL
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
     const int *dL = counts_on_device ? f->cnt + N_L_END : nullptr, *dC = counts_on_device ? f->cnt + N_C_END : nullptr;
+    // ahead of the frame, the landmarks the previous frame kept as inliers have a tracker of their own
+    // (enqueue_tracker_kept); this launch then starts at the landmarks that frame appended
+    const int *dFirst = counts_on_device ? f->cnt + N_IN : nullptr;
     const vohip_klt_set sets[2] = {
-        {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcL, nullptr, dL, f->capU, nL, 0, 0},
-        {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcC, nullptr, dC, f->capU, nC, 0, f->capL}};
+        {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcL, nullptr, dL, f->capU, nL, 0, 0, dFirst},
+        {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcC, nullptr, dC, f->capU, nC, 0, f->capL, nullptr}};
     if (f->trace) (void)hipEventRecord(f->tr_trk[par][0], ctx->stream);
-    if (f->n_L + f->n_C >= SPLIT_TRACKERS_FROM) {
+    if ((counts_on_device ? f->n_C : f->n_L + f->n_C) >= SPLIT_TRACKERS_FROM) {
         // landmarks on the context's stream, candidates on the second stream (where the epipolar filter
         // follows them in stream order); `start`: what the candidate launch waits for on the context's stream
         VOHIP_TRY(vohip_klt_enqueue_sets(ctx, slot_from, slot_to, sets, 1, p.klt_block, p.klt_max_iter,
@@ -1001,6 +1007,25 @@ int enqueue_trackers(vohip_frame *f, int par, int slot_from, int slot_to, int nL
     return VOHIP_OK;
 }
 
+// The landmarks a frame keeps (the inliers of its pose, main_demo.m:394-396) are final long before the
+// frame ends -- pose refinement, triangulation and the candidate bookkeeping follow -- so with the
+// following image's pyramid on its way their tracker runs beside those stages, on the stream that
+// built the pyramid, from the rows srcL[0 .. N_IN) into the first landmark rows of the other table.
+int enqueue_tracker_kept(vohip_frame *f)
+{
+    vohip_ctx *ctx = f->ctx;
+    const vohip_frame_params &p = f->prm;
+    const int par = f->par ^ 1;   // the table of the following frame
+    stream_swap sw(ctx, f->trk);  // (in order behind the following image's pyramid)
+    VOHIP_HIP(ctx, hipStreamWaitEvent(f->trk, f->ev_inl, 0));
+    const vohip_klt_set set = {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcL, nullptr, f->cnt + N_IN,
+                               f->capU, f->n_L, 0, 0, nullptr};
+    VOHIP_TRY(vohip_klt_enqueue_sets(ctx, f->slot_cur, f->slot_next, &set, 1, p.klt_block, p.klt_max_iter,
+                                     p.klt_max_bidir_error));
+    VOHIP_HIP(ctx, hipEventRecord(f->ev_advA[par], f->trk));
+    return VOHIP_OK;
+}
+
 // With the following image's pyramid on its way (the look-ahead), that frame's trackers go behind this
 // frame's last kernel: they need nothing from the host, so the GPU starts them while the host still
 // collects this frame's results and prepares the next call.
@@ -1009,8 +1034,9 @@ int enqueue_trackers_ahead(vohip_frame *f)
     vohip_ctx *ctx = f->ctx;
     hipStream_t s = ctx->stream;
     VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_img, 0));   // the following image's pyramid
-    // landmarks only come from candidates; candidates grow by the detections that are kept
-    const long long nLb = (long long)f->n_L + f->n_C, nCb = (long long)f->n_C + f->capK;
+    // the landmarks this launch tracks are the ones the frame appends, which come from its candidates (the
+    // kept ones have their own, earlier launch); candidates grow by the detections that are kept
+    const long long nLb = (long long)f->n_C, nCb = (long long)f->n_C + f->capK;
     VOHIP_TRY(enqueue_trackers(f, f->par ^ 1, f->slot_cur, f->slot_next, (int)(nLb < f->capL ? nLb : f->capL),
                                (int)(nCb < f->capC ? nCb : f->capC), true, f->ev_tail));
     return VOHIP_OK;
@@ -1173,6 +1199,9 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_advC[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_advC[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_feed, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_inl, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_advA[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_advA[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_tail, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_next, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
@@ -1223,6 +1252,9 @@ int vohip_frame_destroy(vohip_frame *f)
     for (int q = 0; q < 2; ++q)
         if (f->ev_advC[q]) (void)hipEventDestroy(f->ev_advC[q]);
     if (f->ev_feed) (void)hipEventDestroy(f->ev_feed);
+    if (f->ev_inl) (void)hipEventDestroy(f->ev_inl);
+    for (int q = 0; q < 2; ++q)
+        if (f->ev_advA[q]) (void)hipEventDestroy(f->ev_advA[q]);
     if (f->ev_tail) (void)hipEventDestroy(f->ev_tail);
     if (f->ev_next) (void)hipEventDestroy(f->ev_next);
     if (f->ctx) (void)hipStreamSynchronize(f->ctx->stream);
@@ -1382,6 +1414,7 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     }   // (else the previous call enqueued all of that, the trackers behind its own last kernel)
     if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, f->ev_pyr, nullptr));
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
+    if (f->ahead) VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_advA[par], 0));   // the kept landmarks' own tracker
     // the selection of the valid landmark tracks (main_demo.m:381, :387)
     hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->U_xy[par], f->capU, f->U_live[par],
                        f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->rowv, f->cnt, f->dv, pin_u3(f), h0, f->samples3);
@@ -1398,6 +1431,7 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
         VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_next, d_next, f->rows, f->cols, f->colmajor, p.klt_levels));
         VOHIP_HIP(ctx, hipEventRecord(f->ev_img, f->trk));
     }
+    if (next_image) VOHIP_TRY(enqueue_tracker_kept(f));
     VOHIP_TRY(enqueue_tail(f));
     if (next_image) VOHIP_TRY(enqueue_trackers_ahead(f));
     // (last: nothing waits for the following image's corners before the next call's final kernels)
@@ -1422,8 +1456,9 @@ int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose 
     f->t_entry = std::chrono::steady_clock::now();
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     int st = enqueue_localize(f, u3, h, 0);
-    if (st == VOHIP_OK) st = enqueue_tail(f);
     // (the trackers enqueued ahead started from the lists of the first attempt: once more, from the final ones)
+    if (st == VOHIP_OK && f->ahead_launched) st = enqueue_tracker_kept(f);
+    if (st == VOHIP_OK) st = enqueue_tail(f);
     if (st == VOHIP_OK && f->ahead_launched) st = enqueue_trackers_ahead(f);
     if (st != VOHIP_OK) {
         f->stage = STAGE_FAILED;

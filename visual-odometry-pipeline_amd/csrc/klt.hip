@@ -360,10 +360,16 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
     const int32_t *__restrict__ rows = KLT_PICK(rows);
     const uint8_t *__restrict__ live = KLT_PICK(live);
     const int *__restrict__ n_dev = KLT_PICK(n_dev);
+    const int *__restrict__ first_dev = KLT_PICK(first_dev);
     const int ld = KLT_PICK(ld), base = KLT_PICK(base), out_base = KLT_PICK(out_base);
     int n = KLT_PICK(n);
 #undef KLT_PICK
-    if (n_dev) n = min(n, *n_dev);
+    if (first_dev) {   // tracks [*first_dev, *n_dev) of the list; n only sizes the grid
+        i += *first_dev;
+        n = *n_dev;
+    } else if (n_dev) {
+        n = min(n, *n_dev);
+    }
     if (i >= n) return;
     const long long t_start = stats ? clock64() : 0;
     const int r = rows ? rows[i] : base + i;
@@ -377,10 +383,17 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
     double qa, qb, ra, rb;
     int iters = 0;
     const bool ok_f = track_dir<W>(P, Q, max_iter, pa, pb, qa, qb, sI, sJ, iters);
-    const bool ok_b = track_dir<W>(Q, P, max_iter, qa, qb, ra, rb, sI, sJ, iters);
-    const double ea = ra - pa, eb = rb - pb;
-    const double err = sqrt(ea * ea + eb * eb);
     const bool inside = qa >= 0.0 && qa <= (double)(P.A[0] - 1) && qb >= 0.0 && qb <= (double)(P.B[0] - 1);
+    // A track that is already invalid after the forward pass (untrackable at level 0, or outside the image)
+    // is not tracked back: its forward-backward distance is reported as infinite.  (qa, qb are the same in
+    // every lane, so the whole wavefront takes the same side.)
+    bool ok_b = false;
+    double err = __builtin_inf();
+    if (ok_f && inside) {
+        ok_b = track_dir<W>(Q, P, max_iter, qa, qb, ra, rb, sI, sJ, iters);
+        const double ea = ra - pa, eb = rb - pb;
+        err = sqrt(ea * ea + eb * eb);
+    }
     if (threadIdx.x == 0) {
         out_xy[o] = (swap_xy ? qb : qa) + 1.0;
         out_xy[ld + o] = (swap_xy ? qa : qb) + 1.0;
@@ -486,7 +499,7 @@ int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double 
                       const int *d_n, int block_size, int max_iter, double max_bidir_error, double *d_out_xy,
                       uint8_t *d_valid, double *d_fb_err)
 {
-    const vohip_klt_set set = {d_pts_xy, d_out_xy, d_valid, d_fb_err, nullptr, nullptr, d_n, ld, n, 0, -1};
+    const vohip_klt_set set = {d_pts_xy, d_out_xy, d_valid, d_fb_err, nullptr, nullptr, d_n, ld, n, 0, -1, nullptr};
     return vohip_klt_enqueue_sets(ctx, slot_prev, slot_cur, &set, 1, block_size, max_iter, max_bidir_error);
 }
 
@@ -502,6 +515,7 @@ int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vo
         const vohip_klt_set &t = sets[q];
         VOHIP_REQUIRE(ctx, t.n >= 0 && t.base >= 0 && (t.rows || t.ld >= t.base + t.n), "bad point set");
         VOHIP_REQUIRE(ctx, t.n == 0 || (t.pts_xy && t.out_xy && t.valid), "NULL array");
+        VOHIP_REQUIRE(ctx, !t.first_dev || (t.n_dev && t.rows), "a device-side start needs a device-side end and a row list");
         S.s[q] = t;
         total += t.n;
     }

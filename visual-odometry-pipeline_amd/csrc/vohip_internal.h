@@ -118,6 +118,7 @@ struct vohip_klt_set {
     const uint8_t *live;   // may be NULL
     const int *n_dev;      // may be NULL; else the device-side count (<= n, n then only sizes the grid)
     int ld, n, base, out_base;
+    const int *first_dev;  // may be NULL; else the set starts at track *first_dev (device side) and ends before *n_dev
 };
 // Up to three sets in one launch (a launch lasts as long as its slowest track however many tracks
 // it carries).
