@@ -51,8 +51,9 @@ STRESS_EXCLUSION_RADIUS = 2.0
 STRESS_CAPACITY = 16384
 
 
-def thin_by_grid(xy, metric, cell=KITTI_THIN_CELL):
+def thin_by_grid(xy, metric, cell=None):
     """Strongest corner per cell: brings the first frame's detections to about 2k points."""
+    cell = cell or KITTI_THIN_CELL
     key = (np.floor(xy[:, 1] / cell).astype(np.int64) << 20) + np.floor(xy[:, 0] / cell).astype(np.int64)
     order = np.lexsort((-metric, key))
     first = np.ones(len(order), dtype=bool)
@@ -419,7 +420,12 @@ def main():
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--hypotheses", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--thin-cell", type=float, default=KITTI_THIN_CELL, help="thinning cell of the first frame's corners, px")
+    ap.add_argument("--exclusion-radius", type=float, default=KITTI_EXCLUSION_RADIUS,
+                    help="r_discard_redundant of the KITTI-shape workload, px (the reference's value is 10)")
+    ap.add_argument("--only-headline", action="store_true", help="skip the secondary legs")
     args = ap.parse_args()
+    globals().update(KITTI_THIN_CELL=args.thin_cell, KITTI_EXCLUSION_RADIUS=args.exclusion_radius)
 
     import torch
     import torch.distributed as dist
@@ -477,7 +483,7 @@ def main():
             elapsed = float(t.item())
         fps = world * args.steps / elapsed
         extra = {}
-        if world == 1:
+        if world == 1 and not args.only_headline:
             nosync = lambda: torch.cuda.synchronize()   # noqa: E731
             nogather = lambda pipe, seconds: []          # noqa: E731
             el, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync, nogather,

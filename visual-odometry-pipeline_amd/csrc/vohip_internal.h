@@ -36,12 +36,14 @@ enum vohip_buf_id {
     B_BA_INDEX, B_BA_FRAME, B_BA_LM, B_BA_UV, B_BA_COUNT, B_BA_STATE, B_BA_TRIAL, B_BA_SPART, B_BA_GPART,
     B_BA_E, B_BA_GL, B_BA_W, B_BA_DP, B_BA_PART, B_BA_STATUS, H_BA_STATUS,
     B_KLT_STATS,
-    B_PYR0, B_PYR1, B_PYR2, B_PYR3, B_PYR4, B_PYR5, B_PYR6, B_PYR7,
+    B_PYR0,                 // first of VOHIP_PYR_SLOTS consecutive ids, one per pyramid slot (see B_PYR_LAST)
     VOHIP_NBUF = 96
 };
 
 // One image pyramid (float levels, all in one context buffer B_PYR0 + slot).
 constexpr int VOHIP_PYR_SLOTS = 16;
+constexpr int B_PYR_LAST = B_PYR0 + VOHIP_PYR_SLOTS - 1;
+static_assert(B_PYR_LAST < VOHIP_NBUF, "the pyramid slots must fit into the buffer table");
 struct vohip_pyramid {
     int rows = 0, cols = 0, colmajor = 0, levels = 0;
     int A[8] = {0}, B[8] = {0};   // fast / slow axis length per level

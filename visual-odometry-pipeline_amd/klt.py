@@ -12,14 +12,14 @@ from ._lib import dptr
 
 
 class Pyramid:
-    """A float image pyramid resident on the GPU (one of the context's 8 slots).  Build it once
+    """A float image pyramid resident on the GPU (one of the context's 16 slots).  Build it once
     per frame and hand it to several trackers."""
 
     def __init__(self, image, levels=5, ctx=None):
         self.ctx = ctx or _lib.default_context()
         free = self.ctx.__dict__.setdefault("_free_pyr_slots", list(range(16)))
         if not free:
-            raise RuntimeError("all 8 pyramid slots of the context are in use; release() some")
+            raise RuntimeError("all 16 pyramid slots of the context are in use; release() some")
         self.slot = free.pop(0)
         if hasattr(image, "data_ptr"):
             # a uint8 image already resident on the GPU (e.g. a torch tensor), row-major
