@@ -265,3 +265,37 @@ def test_more_hypotheses_on_demand(vo, ctx, oracle, sequence, lookahead):
     assert a.rng.bit_generator.state == b.rng.bit_generator.state
     a.close()
     b.close()
+
+
+def test_two_loops_on_one_context_with_frames_in_flight_together(vo, ctx, oracle, sequence):
+    """Two loops share a context and have their frames in flight at the same time (begin A, begin B, finish
+    A, finish B), one of them preparing the next image ahead on its own streams: each loop owns the scratch
+    its kernels use (candidate poses of the hypotheses, the corner detector's records), so both must give
+    exactly what they give when run alone."""
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    flipped = [np.ascontiguousarray(f[:, ::-1]) for f in frames]     # another sequence: other corners, other poses
+
+    def make(seed, imgs):
+        return vo.VOPipelineDevice(K, imgs[0], X0 if imgs is frames else Xf, xy if imgs is frames else xyf, poses[0],
+                                   hyper_paras=hp, rng=np.random.default_rng(seed), ctx=ctx)
+
+    xyf = xy.copy()
+    xyf[:, 0] = W + 1 - xy[:, 0]                                       # the same points in the mirrored image
+    Xf = X0 * np.array([-1.0, 1.0, 1.0])
+    alone_a, alone_b = make(1, frames), make(2, flipped)
+    Ta = [alone_a.process_frame(frames[i], next_image=frames[i + 1]) for i in range(1, 7)]
+    Tb = [alone_b.process_frame(flipped[i]) for i in range(1, 7)]
+    a, b = make(1, frames), make(2, flipped)
+    for i in range(1, 7):
+        a.begin_frame(frames[i], next_image=frames[i + 1])
+        b.begin_frame(flipped[i])
+        np.testing.assert_array_equal(a.finish_frame(), Ta[i - 1])
+        np.testing.assert_array_equal(b.finish_frame(), Tb[i - 1])
+    for k in ("X", "P", "C", "F", "T"):
+        np.testing.assert_array_equal(getattr(a.S, k), getattr(alone_a.S, k), err_msg=k)
+        np.testing.assert_array_equal(getattr(b.S, k), getattr(alone_b.S, k), err_msg=k)
+    assert a.num_X == alone_a.num_X and b.num_C == alone_b.num_C
+    for p in (a, b, alone_a, alone_b):
+        p.close()

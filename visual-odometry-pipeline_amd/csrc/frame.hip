@@ -719,6 +719,9 @@ struct vohip_frame {
     double *mv_rc, *Xv, *idv, *kp_uv;
     double *p1_rc, *m_rc, *F_t, *T_t, *m2_rc, *F2, *T2, *Xnew;
     double *u8, *fm_F, *dv;
+    double *Rt_all, *M_all;      // candidate poses of the frame's hypotheses (48 doubles per hypothesis each)
+    void *corner_scratch;        // the corner detector's records (this loop's own: detection runs on its own stream)
+    unsigned det_calls = 0;
     double *U_xy[2];             // the track tables of even and odd frames
     uint8_t *U_live[2];
     int32_t *srcL, *srcC;        // table row of every landmark / candidate the next frame starts with
@@ -779,6 +782,9 @@ size_t layout(vohip_frame *f, char *base)
     f->F2 = carve<double>(p, 2 * C);
     f->T2 = carve<double>(p, 12 * C);
     f->Xnew = carve<double>(p, 3 * C);
+    f->corner_scratch = carve<char>(p, vohip_corner_scratch_bytes(f->rows, f->cols));   // (first: zero from the start)
+    f->Rt_all = carve<double>(p, 48 * H);
+    f->M_all = carve<double>(p, 48 * H);
     f->u8 = carve<double>(p, 8 * T);
     f->fm_F = carve<double>(p, 9 * T);
     for (int q = 0; q < 2; ++q) {
@@ -889,11 +895,10 @@ int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t 
 {
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
-    stream_swap sw(ctx, f->side2);
     VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, ready, 0));
-    VOHIP_TRY(vohip_detect_corners_dev(ctx, d_img, f->rows, f->cols, f->colmajor, p.min_quality, p.filter_size, p.border,
-                                       p.detector, f->corner_xy[par], f->corner_metric[par], f->capK,
-                                       f->cnt + N_DET + par));
+    VOHIP_TRY(vohip_detect_corners_enqueue(ctx, f->side2, f->corner_scratch, &f->det_calls, d_img, f->rows, f->cols,
+                                           f->colmajor, p.min_quality, p.filter_size, p.border, p.detector,
+                                           f->corner_xy[par], f->corner_metric[par], f->capK, f->cnt + N_DET + par));
     if (table_free) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, table_free, 0));
     // (the candidate tracker, when it last ran as a launch of its own; complete long ago otherwise)
     if (table_free) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, f->ev_advC[par ^ 1], 0));
@@ -923,10 +928,10 @@ int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready)
         hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more - ready)), dim3(256), 0, s, pin_u3(f), first + ready,
                            more - ready, f->cnt, f->samples3);
     VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
-                                   f->counts4));
+                                   f->counts4, f->Rt_all, f->M_all));
     f->evaluated = h;
     hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->counts4, h,
-                       (const double *)ctx->bufs[B_RANSAC_RT].ptr, (const double *)ctx->bufs[B_RANSAC_M].ptr, f->mv_rc,
+                       (const double *)f->Rt_all, (const double *)f->M_all, f->mv_rc,
                        f->Xv, f->idv, f->rowv,
                        f->dv, f->cnt, f->L_rc, f->L_X, f->L_id, f->srcL, f->kp_uv);
     VOHIP_HIP(ctx, hipGetLastError());
@@ -1217,13 +1222,6 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
         f->trace = true;
         for (int q = 0; q < 8; ++q) (void)hipEventCreate(&f->tr[q]);
         for (int q = 0; q < 4; ++q) (void)hipEventCreate(&f->tr_trk[q >> 1][q & 1]);
-    }
-    // the pose buffers of the hypothesis solver must hold every hypothesis of a frame
-    int st = vohip_reserve(ctx, ctx->bufs[B_RANSAC_RT], (size_t)f->hmax * 48 * sizeof(double));
-    if (st == VOHIP_OK) st = vohip_reserve(ctx, ctx->bufs[B_RANSAC_M], (size_t)f->hmax * 48 * sizeof(double));
-    if (st != VOHIP_OK) {
-        vohip_frame_destroy(f);
-        return st;
     }
     *out = f;
     return VOHIP_OK;

@@ -8,15 +8,20 @@
 //   Harris R = (AB - C^2) - 0.04 (A+B)^2, MinEigen R = ((A+B) - sqrt((A-B)^2 + 4C^2))/2;
 //   corner <=> R > MinQuality*max(R), strict maximum of its 8-neighbourhood, >= border px from
 //   every edge; sub-pixel offset per axis from the parabola through 3 responses (+-0.5 max).
-// Kernels:
-//   corner_response_kernel  fused tile kernel: uint8 tile + 3 px halo -> LDS, gradient products
-//                           in LDS, separable Gaussian through LDS, response to global memory,
-//                           tile maximum -> one atomicMax per workgroup.  fp32, evaluated in a
-//                           fixed order without FMA contraction (bit-reproducible).
-//   corner_nms_kernel       threshold + 3x3 strict maximum -> one bit per pixel; every wavefront
-//                           owns one 64-bit bitmap word (ballot), so there are no atomics.
-//   corner_emit_kernel      popcount prefix + block scan over the bitmap = ordered, deterministic
-//                           compaction; sub-pixel refinement; output.
+// Kernels (the response map never goes to memory):
+//   corner_tile_kernel   one fused tile kernel: uint8 tile + 4 px halo (1 gradient + 2 Gaussian + 1
+//                        non-maximum suppression) -> LDS, gradient products, separable Gaussian and the
+//                        response of the tile and a 1 px ring around it all in LDS; every strict 3x3
+//                        maximum of the tile inside the border margin becomes a 16-byte record (pixel
+//                        index, response, sub-pixel position) in the tile's own list, in pixel order
+//                        (ballot compaction, no atomics); tile maximum -> one atomicMax per workgroup.
+//                        fp32, evaluated in a fixed order without FMA contraction (bit-reproducible).
+//   corner_emit_kernel   one workgroup per row of tiles: applies R > MinQuality * max(R) to the records
+//                        and writes the survivors in ascending pixel order (counts per (image row, tile)
+//                        cell in LDS, prefix over the cells, survivors of earlier tile rows counted from
+//                        their records): ordered and deterministic.
+// Per image: the uint8 image is read once (plus the halos), ~16 bytes are written and read per local
+// maximum and 12 bytes written per corner.
 #include "vohip_internal.h"
 
 #include <cmath>
@@ -24,11 +29,19 @@
 namespace {
 
 constexpr int TA = 64, TB = 16, FS = 5, HALF = FS / 2;
-constexpr int IA = TA + 2 * HALF + 2, IB = TB + 2 * HALF + 2;  // staged image tile
-constexpr int PA = TA + 2 * HALF, PB = TB + 2 * HALF;          // gradient-product tile
+constexpr int RA = TA + 2, RB = TB + 2;                        // response tile: the tile and a 1 px ring
+constexpr int PA = RA + 2 * HALF, PB = RB + 2 * HALF;          // gradient-product tile
+constexpr int IA = PA + 2, IB = PB + 2;                        // staged image tile
+constexpr int TILE_CAP = TA * TB / 4;                          // strict 3x3 maxima cannot touch: at most one per 2x2
+constexpr int MAX_TILES_A = 128;                               // tiles along the fast axis the emit kernel handles
 
 struct taps5 {
     float w[FS];
+};
+
+struct corner_rec {   // 16 bytes
+    int key;          // pixel index b * A + a
+    float r, pa, pb;  // response, sub-pixel position (0-based)
 };
 
 __device__ __forceinline__ unsigned ordered_bits(float f)
@@ -43,22 +56,30 @@ __device__ __forceinline__ float from_ordered_bits(unsigned k)
 
 #pragma clang fp contract(off)
 
-__global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t *__restrict__ img, int A, int B,
-                                                              taps5 G, int method, float *__restrict__ R,
-                                                              unsigned *__restrict__ max_bits)
+// max_bits[0 / 1]: the maximum of this call / cleared here for the next call (the two alternate).
+__global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restrict__ img, int A, int B, taps5 G,
+                                                          int method, int lo, corner_rec *__restrict__ recs,
+                                                          int *__restrict__ tile_count,
+                                                          unsigned *__restrict__ max_now,
+                                                          unsigned *__restrict__ max_next)
 {
     __shared__ float sI[IA * IB];
     __shared__ float sP[3][PA * PB];
-    __shared__ float sH[3][TA * PB];
+    __shared__ float sH[3][RA * PB];
+    __shared__ float sR[RA * RB];
     __shared__ unsigned sMax;
-    const int tid = threadIdx.x;
+    __shared__ int sCnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int a0 = blockIdx.x * TA, b0 = blockIdx.y * TB;
-    if (tid == 0) sMax = 0u;
+    if (tid == 0) {
+        sMax = 0u;
+        if (blockIdx.x == 0 && blockIdx.y == 0) *max_next = 0u;
+    }
     const float s255 = 1.0f / 255.0f;
     for (int q = tid; q < IA * IB; q += 256) {
         const int rb = q / IA, ra = q - rb * IA;
-        const int a = min(max(a0 - HALF - 1 + ra, 0), A - 1);
-        const int b = min(max(b0 - HALF - 1 + rb, 0), B - 1);
+        const int a = min(max(a0 - HALF - 2 + ra, 0), A - 1);
+        const int b = min(max(b0 - HALF - 2 + rb, 0), B - 1);
         sI[q] = (float)img[(size_t)b * A + a] * s255;
     }
     __syncthreads();
@@ -72,8 +93,8 @@ __global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t *__r
         sP[2][q] = gx * gy;
     }
     __syncthreads();
-    for (int q = tid; q < TA * PB; q += 256) {
-        const int rb = q / TA, ra = q - rb * TA;
+    for (int q = tid; q < RA * PB; q += 256) {
+        const int rb = q / RA, ra = q - rb * RA;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             const float *p = sP[ch] + rb * PA + ra;
@@ -85,15 +106,15 @@ __global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t *__r
     }
     __syncthreads();
     float best = -INFINITY;
-    for (int q = tid; q < TA * TB; q += 256) {
-        const int rb = q / TA, ra = q - rb * TA;
+    for (int q = tid; q < RA * RB; q += 256) {
+        const int rb = q / RA, ra = q - rb * RA;
         float v[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const float *p = sH[ch] + rb * TA + ra;
+            const float *p = sH[ch] + rb * RA + ra;
             float s = G.w[0] * p[0];
 #pragma unroll
-            for (int i = 1; i < FS; ++i) s = s + G.w[i] * p[i * TA];
+            for (int i = 1; i < FS; ++i) s = s + G.w[i] * p[i * RA];
             v[ch] = s;
         }
         float r;
@@ -105,96 +126,159 @@ __global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t *__r
             const float d = v[0] - v[1];
             r = ((v[0] + v[1]) - sqrtf(d * d + 4.0f * (v[2] * v[2]))) * 0.5f;
         }
-        const int a = a0 + ra, b = b0 + rb;
-        if (a < A && b < B) {
-            R[(size_t)b * A + a] = r;
-            best = fmaxf(best, r);
-        }
+        sR[q] = r;
+        // the image maximum is taken over the pixels of the tile itself (every pixel belongs to one tile)
+        const int a = a0 - 1 + ra, b = b0 - 1 + rb;
+        if (ra >= 1 && ra <= TA && rb >= 1 && rb <= TB && a < A && b < B) best = fmaxf(best, r);
     }
-    // tile maximum -> one atomic per workgroup
     unsigned kb = ordered_bits(best);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) kb = max(kb, (unsigned)__shfl_xor((int)kb, m, 64));
-    if ((tid & 63) == 0) atomicMax(&sMax, kb);
+    if (lane == 0) atomicMax(&sMax, kb);
     __syncthreads();
-    if (tid == 0) atomicMax(max_bits, sMax);
-}
-
-// Threshold + strict 3x3 maximum.  Threads run over the linear pixel index, so each wavefront
-// covers 64 consecutive pixels and owns exactly one 64-bit word of the corner bitmap (written by
-// lane 0, no atomics, every word written on every call).
-__global__ __launch_bounds__(256) void corner_nms_kernel(const float *__restrict__ R, int A, int B, int lo,
-                                                         float min_quality, const unsigned *__restrict__ max_bits,
-                                                         unsigned long long *__restrict__ bitmap)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int b = idx / A, a = idx - b * A;
-    bool corner = false;
-    if (idx < A * B && a >= lo && a < A - lo && b >= lo && b < B - lo) {
-        const float thr = min_quality * from_ordered_bits(*max_bits);
-        const float *c = R + idx;
-        const float r = c[0];
-        corner = r > thr && r > c[-1] && r > c[1] && r > c[-A] && r > c[A] && r > c[-A - 1] && r > c[-A + 1] &&
-                 r > c[A - 1] && r > c[A + 1];
-    }
-    const unsigned long long m = __ballot(corner);
-    if ((threadIdx.x & 63) == 0 && (idx & ~63) < A * B) bitmap[idx >> 6] = m;
-}
-
-// Ordered, deterministic compaction of the corner bitmap.  Thread t of workgroup g owns bitmap word
-// 256 g + t.  Every workgroup first sums the popcounts of all words before its own (a redundant
-// but cheap read of at most the whole bitmap from L2; no inter-workgroup hand-off), then scans its
-// own 256 counts, and every thread writes the corners of its word at their ranks: sub-pixel
-// position (x, y 1-based; swap_xy as in the tracker) and metric.  The last workgroup stores the
-// total.
-__global__ __launch_bounds__(256) void corner_emit_kernel(const float *__restrict__ R, int A, int B,
-                                                          const unsigned long long *__restrict__ bitmap, int cap,
-                                                          int swap_xy, float *__restrict__ xy_out,
-                                                          float *__restrict__ metric_out, int *__restrict__ count)
-{
-    __shared__ int sPre[4], sWave[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nwords = (A * B + 63) / 64;
-    const int first = blockIdx.x * 256;
-    int before = 0;
-    for (int w = tid; w < first; w += 256) before += __popcll(bitmap[w]);
+    if (tid == 0) atomicMax(max_now, sMax);
+    // strict 3x3 maxima of the tile, in pixel order: pixel q = 256 k + tid of the tile is (row q / 64,
+    // column q % 64), so wavefront `wave` of round k holds one tile row and the order is (k, wave, lane)
+    bool is_max[4];
+    unsigned long long bal[4];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) before += __shfl_xor(before, m, 64);
-    const int w = first + tid;
-    unsigned long long m = w < nwords ? bitmap[w] : 0ull;
-    const int c = __popcll(m);
-    int incl = c;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += t;
+    for (int k = 0; k < 4; ++k) {
+        const int rb = 4 * k + wave, ra = lane;
+        const int a = a0 + ra, b = b0 + rb;
+        bool m = false;
+        if (a >= lo && a < A - lo && b >= lo && b < B - lo) {
+            const float *c = sR + (rb + 1) * RA + (ra + 1);
+            const float r = c[0];
+            m = r > c[-1] && r > c[1] && r > c[-RA] && r > c[RA] && r > c[-RA - 1] && r > c[-RA + 1] && r > c[RA - 1] &&
+                r > c[RA + 1];
+        }
+        is_max[k] = m;
+        bal[k] = __ballot(m);
+        if (lane == 0) sCnt[4 * k + wave] = __popcll(bal[k]);
     }
-    if (lane == 63) sWave[wave] = incl;
-    if (lane == 0) sPre[wave] = before;
     __syncthreads();
-    int pos = sPre[0] + sPre[1] + sPre[2] + sPre[3] + incl - c;
-    for (int q = 0; q < wave; ++q) pos += sWave[q];
-    if (blockIdx.x == gridDim.x - 1 && tid == 255) *count = pos + c;
-    while (m) {
-        const int bit = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        if (pos < cap) {
-            const int key = w * 64 + bit;
-            const int b = key / A, a = key - b * A;
-            const float *cc = R + key;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    corner_rec *out = recs + (size_t)tile * TILE_CAP;
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int before = 0;
+        for (int w = 0; w < 4 * k + wave; ++w) before += sCnt[w];
+        if (is_max[k]) {
+            const int rb = 4 * k + wave, ra = lane;
+            const int a = a0 + ra, b = b0 + rb;
+            const float *cc = sR + (rb + 1) * RA + (ra + 1);
             const float r = cc[0];
             const float da = cc[1] - cc[-1], dda = (cc[1] - 2.0f * r) + cc[-1];
-            const float db = cc[A] - cc[-A], ddb = (cc[A] - 2.0f * r) + cc[-A];
+            const float db = cc[RA] - cc[-RA], ddb = (cc[RA] - 2.0f * r) + cc[-RA];
             float oa = dda < 0.0f ? -0.5f * da / dda : 0.0f;
             float ob = ddb < 0.0f ? -0.5f * db / ddb : 0.0f;
             oa = fminf(fmaxf(oa, -0.5f), 0.5f);
             ob = fminf(fmaxf(ob, -0.5f), 0.5f);
-            const float pa = (float)a + oa + 1.0f, pb = (float)b + ob + 1.0f;
-            xy_out[pos] = swap_xy ? pb : pa;
-            xy_out[cap + pos] = swap_xy ? pa : pb;
-            metric_out[pos] = r;
+            corner_rec rec;
+            rec.key = b * A + a;
+            rec.r = r;
+            rec.pa = (float)a + oa;
+            rec.pb = (float)b + ob;
+            out[before + __popcll(bal[k] & ((1ull << lane) - 1ull))] = rec;
         }
-        ++pos;
+    }
+    if (tid == 0) {
+        for (int w = 0; w < 16; ++w) total += sCnt[w];
+        tile_count[tile] = total;
+    }
+}
+
+// One workgroup per row of tiles (TB image rows).  Survivors of the quality threshold are written at
+// their rank in ascending pixel order: [survivors in earlier tile rows] + [survivors in the cells
+// (image row, tile) before the record's own cell] + [survivors before it in its own cell] -- within a
+// tile the records are in pixel order, so those of one image row are consecutive.
+__global__ __launch_bounds__(256) void corner_emit_kernel(const corner_rec *__restrict__ recs,
+                                                          const int *__restrict__ tile_count, int tiles_a, int A,
+                                                          float min_quality, const unsigned *__restrict__ max_bits,
+                                                          int cap, int swap_xy, float *__restrict__ xy_out,
+                                                          float *__restrict__ metric_out, int *__restrict__ count)
+{
+    __shared__ int sCell[TB * MAX_TILES_A];   // survivors per cell, then the exclusive prefix over the cells
+    __shared__ int sRed[4];
+    __shared__ int sRow[TB + 1];
+    __shared__ unsigned char sPass[TILE_CAP], sRb[TILE_CAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float thr = min_quality * from_ordered_bits(*max_bits);
+    const int first_tile = blockIdx.x * tiles_a;
+    const int b0 = blockIdx.x * TB;
+    // survivors in the tile rows before this one
+    int before = 0;
+    for (int t = tid; t < first_tile; t += 256) {
+        const int n = tile_count[t];
+        const corner_rec *r = recs + (size_t)t * TILE_CAP;
+        for (int j = 0; j < n; ++j) before += r[j].r > thr ? 1 : 0;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) before += __shfl_xor(before, m, 64);
+    if (lane == 0) sRed[wave] = before;
+    for (int q = tid; q < TB * tiles_a; q += 256) sCell[q] = 0;
+    __syncthreads();
+    const int base = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+    // survivors per cell (integer atomics in LDS: the sums do not depend on the order)
+    for (int tx = 0; tx < tiles_a; ++tx) {
+        const int n = tile_count[first_tile + tx];
+        if (tid < n) {
+            const corner_rec r = recs[(size_t)(first_tile + tx) * TILE_CAP + tid];
+            if (r.r > thr) atomicAdd(&sCell[(r.key / A - b0) * tiles_a + tx], 1);
+        }
+    }
+    __syncthreads();
+    // exclusive prefix over the cells in (image row, tile) order: one thread per image row sums its cells,
+    // thread 0 chains the rows, then every row thread turns its cells into offsets
+    if (tid < TB) {
+        int s = 0;
+        for (int tx = 0; tx < tiles_a; ++tx) s += sCell[tid * tiles_a + tx];
+        sRow[tid + 1] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        sRow[0] = 0;
+        for (int r = 0; r < TB; ++r) sRow[r + 1] += sRow[r];
+    }
+    __syncthreads();
+    if (tid < TB) {
+        int s = sRow[tid];
+        for (int tx = 0; tx < tiles_a; ++tx) {
+            const int c = sCell[tid * tiles_a + tx];
+            sCell[tid * tiles_a + tx] = s;
+            s += c;
+        }
+    }
+    __syncthreads();
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *count = base + sRow[TB];
+    for (int tx = 0; tx < tiles_a; ++tx) {
+        const int n = tile_count[first_tile + tx];
+        corner_rec r;
+        bool pass = false;
+        int rb = 0;
+        if (tid < n) {
+            r = recs[(size_t)(first_tile + tx) * TILE_CAP + tid];
+            pass = r.r > thr;
+            rb = r.key / A - b0;
+        }
+        __syncthreads();   // (the previous tile's flags have been read)
+        if (tid < TILE_CAP) {
+            sPass[tid] = pass ? 1 : 0;
+            sRb[tid] = tid < n ? (unsigned char)rb : 255;
+        }
+        __syncthreads();
+        if (pass) {
+            int within = 0;
+            for (int j = tid - 1; j >= 0 && sRb[j] == rb; --j) within += sPass[j];
+            const int pos = base + sCell[rb * tiles_a + tx] + within;
+            if (pos < cap) {
+                const float pa = r.pa + 1.0f, pb = r.pb + 1.0f;
+                xy_out[pos] = swap_xy ? pb : pa;
+                xy_out[cap + pos] = swap_xy ? pa : pb;
+                metric_out[pos] = r.r;
+            }
+        }
     }
 }
 
@@ -215,6 +299,46 @@ void gaussian_taps(int filter_size, float *w)
 
 }  // namespace
 
+size_t vohip_corner_scratch_bytes(int rows, int cols)
+{
+    // (the same for either storage order: the tile grid is transposed with the image)
+    const int ta = (rows + TA - 1) / TA, tb = (cols + TB - 1) / TB, ta2 = (cols + TA - 1) / TA, tb2 = (rows + TB - 1) / TB;
+    const size_t tiles = (size_t)ta * tb > (size_t)ta2 * tb2 ? (size_t)ta * tb : (size_t)ta2 * tb2;
+    return 256 + tiles * (sizeof(int) + TILE_CAP * sizeof(corner_rec));
+}
+
+// Corner detection on `stream` with caller-owned scratch memory: `scratch` holds
+// vohip_corner_scratch_bytes(rows, cols) bytes whose first 256 were zero before its first use; *calls
+// counts the uses of this scratch (the two maximum slots alternate: a call clears the other one).
+int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, unsigned *calls, const uint8_t *d_img,
+                                 int rows, int cols, int colmajor, double min_quality, int filter_size, int border,
+                                 int method, float *d_xy, float *d_metric, int cap, int *d_count)
+{
+    VOHIP_REQUIRE(ctx, d_img && d_xy && d_metric && d_count && scratch && calls, "NULL argument");
+    VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
+    VOHIP_REQUIRE(ctx, filter_size == FS, "only FilterSize 5 (the toolbox default) is built");
+    VOHIP_REQUIRE(ctx, method == 0 || method == 1, "method: 0 = Harris, 1 = MinEigen");
+    VOHIP_REQUIRE(ctx, cap >= 1 && cap <= 16384, "cap must be 1..16384");
+    VOHIP_REQUIRE(ctx, border >= 0, "negative border");
+    const int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
+    const int tiles_a = (A + TA - 1) / TA, tiles_b = (B + TB - 1) / TB;
+    VOHIP_REQUIRE(ctx, tiles_a <= MAX_TILES_A, "image wider than 8192 pixels along its fast axis");
+    unsigned *max2 = (unsigned *)scratch;
+    int *tile_count = (int *)((char *)scratch + 256);
+    corner_rec *recs = (corner_rec *)((char *)scratch + 256 + ((sizeof(int) * (size_t)tiles_a * tiles_b + 255) / 256) * 256);
+    const unsigned slot = (*calls)++ & 1u;
+    taps5 G;
+    gaussian_taps(filter_size, G.w);
+    const int lo = border < 1 ? 1 : border;
+    hipLaunchKernelGGL(corner_tile_kernel, dim3(tiles_a, tiles_b), dim3(256), 0, st, d_img, A, B, G, method, lo, recs,
+                       tile_count, max2 + slot, max2 + (slot ^ 1u));
+    hipLaunchKernelGGL(corner_emit_kernel, dim3(tiles_b), dim3(256), 0, st, (const corner_rec *)recs,
+                       (const int *)tile_count, tiles_a, A, (float)min_quality, (const unsigned *)(max2 + slot), cap,
+                       colmajor ? 1 : 0, d_xy, d_metric, d_count);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
 extern "C" {
 
 // d_xy: cap x 2 floats (x column then y column), d_metric: cap floats, d_count: 1 int (total
@@ -224,31 +348,15 @@ int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int
                              float *d_metric, int cap, int *d_count)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
-    VOHIP_REQUIRE(ctx, d_img && d_xy && d_metric && d_count, "NULL argument");
     VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
-    VOHIP_REQUIRE(ctx, filter_size == FS, "only FilterSize 5 (the toolbox default) is built");
-    VOHIP_REQUIRE(ctx, method == 0 || method == 1, "method: 0 = Harris, 1 = MinEigen");
-    VOHIP_REQUIRE(ctx, cap >= 1 && cap <= 16384, "cap must be 1..16384");
-    VOHIP_REQUIRE(ctx, border >= 0, "negative border");
-    const int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
-    void *d_R, *d_bitmap, *d_max;
-    const int nwords = (A * B + 63) / 64;
-    VOHIP_TRY(vohip_upload(ctx, B_HARRIS_R, nullptr, sizeof(float) * (size_t)A * B, &d_R));
-    VOHIP_TRY(vohip_upload(ctx, B_HARRIS_KEYS, nullptr, sizeof(unsigned long long) * (size_t)nwords, &d_bitmap));
-    VOHIP_TRY(vohip_upload(ctx, B_HARRIS_MAX, nullptr, 256, &d_max));
-    taps5 G;
-    gaussian_taps(filter_size, G.w);
-    hipStream_t st = ctx->stream;
-    VOHIP_HIP(ctx, hipMemsetAsync(d_max, 0, 256, st));
-    hipLaunchKernelGGL(corner_response_kernel, dim3((A + TA - 1) / TA, (B + TB - 1) / TB), dim3(256), 0, st, d_img, A,
-                       B, G, method, (float *)d_R, (unsigned *)d_max);
-    const int lo = border < 1 ? 1 : border;
-    hipLaunchKernelGGL(corner_nms_kernel, dim3((A * B + 255) / 256), dim3(256), 0, st, (const float *)d_R, A, B, lo,
-                       (float)min_quality, (const unsigned *)d_max, (unsigned long long *)d_bitmap);
-    hipLaunchKernelGGL(corner_emit_kernel, dim3((nwords + 255) / 256), dim3(256), 0, st, (const float *)d_R, A, B,
-                       (const unsigned long long *)d_bitmap, cap, colmajor ? 1 : 0, d_xy, d_metric, d_count);
-    VOHIP_HIP(ctx, hipGetLastError());
-    return VOHIP_OK;
+    const size_t bytes = vohip_corner_scratch_bytes(rows, cols) + 256;
+    vohip_buf &b = ctx->bufs[B_HARRIS_SCRATCH];
+    if (!b.ptr || b.cap < bytes) {   // (a new allocation: its maximum slots start at zero)
+        VOHIP_TRY(vohip_reserve(ctx, b, bytes));
+        VOHIP_HIP(ctx, hipMemsetAsync(b.ptr, 0, 256, ctx->stream));
+    }
+    return vohip_detect_corners_enqueue(ctx, ctx->stream, b.ptr, &ctx->harris_calls, d_img, rows, cols, colmajor,
+                                        min_quality, filter_size, border, method, d_xy, d_metric, cap, d_count);
 }
 
 int vohip_detect_corners(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double min_quality,

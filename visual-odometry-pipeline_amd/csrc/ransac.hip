@@ -753,16 +753,15 @@ int launch_count(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n
 
 }  // namespace
 
-// Solve + score hypotheses [first, first + h) of the context's pose buffers (which must already be
-// reserved for first + h hypotheses) for points whose count may live on the device.
+// Solve + score hypotheses [first, first + h) for points whose count may live on the device.
 int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
-                         const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts)
+                         const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts,
+                         double *d_Rt_all, double *d_M_all)
 {
-    VOHIP_REQUIRE(ctx, (size_t)(first + h) * 48 * sizeof(double) <= ctx->bufs[B_RANSAC_RT].cap &&
-                           (size_t)(first + h) * 48 * sizeof(double) <= ctx->bufs[B_RANSAC_M].cap,
-                  "pose buffers not reserved for this many hypotheses");
-    double *d_Rt = (double *)ctx->bufs[B_RANSAC_RT].ptr + (size_t)first * 48;
-    double *d_M = (double *)ctx->bufs[B_RANSAC_M].ptr + (size_t)first * 48;
+    // the candidate poses go to the caller's arrays (48 doubles per hypothesis each, hypothesis 0 first)
+    VOHIP_REQUIRE(ctx, d_Rt_all && d_M_all, "NULL pose buffers");
+    double *d_Rt = d_Rt_all + (size_t)first * 48;
+    double *d_M = d_M_all + (size_t)first * 48;
     const vohip_K Kv = vohip_make_K(K);
     // few hypotheses: several wavefronts share each (their partial counts are added to counts the solve
     // kernel cleared); many: one wavefront per hypothesis over LDS-staged tiles
@@ -778,7 +777,6 @@ int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
     } else {
         VOHIP_TRY(launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, h, d_counts + 4 * (size_t)first, d_n));
     }
-    if (ctx->ransac_h < first + h) ctx->ransac_h = first + h;
     return VOHIP_OK;
 }
 

@@ -31,7 +31,7 @@ enum vohip_buf_id {
     B_STAGE0, B_STAGE1, B_STAGE2, B_STAGE3, B_STAGE4, B_STAGE5, B_STAGE6, B_STAGE7,
     H_STAGE0, H_STAGE1, H_STAGE2, H_STAGE3,
     B_IMG_STAGE,
-    B_HARRIS_R, B_HARRIS_KEYS, B_HARRIS_MAX,
+    B_HARRIS_SCRATCH,
     B_FM_NRM, B_FM_F, B_FM_COUNTS, H_FM_COUNTS,
     B_BA_INDEX, B_BA_FRAME, B_BA_LM, B_BA_UV, B_BA_COUNT, B_BA_STATE, B_BA_TRIAL, B_BA_SPART, B_BA_GPART,
     B_BA_E, B_BA_GL, B_BA_W, B_BA_DP, B_BA_PART, B_BA_STATUS, H_BA_STATUS,
@@ -60,6 +60,7 @@ struct vohip_ctx {
     int ransac_h = 0;  // hypotheses held by B_RANSAC_RT / B_RANSAC_M
     int opt_ransac_variant = -1;  // scoring-kernel geometry, see vohip_set_option
     int opt_klt_stats = 0;        // count tracker work (two atomics per track), see vohip_klt_stats
+    unsigned harris_calls = 0;    // uses of B_HARRIS_SCRATCH (its two maximum slots alternate)
 };
 
 int vohip_fail(vohip_ctx *ctx, int status, const char *fmt, ...);
@@ -127,7 +128,8 @@ struct vohip_klt_set {
 int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vohip_klt_set *sets, int nsets,
                            int block_size, int max_iter, double max_bidir_error);
 int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
-                         const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts);
+                         const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts,
+                         double *d_Rt_all, double *d_M_all);
 int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                               const double *d_M12, uint8_t *d_mask);
 double vohip_ransac_adaptive_iterations(int max_num_inliers, int n);
@@ -143,6 +145,10 @@ int vohip_candidate_triangulate_enqueue(vohip_ctx *ctx, const double *d_cur_rc, 
                                         const double *d_T_first, int n_cap, const int *d_n, const double *d_T_W_C,
                                         const double K[9], double angle_threshold_deg, double min_depth,
                                         double max_depth, int is_BA, uint8_t *d_status, double *d_X);
+size_t vohip_corner_scratch_bytes(int rows, int cols);
+int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, unsigned *calls, const uint8_t *d_img,
+                                 int rows, int cols, int colmajor, double min_quality, int filter_size, int border,
+                                 int method, float *d_xy, float *d_metric, int cap, int *d_count);
 int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, const double *d_X, int n,
                               const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
                               double *d_stats);

@@ -81,6 +81,7 @@ class VOPipelineDevice:
         self._keep_images = (keep, None)
         self._next_image = None
         self._u8_ahead = None
+        self._pending = None
         self.est_trans = [T[:3, 3].copy()]
         self.est_rot = [T[:3, :3].reshape(-1, order="F").copy()]
         self.num_X, self.num_C, self.num_new = [X.shape[0]], [0], [0]
@@ -110,7 +111,15 @@ class VOPipelineDevice:
         """One frame of the loop (main_demo.m:377-427).  next_image: the frame after this one, when the
         caller already holds it (a stored sequence): its transfer, pyramid and corner detection then run
         beside this frame's localisation; the results do not change, and the next call must pass that image."""
+        self.begin_frame(image, next_image)
+        return self.finish_frame()
+
+    def begin_frame(self, image, next_image=None):
+        """First half of process_frame: enqueues the frame on the GPU and returns at once (several loops
+        that share a context or a GPU can have their frames in flight together)."""
         lib = _lib.load()
+        if self._pending is not None:
+            raise RuntimeError("a frame is already in flight: finish_frame() first")
         if self._next_image is not None:
             if image is not self._next_image[0]:
                 # the library has that image's pyramid, corners and trackers under way already
@@ -120,7 +129,6 @@ class VOPipelineDevice:
             ptr, on_dev, keep = self._image_ptr(image)
         nptr, non_dev, nkeep = self._image_ptr(next_image) if next_image is not None else (None, 0, None)
         self._next_image = (next_image, (nptr, non_dev, nkeep)) if next_image is not None else None
-        pose, counts = _lib.FramePose(), _lib.FrameCounts()
         have_map = self.num_C[-1] > 0                                                       # :406
         u8 = None
         if have_map:                                                                        # update_landmarks.m:13
@@ -135,6 +143,16 @@ class VOPipelineDevice:
         # of the localisation's; they are given back if the next frame turns out to have no candidates)
         state_map = self.rng_map.bit_generator.state
         u8_ahead = self.rng_map.random((self.params.fm_trials, 8))
+        self._pending = (state, have, have_map, state_map, u8_ahead, keep, nkeep)
+
+    def finish_frame(self):
+        """Second half of process_frame: waits for the frame and returns T_W_C."""
+        lib = _lib.load()
+        if self._pending is None:
+            raise RuntimeError("no frame is in flight: begin_frame() first")
+        state, have, have_map, state_map, u8_ahead, keep, nkeep = self._pending
+        self._pending = None
+        pose, counts = _lib.FramePose(), _lib.FrameCounts()
         st = lib.vohip_frame_finish(self._h, C.byref(pose), C.byref(counts))
         while st == VOHIP_SAMPLES_EXHAUSTED and have < MAX_ITERATIONS:
             have = min(max(8 * have, int(np.ceil(pose.num_iterations)) + 8), MAX_ITERATIONS)
