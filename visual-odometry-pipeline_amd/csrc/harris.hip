@@ -16,10 +16,10 @@
 //                        index, response, sub-pixel position) in the tile's own list, in pixel order
 //                        (ballot compaction, no atomics); tile maximum -> one atomicMax per workgroup.
 //                        fp32, evaluated in a fixed order without FMA contraction (bit-reproducible).
-//   corner_emit_kernel   one workgroup per row of tiles: applies R > MinQuality * max(R) to the records
-//                        and writes the survivors in ascending pixel order (counts per (image row, tile)
-//                        cell in LDS, prefix over the cells, survivors of earlier tile rows counted from
-//                        their records): ordered and deterministic.
+//   corner_count_kernel  one wavefront per tile: applies R > MinQuality * max(R) to the tile's records and
+//                        counts the survivors per (tile, image row) cell.
+//   corner_emit_kernel   one wavefront per tile: prefix over the cells in pixel order, then the survivors
+//                        go to their ranks: ordered and deterministic, no atomics.
 // Per image: the uint8 image is read once (plus the halos), ~16 bytes are written and read per local
 // maximum and 12 bytes written per corner.
 #include "vohip_internal.h"
@@ -33,7 +33,6 @@ constexpr int RA = TA + 2, RB = TB + 2;                        // response tile:
 constexpr int PA = RA + 2 * HALF, PB = RB + 2 * HALF;          // gradient-product tile
 constexpr int IA = PA + 2, IB = PB + 2;                        // staged image tile
 constexpr int TILE_CAP = TA * TB / 4;                          // strict 3x3 maxima cannot touch: at most one per 2x2
-constexpr int MAX_TILES_A = 128;                               // tiles along the fast axis the emit kernel handles
 
 struct taps5 {
     float w[FS];
@@ -189,95 +188,112 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restr
     }
 }
 
-// One workgroup per row of tiles (TB image rows).  Survivors of the quality threshold are written at
-// their rank in ascending pixel order: [survivors in earlier tile rows] + [survivors in the cells
-// (image row, tile) before the record's own cell] + [survivors before it in its own cell] -- within a
-// tile the records are in pixel order, so those of one image row are consecutive.
-__global__ __launch_bounds__(256) void corner_emit_kernel(const corner_rec *__restrict__ recs,
-                                                          const int *__restrict__ tile_count, int tiles_a, int A,
-                                                          float min_quality, const unsigned *__restrict__ max_bits,
-                                                          int cap, int swap_xy, float *__restrict__ xy_out,
-                                                          float *__restrict__ metric_out, int *__restrict__ count)
+// Survivors of the quality threshold per cell (tile, image row): one wavefront per tile.  cells: 16 ints
+// per tile, totals: one int per tile.
+__global__ __launch_bounds__(256) void corner_count_kernel(const corner_rec *__restrict__ recs,
+                                                           const int *__restrict__ tile_count, int ntiles, int tiles_a,
+                                                           int A, float min_quality,
+                                                           const unsigned *__restrict__ max_bits,
+                                                           int *__restrict__ cells, int *__restrict__ totals)
 {
-    __shared__ int sCell[TB * MAX_TILES_A];   // survivors per cell, then the exclusive prefix over the cells
-    __shared__ int sRed[4];
-    __shared__ int sRow[TB + 1];
-    __shared__ unsigned char sPass[TILE_CAP], sRb[TILE_CAP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
     const float thr = min_quality * from_ordered_bits(*max_bits);
-    const int first_tile = blockIdx.x * tiles_a;
-    const int b0 = blockIdx.x * TB;
-    // survivors in the tile rows before this one
-    int before = 0;
-    for (int t = tid; t < first_tile; t += 256) {
-        const int n = tile_count[t];
-        const corner_rec *r = recs + (size_t)t * TILE_CAP;
-        for (int j = 0; j < n; ++j) before += r[j].r > thr ? 1 : 0;
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) before += __shfl_xor(before, m, 64);
-    if (lane == 0) sRed[wave] = before;
-    for (int q = tid; q < TB * tiles_a; q += 256) sCell[q] = 0;
-    __syncthreads();
-    const int base = sRed[0] + sRed[1] + sRed[2] + sRed[3];
-    // survivors per cell (integer atomics in LDS: the sums do not depend on the order)
-    for (int tx = 0; tx < tiles_a; ++tx) {
-        const int n = tile_count[first_tile + tx];
-        if (tid < n) {
-            const corner_rec r = recs[(size_t)(first_tile + tx) * TILE_CAP + tid];
-            if (r.r > thr) atomicAdd(&sCell[(r.key / A - b0) * tiles_a + tx], 1);
-        }
-    }
-    __syncthreads();
-    // exclusive prefix over the cells in (image row, tile) order: one thread per image row sums its cells,
-    // thread 0 chains the rows, then every row thread turns its cells into offsets
-    if (tid < TB) {
-        int s = 0;
-        for (int tx = 0; tx < tiles_a; ++tx) s += sCell[tid * tiles_a + tx];
-        sRow[tid + 1] = s;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        sRow[0] = 0;
-        for (int r = 0; r < TB; ++r) sRow[r + 1] += sRow[r];
-    }
-    __syncthreads();
-    if (tid < TB) {
-        int s = sRow[tid];
-        for (int tx = 0; tx < tiles_a; ++tx) {
-            const int c = sCell[tid * tiles_a + tx];
-            sCell[tid * tiles_a + tx] = s;
-            s += c;
-        }
-    }
-    __syncthreads();
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) *count = base + sRow[TB];
-    for (int tx = 0; tx < tiles_a; ++tx) {
-        const int n = tile_count[first_tile + tx];
-        corner_rec r;
+    const int b0 = (t / tiles_a) * TB;
+    const int n = tile_count[t];
+    int mine = 0, total = 0;   // lane k < 16 collects the count of image row k
+    for (int c = 0; c < n; c += 64) {
         bool pass = false;
-        int rb = 0;
-        if (tid < n) {
-            r = recs[(size_t)(first_tile + tx) * TILE_CAP + tid];
+        int rb = -1;
+        if (c + lane < n) {
+            const corner_rec r = recs[(size_t)t * TILE_CAP + c + lane];
             pass = r.r > thr;
             rb = r.key / A - b0;
         }
-        __syncthreads();   // (the previous tile's flags have been read)
-        if (tid < TILE_CAP) {
-            sPass[tid] = pass ? 1 : 0;
-            sRb[tid] = tid < n ? (unsigned char)rb : 255;
+#pragma unroll
+        for (int k = 0; k < TB; ++k) {
+            const int cnt = __popcll(__ballot(pass && rb == k));
+            if (lane == k) mine += cnt;
+            total += cnt;
         }
-        __syncthreads();
-        if (pass) {
-            int within = 0;
-            for (int j = tid - 1; j >= 0 && sRb[j] == rb; --j) within += sPass[j];
-            const int pos = base + sCell[rb * tiles_a + tx] + within;
-            if (pos < cap) {
-                const float pa = r.pa + 1.0f, pb = r.pb + 1.0f;
-                xy_out[pos] = swap_xy ? pb : pa;
-                xy_out[cap + pos] = swap_xy ? pa : pb;
-                metric_out[pos] = r.r;
-            }
+    }
+    if (lane < TB) cells[(size_t)t * TB + lane] = mine;
+    if (lane == 0) totals[t] = total;
+}
+
+// One wavefront per tile writes the tile's survivors at their ranks in ascending pixel order: [survivors
+// in earlier rows of tiles] + [survivors in the cells (image row, tile) before the record's cell in this
+// row of tiles] + [survivors before it in its own cell] -- within a tile the records are in pixel order,
+// so those of one image row are consecutive.  Ordered and deterministic; no atomics.
+__global__ __launch_bounds__(256) void corner_emit_kernel(const corner_rec *__restrict__ recs,
+                                                          const int *__restrict__ tile_count,
+                                                          const int *__restrict__ cells,
+                                                          const int *__restrict__ totals, int ntiles, int tiles_a,
+                                                          int A, float min_quality,
+                                                          const unsigned *__restrict__ max_bits, int cap, int swap_xy,
+                                                          float *__restrict__ xy_out, float *__restrict__ metric_out,
+                                                          int *__restrict__ count)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= ntiles) return;
+    const float thr = min_quality * from_ordered_bits(*max_bits);
+    const int ty = t / tiles_a, tx = t - ty * tiles_a;
+    const int b0 = ty * TB;
+    // survivors in the rows of tiles before this one
+    int base = 0;
+    for (int q = lane; q < ty * tiles_a; q += 64) base += totals[q];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) base += __shfl_xor(base, m, 64);
+    // this row of tiles: lanes 4 rb .. 4 rb + 3 share image row rb; `full` = survivors of the whole image
+    // row, `part` = those in the tiles before this one
+    const int rb_l = lane >> 2, sub = lane & 3;
+    int full = 0, part = 0;
+    for (int x = sub; x < tiles_a; x += 4) {
+        const int v = cells[((size_t)ty * tiles_a + x) * TB + rb_l];
+        full += v;
+        part += x < tx ? v : 0;
+    }
+    full += __shfl_xor(full, 1, 64);
+    full += __shfl_xor(full, 2, 64);
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    int incl = full;   // inclusive prefix over the image rows (lanes with the same `sub` hold the same values)
+#pragma unroll
+    for (int d = 4; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    const int offset = base + (incl - full) + part;   // rank of the first survivor of cell (rb_l, tx)
+    if (t == ntiles - 1 && lane == 63) *count = base + incl;
+    const int n = tile_count[t];
+    int run = 0;   // lane k < 16: survivors of image row k in the chunks done so far
+    for (int c = 0; c < n; c += 64) {
+        corner_rec r;
+        bool pass = false;
+        int rb = -1;
+        if (c + lane < n) {
+            r = recs[(size_t)t * TILE_CAP + c + lane];
+            pass = r.r > thr;
+            rb = r.key / A - b0;
+        }
+        unsigned long long same = 0ull;
+        int run_next = run;
+#pragma unroll
+        for (int k = 0; k < TB; ++k) {
+            const unsigned long long b = __ballot(pass && rb == k);
+            if (rb == k) same = b;
+            if (lane == k) run_next += __popcll(b);
+        }
+        const int rbc = rb < 0 ? 0 : rb;
+        const int pos = __shfl(offset, 4 * rbc, 64) + __shfl(run, rbc, 64) + __popcll(same & ((1ull << lane) - 1ull));
+        run = run_next;
+        if (pass && pos < cap) {
+            const float pa = r.pa + 1.0f, pb = r.pb + 1.0f;
+            xy_out[pos] = swap_xy ? pb : pa;
+            xy_out[cap + pos] = swap_xy ? pa : pb;
+            metric_out[pos] = r.r;
         }
     }
 }
@@ -304,7 +320,7 @@ size_t vohip_corner_scratch_bytes(int rows, int cols)
     // (the same for either storage order: the tile grid is transposed with the image)
     const int ta = (rows + TA - 1) / TA, tb = (cols + TB - 1) / TB, ta2 = (cols + TA - 1) / TA, tb2 = (rows + TB - 1) / TB;
     const size_t tiles = (size_t)ta * tb > (size_t)ta2 * tb2 ? (size_t)ta * tb : (size_t)ta2 * tb2;
-    return 256 + tiles * (sizeof(int) + TILE_CAP * sizeof(corner_rec));
+    return 1024 + tiles * ((2 + TB) * sizeof(int) + TILE_CAP * sizeof(corner_rec));
 }
 
 // Corner detection on `stream` with caller-owned scratch memory: `scratch` holds
@@ -322,19 +338,29 @@ int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, 
     VOHIP_REQUIRE(ctx, border >= 0, "negative border");
     const int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
     const int tiles_a = (A + TA - 1) / TA, tiles_b = (B + TB - 1) / TB;
-    VOHIP_REQUIRE(ctx, tiles_a <= MAX_TILES_A, "image wider than 8192 pixels along its fast axis");
     unsigned *max2 = (unsigned *)scratch;
-    int *tile_count = (int *)((char *)scratch + 256);
-    corner_rec *recs = (corner_rec *)((char *)scratch + 256 + ((sizeof(int) * (size_t)tiles_a * tiles_b + 255) / 256) * 256);
+    const int ntiles = tiles_a * tiles_b;
+    auto round256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    char *p = (char *)scratch + 256;
+    int *tile_count = (int *)p;
+    p += round256(sizeof(int) * (size_t)ntiles);
+    int *totals = (int *)p;
+    p += round256(sizeof(int) * (size_t)ntiles);
+    int *cells = (int *)p;
+    p += round256(sizeof(int) * (size_t)ntiles * TB);
+    corner_rec *recs = (corner_rec *)p;
     const unsigned slot = (*calls)++ & 1u;
     taps5 G;
     gaussian_taps(filter_size, G.w);
     const int lo = border < 1 ? 1 : border;
     hipLaunchKernelGGL(corner_tile_kernel, dim3(tiles_a, tiles_b), dim3(256), 0, st, d_img, A, B, G, method, lo, recs,
                        tile_count, max2 + slot, max2 + (slot ^ 1u));
-    hipLaunchKernelGGL(corner_emit_kernel, dim3(tiles_b), dim3(256), 0, st, (const corner_rec *)recs,
-                       (const int *)tile_count, tiles_a, A, (float)min_quality, (const unsigned *)(max2 + slot), cap,
-                       colmajor ? 1 : 0, d_xy, d_metric, d_count);
+    hipLaunchKernelGGL(corner_count_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, (const corner_rec *)recs,
+                       (const int *)tile_count, ntiles, tiles_a, A, (float)min_quality, (const unsigned *)(max2 + slot),
+                       cells, totals);
+    hipLaunchKernelGGL(corner_emit_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, (const corner_rec *)recs,
+                       (const int *)tile_count, (const int *)cells, (const int *)totals, ntiles, tiles_a, A,
+                       (float)min_quality, (const unsigned *)(max2 + slot), cap, colmajor ? 1 : 0, d_xy, d_metric, d_count);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
