@@ -157,6 +157,7 @@ __device__ __forceinline__ bool inv3_sym(const double V[3][3], double E[3][3])
 struct ba_status {
     double cost, cost_trial, lambda, step_norm2, x_norm2, cost0;
     int iter, rejects, done, solve_failed, accepted_last, trials;
+    int cur;   // which of the two state buffers holds the current estimate (the other one takes the trial step)
 };
 
 struct ba_problem {
@@ -228,14 +229,15 @@ __global__ __launch_bounds__(256) void ba_init_status_kernel(const double *__res
         st->cost = st->cost0 = c;
         st->cost_trial = 0.0;
         st->lambda = 1e-3;
-        st->iter = st->rejects = st->done = st->solve_failed = st->accepted_last = st->trials = 0;
+        st->iter = st->rejects = st->done = st->solve_failed = st->accepted_last = st->trials = st->cur = 0;
         st->step_norm2 = st->x_norm2 = 0.0;
     }
 }
 
 // LDS layout of ba_linearize_kernel (dynamic): per (local landmark, frame) slot
 //   Jp 12, r 2, W 18, Y 18 doubles; per landmark E 9, gl 3; frames.
-__global__ __launch_bounds__(256) void ba_linearize_kernel(ba_problem P, const double *__restrict__ state,
+__global__ __launch_bounds__(256) void ba_linearize_kernel(ba_problem P, const double *__restrict__ X0,
+                                                           const double *__restrict__ X1,
                                                            const ba_status *__restrict__ st,
                                                            double *__restrict__ S_part, double *__restrict__ g_part,
                                                            double *__restrict__ E_out, double *__restrict__ gl_out,
@@ -251,6 +253,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(ba_problem P, const d
     double *sE = sY + LT * F * 18;                                      // [LT][9]
     double *sGl = sE + LT * 9;                                          // [LT][3]
     if (st->done) return;
+    const double *__restrict__ state = st->cur ? X1 : X0;
     const double lambda = st->lambda;
     if (tid < F) {
         double tw[6];
@@ -412,23 +415,47 @@ __device__ __forceinline__ bool cholesky_solve_rows(double *S, const double *g, 
     return __builtin_amdgcn_ballot_w64(!pos) == 0;
 }
 
-// sum of the partial systems' entries e, in workgroup order; eight loads are in flight at a time
+// sum of the partial systems' entries e, in workgroup order; sixteen loads are in flight at a time
 __device__ __forceinline__ double ordered_partial_sum(const double *__restrict__ part, size_t stride, int nblocks, int e)
 {
     double acc = 0.0;
     int b = 0;
-    for (; b + 8 <= nblocks; b += 8) {
-        double v[8];
+    for (; b + 16 <= nblocks; b += 16) {
+        double v[16];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(b + q) * stride + e];
+        for (int q = 0; q < 16; ++q) v[q] = part[(size_t)(b + q) * stride + e];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc += v[q];
+        for (int q = 0; q < 16; ++q) acc += v[q];
     }
     for (; b < nblocks; ++b) acc += part[(size_t)b * stride + e];
     return acc;
 }
 
-__global__ __launch_bounds__(256) void ba_solve_kernel(int np, int nblocks, const double *__restrict__ S_part,
+// First stage of the ordered sum when there are many partial systems (one per 16 landmarks): workgroup r
+// adds the systems of a contiguous range of `chunk` workgroups, in order, entry by entry, so that the
+// single workgroup that solves reads RED_GROUPS systems instead of hundreds (it is bound by what one
+// compute unit can load: 318 systems of 900 doubles took 64 us).
+constexpr int RED_GROUPS = 32;
+constexpr int RED_FROM = 64;   // fewer partial systems than this are summed by the solving workgroup itself
+
+__global__ __launch_bounds__(1024) void ba_reduce_kernel(int np, int nblocks, int chunk, const double *__restrict__ S_part,
+                                                         const double *__restrict__ g_part,
+                                                         const ba_status *__restrict__ st, double *__restrict__ S_red,
+                                                         double *__restrict__ g_red)
+{
+    if (st->done) return;
+    const int first = blockIdx.x * chunk;
+    const int count = min(chunk, nblocks - first);
+    const size_t n2 = (size_t)np * np;
+    for (int e = threadIdx.x; e < np * np; e += blockDim.x)
+        S_red[blockIdx.x * n2 + e] = count > 0 ? ordered_partial_sum(S_part + first * n2, n2, count, e) : 0.0;
+    for (int e = threadIdx.x; e < np; e += blockDim.x)
+        g_red[(size_t)blockIdx.x * np + e] = count > 0 ? ordered_partial_sum(g_part + (size_t)first * np, (size_t)np, count, e) : 0.0;
+}
+
+// 1024 threads: every entry of the reduced system (900 at 5 frames) has a thread of its own for the ordered
+// sum over the partial systems, which is what this kernel's time is (one wavefront then factorises).
+__global__ __launch_bounds__(1024) void ba_solve_kernel(int np, int nblocks, const double *__restrict__ S_part,
                                                        const double *__restrict__ g_part, ba_status *__restrict__ st,
                                                        const int *__restrict__ fail_flag, double *__restrict__ dp)
 {
@@ -462,12 +489,12 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(int np, int nblocks, cons
 }
 
 // Back-substitution, trial state and its cost.  One thread per landmark.
-__global__ __launch_bounds__(256) void ba_update_kernel(ba_problem P, const double *__restrict__ state,
+__global__ __launch_bounds__(256) void ba_update_kernel(ba_problem P, double *__restrict__ X0, double *__restrict__ X1,
                                                         const double *__restrict__ dp,
                                                         const double *__restrict__ E_in,
                                                         const double *__restrict__ gl_in,
                                                         const double *__restrict__ W_in,
-                                                        const ba_status *__restrict__ st, double *__restrict__ trial,
+                                                        const ba_status *__restrict__ st,
                                                         double *__restrict__ partial /* 3 per block */)
 {
     __shared__ frame_lin sF[FMAX];
@@ -475,6 +502,8 @@ __global__ __launch_bounds__(256) void ba_update_kernel(ba_problem P, const doub
     __shared__ double sRed[3][256];
     const int F = P.F, np = 6 * F, tid = threadIdx.x;
     if (st->done || st->solve_failed) return;
+    const double *__restrict__ state = st->cur ? X1 : X0;   // the trial state goes to the other buffer
+    double *__restrict__ trial = st->cur ? X0 : X1;
     if (tid < np) sdp[tid] = dp[tid];
     __syncthreads();
     if (tid < F) {
@@ -535,18 +564,15 @@ __global__ __launch_bounds__(256) void ba_update_kernel(ba_problem P, const doub
         for (int q = 0; q < 3; ++q) partial[3 * blockIdx.x + q] = sRed[q][0];
 }
 
-__global__ __launch_bounds__(256) void ba_decide_kernel(int nx, int nblocks, const double *__restrict__ partial,
-                                                        const double *__restrict__ trial, double *__restrict__ state,
-                                                        ba_status *__restrict__ st, int *__restrict__ fail_flag,
-                                                        int max_iter, double ftol, double xtol)
+// One thread.  An accepted step is not copied anywhere: the two state buffers change roles.
+__global__ __launch_bounds__(64) void ba_decide_kernel(int nblocks, const double *__restrict__ partial,
+                                                       ba_status *__restrict__ st, int *__restrict__ fail_flag,
+                                                       int max_iter, double ftol, double xtol)
 {
-    __shared__ int accept, was_done;
-    if (threadIdx.x == 0) was_done = st->done;
-    __syncthreads();
-    if (was_done) return;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x != 0 || st->done) return;
+    int accept = 0;
+    {
         st->trials++;
-        accept = 0;
         bool finished = false;
         if (st->solve_failed) {
             st->lambda *= 10.0;
@@ -577,12 +603,10 @@ __global__ __launch_bounds__(256) void ba_decide_kernel(int nx, int nblocks, con
             }
         }
         st->accepted_last = accept;
+        if (accept) st->cur ^= 1;
         st->done = finished ? 1 : 0;
         *fail_flag = 0;
     }
-    __syncthreads();
-    if (accept)
-        for (int i = threadIdx.x; i < nx; i += 256) state[i] = trial[i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -897,6 +921,13 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
     VOHIP_TRY(vohip_upload(ctx, B_BA_GL, nullptr, sizeof(double) * 3 * (size_t)(m > 0 ? m : 1), &d_gl));
     VOHIP_TRY(vohip_upload(ctx, B_BA_W, nullptr, sizeof(double) * 18 * (size_t)o.nobs, &d_W));
     VOHIP_TRY(vohip_upload(ctx, B_BA_DP, nullptr, sizeof(double) * 6 * FMAX, &d_dp));
+    const bool two_stage = nb_lin >= RED_FROM;
+    const int red_chunk = (nb_lin + RED_GROUPS - 1) / RED_GROUPS;
+    void *d_Sr = nullptr, *d_gr = nullptr;
+    if (two_stage) {
+        VOHIP_TRY(vohip_upload(ctx, B_BA_SRED, nullptr, sizeof(double) * (size_t)RED_GROUPS * np * np, &d_Sr));
+        VOHIP_TRY(vohip_upload(ctx, B_BA_GRED, nullptr, sizeof(double) * (size_t)RED_GROUPS * np, &d_gr));
+    }
     const int nb_part = nb_upd > nb_cost ? nb_upd : nb_cost;
     VOHIP_TRY(vohip_upload(ctx, B_BA_PART, nullptr, sizeof(double) * 3 * (size_t)nb_part, &d_part));
     VOHIP_TRY(vohip_upload(ctx, B_BA_STATUS, nullptr, 512, &d_st));
@@ -914,16 +945,23 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
     const int max_trials = max_iter + 12 * (max_iter + 1);
     for (int trial = 0; trial < max_trials; ++trial) {
         hipLaunchKernelGGL(ba_linearize_kernel, dim3(nb_lin), dim3(256), lds_lin, s, P, (const double *)d_state,
-                           (const ba_status *)d_st, (double *)d_Sp, (double *)d_gp, (double *)d_E, (double *)d_gl,
-                           (double *)d_W, (int *)d_fail);
-        hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), 0, s, np, nb_lin, (const double *)d_Sp,
-                           (const double *)d_gp, (ba_status *)d_st, (const int *)d_fail, (double *)d_dp);
-        hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, s, P, (const double *)d_state,
+                           (const double *)d_trial, (const ba_status *)d_st, (double *)d_Sp, (double *)d_gp, (double *)d_E,
+                           (double *)d_gl, (double *)d_W, (int *)d_fail);
+        if (two_stage) {
+            hipLaunchKernelGGL(ba_reduce_kernel, dim3(RED_GROUPS), dim3(1024), 0, s, np, nb_lin, red_chunk,
+                               (const double *)d_Sp, (const double *)d_gp, (const ba_status *)d_st, (double *)d_Sr,
+                               (double *)d_gr);
+            hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(1024), 0, s, np, RED_GROUPS, (const double *)d_Sr,
+                               (const double *)d_gr, (ba_status *)d_st, (const int *)d_fail, (double *)d_dp);
+        } else {
+            hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(1024), 0, s, np, nb_lin, (const double *)d_Sp,
+                               (const double *)d_gp, (ba_status *)d_st, (const int *)d_fail, (double *)d_dp);
+        }
+        hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, s, P, (double *)d_state, (double *)d_trial,
                            (const double *)d_dp, (const double *)d_E, (const double *)d_gl, (const double *)d_W,
-                           (const ba_status *)d_st, (double *)d_trial, (double *)d_part);
-        hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(256), 0, s, nx, nb_upd, (const double *)d_part,
-                           (const double *)d_trial, (double *)d_state, (ba_status *)d_st, (int *)d_fail, max_iter, ftol,
-                           xtol);
+                           (const ba_status *)d_st, (double *)d_part);
+        hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, s, nb_upd, (const double *)d_part, (ba_status *)d_st,
+                           (int *)d_fail, max_iter, ftol, xtol);
         VOHIP_HIP(ctx, hipGetLastError());
         // The status comes back after every third trial only: the kernels of a trial return at once
         // when the run has ended, so at most two idle trials are enqueued, and two of three
@@ -934,7 +972,7 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
         std::memcpy(&hs, h_st, sizeof(hs));
         if (hs.done) break;
     }
-    VOHIP_TRY(vohip_download(ctx, state, d_state, sizeof(double) * nx));
+    VOHIP_TRY(vohip_download(ctx, state, hs.cur ? d_trial : d_state, sizeof(double) * nx));
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
     if (stats) {
         stats[0] = hs.iter;

@@ -34,7 +34,7 @@ enum vohip_buf_id {
     B_HARRIS_SCRATCH,
     B_FM_NRM, B_FM_F, B_FM_COUNTS, H_FM_COUNTS,
     B_BA_INDEX, B_BA_FRAME, B_BA_LM, B_BA_UV, B_BA_COUNT, B_BA_STATE, B_BA_TRIAL, B_BA_SPART, B_BA_GPART,
-    B_BA_E, B_BA_GL, B_BA_W, B_BA_DP, B_BA_PART, B_BA_STATUS, H_BA_STATUS,
+    B_BA_E, B_BA_GL, B_BA_W, B_BA_DP, B_BA_PART, B_BA_STATUS, H_BA_STATUS, B_BA_SRED, B_BA_GRED,
     B_KLT_STATS,
     B_PYR0,                 // first of VOHIP_PYR_SLOTS consecutive ids, one per pyramid slot (see B_PYR_LAST)
     VOHIP_NBUF = 96

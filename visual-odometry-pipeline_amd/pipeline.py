@@ -125,7 +125,14 @@ def update_candidate(S, valid_key_candidates, image, K, hyper_paras, ctx=None):
 
 
 def _columns_with_ids(id_row, ids):
-    """[~, col] = find(id_row == ids(:)): ascending column indices whose id is in `ids`."""
+    """[~, col] = find(id_row == ids(:)): ascending column indices whose id is in `ids`.  Landmark ids only
+    ever grow (update_landmarks.m:83-87 appends B.new_idx, B.new_idx + 1, ...), so id_row is ascending and a
+    binary search finds the columns; anything else takes the general route."""
+    id_row = np.asarray(id_row)
+    ids = np.asarray(ids)
+    if id_row.size and ids.size and np.all(id_row[1:] > id_row[:-1]) and np.all(ids[1:] > ids[:-1]):
+        cols = np.minimum(np.searchsorted(id_row, ids), id_row.size - 1)
+        return cols[id_row[cols] == ids]
     return np.flatnonzero(np.isin(id_row, ids))
 
 
