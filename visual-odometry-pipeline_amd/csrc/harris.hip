@@ -56,8 +56,9 @@ __device__ __forceinline__ float from_ordered_bits(unsigned k)
 #pragma clang fp contract(off)
 
 // max_bits[0 / 1]: the maximum of this call / cleared here for the next call (the two alternate).
-__global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restrict__ img, int A, int B, taps5 G,
-                                                          int method, int lo, corner_rec *__restrict__ recs,
+__global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restrict__ img, int A, int B, int tiles_a,
+                                                          int tiles_b, taps5 G, int method, int lo,
+                                                          corner_rec *__restrict__ recs,
                                                           int *__restrict__ tile_count,
                                                           unsigned *__restrict__ max_now,
                                                           unsigned *__restrict__ max_next)
@@ -69,10 +70,16 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restr
     __shared__ unsigned sMax;
     __shared__ int sCnt[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int a0 = blockIdx.x * TA, b0 = blockIdx.y * TB;
+    // Workgroups are dealt to the 8 XCDs in turn and each XCD has its own L2: workgroup w takes tile
+    // (w % 8) * per_xcd + w / 8, so that an XCD works on a contiguous band of the image and the halos its
+    // tiles share are fetched into its L2 once.
+    const int ntiles = tiles_a * tiles_b, per_xcd = (ntiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= ntiles) return;
+    const int a0 = (tile % tiles_a) * TA, b0 = (tile / tiles_a) * TB;
     if (tid == 0) {
         sMax = 0u;
-        if (blockIdx.x == 0 && blockIdx.y == 0) *max_next = 0u;
+        if (tile == 0) *max_next = 0u;
     }
     const float s255 = 1.0f / 255.0f;
     for (int q = tid; q < IA * IB; q += 256) {
@@ -156,7 +163,6 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restr
         if (lane == 0) sCnt[4 * k + wave] = __popcll(bal[k]);
     }
     __syncthreads();
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
     corner_rec *out = recs + (size_t)tile * TILE_CAP;
     int total = 0;
 #pragma unroll
@@ -353,8 +359,8 @@ int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, 
     taps5 G;
     gaussian_taps(filter_size, G.w);
     const int lo = border < 1 ? 1 : border;
-    hipLaunchKernelGGL(corner_tile_kernel, dim3(tiles_a, tiles_b), dim3(256), 0, st, d_img, A, B, G, method, lo, recs,
-                       tile_count, max2 + slot, max2 + (slot ^ 1u));
+    hipLaunchKernelGGL(corner_tile_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, st, d_img, A, B, tiles_a, tiles_b, G,
+                       method, lo, recs, tile_count, max2 + slot, max2 + (slot ^ 1u));
     hipLaunchKernelGGL(corner_count_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, (const corner_rec *)recs,
                        (const int *)tile_count, ntiles, tiles_a, A, (float)min_quality, (const unsigned *)(max2 + slot),
                        cells, totals);
