@@ -258,7 +258,15 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
  * fundamental-matrix trials (may be NULL while there are no candidates yet).  One synchronisation.
  * VOHIP_SAMPLES_EXHAUSTED: the adaptive rule wants more than h hypotheses (pose->num_iterations tells
  * how many); call vohip_frame_retry with a longer u3 whose first h triples are the ones already
- * passed.  VOHIP_NO_MODEL: no hypothesis reached 30 inliers (the reference stops there too). */
+ * passed.  VOHIP_NO_MODEL: no hypothesis reached 30 inliers (the reference stops there too).
+ * VOHIP_TOO_FEW_POINTS: fewer than 3 landmark tracks (main_demo.m:389-391 stops) or fewer than 8
+ * candidate tracks for the 8-point algorithm.  VOHIP_CAPACITY_EXCEEDED: the frame found more corners,
+ * landmarks or candidates than cap_corners / cap_landmarks / cap_candidates hold (counts->overflow: bit 0
+ * landmarks, bit 1 candidates); the surplus was dropped, which the reference never does
+ * (update_landmarks.m:83-95 and update_candidate.m grow their arrays).  After VOHIP_NO_MODEL,
+ * VOHIP_TOO_FEW_POINTS or VOHIP_CAPACITY_EXCEEDED the state is no longer the reference's: every call
+ * but vohip_frame_reset and vohip_frame_destroy is refused (create the loop with larger capacities and
+ * start it again from the last good state). */
 int vohip_frame_step(vohip_frame *f, const uint8_t *image, int image_on_device, const double *u3, int h,
                      const double *u8, vohip_frame_pose *pose, vohip_frame_counts *counts);
 int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *counts);

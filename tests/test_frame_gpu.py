@@ -123,6 +123,24 @@ def test_device_loop_accepts_device_images_and_reports_errors(vo, ctx, oracle, s
         vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, ctx=ctx, cap_landmarks=64)
 
 
+def test_overflow_stops_the_loop(vo, ctx, oracle, sequence):
+    """A frame that finds more candidates than cap_candidates holds drops the surplus, which the reference
+    never does (update_candidate.m grows S.C): the call reports VOHIP_CAPACITY_EXCEEDED and the loop then
+    refuses every further frame."""
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    e = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(3), ctx=ctx,
+                            cap_candidates=64)
+    with pytest.raises(vo.VohipError) as err:
+        e.process_frame(frames[1])
+    assert err.value.status == vo._lib.VOHIP_CAPACITY_EXCEEDED
+    with pytest.raises(vo.VohipError) as err:
+        e.process_frame(frames[2])
+    assert "vohip_frame_reset" in str(err.value)
+    e.close()
+
+
 @pytest.mark.parametrize("on_device", [False, True, "pinned"])
 def test_preparing_the_next_frame_ahead_changes_nothing(vo, ctx, oracle, sequence, on_device):
     """vohip_frame_step_ahead: with the next image in hand its pyramid and corners are prepared beside

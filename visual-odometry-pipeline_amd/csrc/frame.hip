@@ -1107,6 +1107,13 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     f->ahead = f->ahead_launched;
     const int n_det_now = hc[N_DET + f->par];
     f->par ^= 1;
+    // The reference stops at each of these (main_demo.m:389-391 without tracks, the 8-point algorithm
+    // without matches) or never meets it (MATLAB arrays grow: update_landmarks.m:83-95 drops nothing).
+    // Here the frame has run to its end on truncated or empty lists, so the state no longer is what the
+    // reference would hold: only vohip_frame_reset (or destroy) is accepted after any of them.
+    const bool lost = hc[N_V] < 3 || !hc[R_FOUND] || (f->have_map && hc[N_CV] < 8);
+    const bool over = n_det_now > f->capK || hc[OVERFLOW] != 0;
+    if (lost || over) f->stage = STAGE_FAILED;
     if (hc[N_V] < 3) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "only %d landmarks were tracked", hc[N_V]);
     if (!hc[R_FOUND])
         return vohip_fail(ctx, VOHIP_NO_MODEL, "no hypothesis reached 30 inliers in %d iterations", hc[R_ITER]);
