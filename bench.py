@@ -323,8 +323,12 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50):
         ctx.check(lib.vohip_detect_corners_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 2e-4, 5, 16, 0,
                                                d_xy.data_ptr(), d_metric.data_ptr(), cap, d_count.data_ptr()))
 
+    def detect_fast():   # main_eval.m:172-173
+        ctx.check(lib.vohip_detect_fast_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 0.11, 0.1, 16,
+                                            d_xy.data_ptr(), d_metric.data_ptr(), cap, d_count.data_ptr()))
+
     out = {}
-    for name, fn in (("pyramid_build", build), ("corner_detection", detect)):
+    for name, fn in (("pyramid_build", build), ("fast_detection", detect_fast), ("corner_detection", detect)):
         fn()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -334,6 +338,8 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50):
         ev1.record()
         torch.cuda.synchronize()
         out[name] = ev0.elapsed_time(ev1) / reps
+        if name == "fast_detection":
+            n_fast = min(int(d_count.item()), cap)
     px = float(rows * cols)
     levels = sum(0.25 ** l for l in range(5))
     n_corners = min(int(d_count.item()), cap)
@@ -346,7 +352,10 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50):
                               "achieved_gbs": bytes_pyr / (out["pyramid_build"] * 1e-3) / 1e9, "peak_gbs": 8000.0},
             "corner_detection": {"ms": out["corner_detection"], "corners": n_corners, "algorithmic_bytes": bytes_det,
                                  "achieved_gbs": bytes_det / (out["corner_detection"] * 1e-3) / 1e9,
-                                 "peak_gbs": 8000.0}}
+                                 "peak_gbs": 8000.0},
+            "fast_detection": {"ms": out["fast_detection"], "corners": n_fast, "algorithmic_bytes": px + 8.0 * n_fast,
+                               "achieved_gbs": (px + 8.0 * n_fast) / (out["fast_detection"] * 1e-3) / 1e9,
+                               "peak_gbs": 8000.0}}
 
 
 def bench_ba(vo, ctx, with_cpu):

@@ -213,7 +213,7 @@ typedef struct vohip_frame vohip_frame;
 typedef struct vohip_frame_params {
     int klt_block, klt_levels, klt_max_iter;   /* vision.PointTracker arguments, main_demo.m:342-343 */
     double klt_max_bidir_error;
-    int detector;                              /* 0 Harris, 1 MinEigen (genKeypoints.m:16-18,31-32) */
+    int detector;                              /* 0 Harris, 1 MinEigen, 2 FAST (genKeypoints.m:16-19,31-32) */
     double min_quality;
     int filter_size, border;
     double r_discard_redundant;                /* hyper_paras, main_demo.m:36-43, 72-75 */
@@ -226,6 +226,7 @@ typedef struct vohip_frame_params {
     int slot_a, slot_b, slot_c;                /* the three pyramid slots of the context this loop uses */
     int is_BA;                                 /* hyper_paras.is_BA: update_landmarks.m:78-88 then also asks for
                                                   reprojection errors below 100 px in both views */
+    double min_contrast;                       /* detector 2: detectFASTFeatures' 'MinContrast' (main_eval.m:172-173) */
 } vohip_frame_params;
 
 typedef struct vohip_frame_pose {
@@ -436,6 +437,17 @@ int vohip_detect_corners(vohip_ctx *ctx, const uint8_t *img, int rows, int cols,
 int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor,
                              double min_quality, int filter_size, int border, int method, float *d_xy,
                              float *d_metric, int cap, int *d_count);
+
+/* Stands in for genKeypoints.m:1-33 with method 'FAST' (dispatch table genKeypoints.m:19; main_eval.m:172-173
+ * passes {'MinContrast', 0.11}): detectFASTFeatures(image, 'MinContrast', c, 'MinQuality', q) followed by
+ * extractFeatures' border drop.  The segment test of Rosten & Drummond on the 16-pixel circle with 9
+ * contiguous pixels, threshold t = round(255 c); Metric = the largest threshold the pixel still passes;
+ * strict 3x3 non-maximum suppression on the metric; Metric > q * max(Metric); integer pixel positions.
+ * The other arguments, the output layout and order are those of vohip_detect_corners. */
+int vohip_detect_fast(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double min_contrast,
+                      double min_quality, int border, float *xy_out, float *metric_out, int cap, int *n_out);
+int vohip_detect_fast_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, double min_contrast,
+                          double min_quality, int border, float *d_xy, float *d_metric, int cap, int *d_count);
 
 #ifdef __cplusplus
 }

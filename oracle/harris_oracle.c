@@ -135,3 +135,71 @@ int vo_detect_corners(const uint8_t *img, int A, int B, double min_quality, int 
     free(R);
     return n;
 }
+
+/*
+ * FAST, the stand-in for detectFASTFeatures + extractFeatures' border drop as genKeypoints.m:19,31-32
+ * calls them (main_eval.m:172-173: 'MinContrast' 0.11).  PARITY UNPINNED (closed-source toolbox
+ * function, no keypoint fixtures in the reference).  This project's definition, after Rosten &
+ * Drummond's segment test:
+ *   circle  = the 16 pixels of the Bresenham circle of radius 3 around p
+ *   corner <=> 9 contiguous circle pixels are all > I_p + t or all < I_p - t, t = round(255 MinContrast)
+ *   Metric  = the largest t for which that still holds
+ *           = max over the 16 arcs of max(min_q (I_q - I_p), min_q (I_p - I_q)) - 1
+ *   pixels closer than 3 px to an image edge are never corners
+ *   kept   <=> Metric strictly greater than the Metric of the 8 neighbours (non-corners count 0),
+ *              Metric > MinQuality * max(Metric), at least `border` px from every edge
+ * Integer positions, output order as vo_detect_corners.  Written as the plain double loop over arcs.
+ */
+void vo_fast_score(const uint8_t *img, int A, int B, int threshold, int *S)
+{
+    static const int ca[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    static const int cb[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+    memset(S, 0, sizeof(int) * (size_t)A * B);
+    for (int b = 3; b < B - 3; ++b)
+        for (int a = 3; a < A - 3; ++a) {
+            const int p = img[(size_t)b * A + a];
+            int best = -256;
+            for (int s = 0; s < 16; ++s) {
+                int mn_bright = 256, mn_dark = 256;
+                for (int j = 0; j < 9; ++j) {
+                    const int k = (s + j) % 16;
+                    const int d = (int)img[(size_t)(b + cb[k]) * A + (a + ca[k])] - p;
+                    if (d < mn_bright) mn_bright = d;
+                    if (-d < mn_dark) mn_dark = -d;
+                }
+                if (mn_bright > best) best = mn_bright;
+                if (mn_dark > best) best = mn_dark;
+            }
+            const int score = best - 1;
+            S[(size_t)b * A + a] = score >= threshold ? score : 0;
+        }
+}
+
+int vo_detect_fast(const uint8_t *img, int A, int B, double min_contrast, double min_quality, int border,
+                   float *ab_out, float *metric_out, int cap)
+{
+    int *S = (int *)malloc(sizeof(int) * (size_t)A * B);
+    vo_fast_score(img, A, B, (int)floor(min_contrast * 255.0 + 0.5), S);
+    int smax = 0;
+    for (size_t i = 0; i < (size_t)A * B; ++i) if (S[i] > smax) smax = S[i];
+    const float thr = (float)min_quality * (float)smax;
+    const int lo = border < 1 ? 1 : border;
+    int n = 0;
+    for (int b = lo; b < B - lo; ++b)
+        for (int a = lo; a < A - lo; ++a) {
+            const int *c = S + (size_t)b * A + a;
+            const int r = c[0];
+            if (!((float)r > thr)) continue;
+            if (!(r > c[-1] && r > c[1] && r > c[-A] && r > c[A] && r > c[-A - 1] && r > c[-A + 1] &&
+                  r > c[A - 1] && r > c[A + 1]))
+                continue;
+            if (n < cap) {
+                ab_out[n] = (float)a;
+                ab_out[cap + n] = (float)b;
+                metric_out[n] = (float)r;
+            }
+            ++n;
+        }
+    free(S);
+    return n;
+}

@@ -188,8 +188,7 @@ class OraclePipeline:
         S, B, K, hp = self.S, self.B, self.K, self.hp
         image = np.ascontiguousarray(image)
         opts = dict(zip(hp.feature_extract_options[::2], hp.feature_extract_options[1::2]))
-        ab, _, _ = orc.detect_corners(image, min_quality=opts.get("MinQuality", 0.01), filter_size=5, border=16,
-                                      method=0 if hp.feature_extract == "Harris" else 1)     # main_demo.m:377
+        ab, _, _ = orc.detect(image, hp.feature_extract, opts)                                # main_demo.m:377
         location = ab + np.float32(1.0)
         matched_points, validity = klt_step(self.prev_img, image, self.L_pts)               # :380
         matched_valid = np.fliplr(matched_points[validity])                                 # :381
@@ -234,8 +233,7 @@ def matching_init(img0, img_seqs, hp):
     a point lost in an intermediate image stays lost."""
     img0 = np.ascontiguousarray(img0)
     opts = dict(zip(hp.feature_extract_options[::2], hp.feature_extract_options[1::2]))
-    ab, _, _ = orc.detect_corners(img0, min_quality=opts.get("MinQuality", 0.01), filter_size=5, border=16,
-                                  method=0 if hp.feature_extract == "Harris" else 1)        # :12
+    ab, _, _ = orc.detect(img0, hp.feature_extract, opts)                                  # :12
     init_points_ = ab + np.float32(1.0)                                                    # :13 (single)
     pts = init_points_.astype(np.float64)
     alive = np.ones(len(pts), dtype=bool)

@@ -151,6 +151,11 @@ void vo_gaussian_taps(int filter_size, float *w);
 void vo_corner_response(const uint8_t *img, int A, int B, int filter_size, int method, float *R);
 int vo_detect_corners(const uint8_t *img, int A, int B, double min_quality, int filter_size, int border,
                       int method, float *ab_out, float *metric_out, int cap);
+/* This project's definition of the FAST detector that stands in for detectFASTFeatures (genKeypoints.m:19);
+ * see harris_oracle.c.  S: A x B segment-test scores (0 where the pixel is no corner at `threshold`). */
+void vo_fast_score(const uint8_t *img, int A, int B, int threshold, int *S);
+int vo_detect_fast(const uint8_t *img, int A, int B, double min_contrast, double min_quality, int border,
+                   float *ab_out, float *metric_out, int cap);
 
 #ifdef __cplusplus
 }

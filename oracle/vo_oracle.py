@@ -256,6 +256,38 @@ def detect_corners(img_ab, min_quality=0.01, filter_size=5, border=16, method=0,
     return np.stack([ab[:n], ab[cap:cap + n]], axis=1).copy(), metric[:n].copy(), total
 
 
+def fast_score(img_ab, threshold):
+    """Segment-test scores of every pixel (0 where no corner at `threshold`): int32 (B, A)."""
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    S = np.zeros((B, A), dtype=np.int32)
+    lib().vo_fast_score(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_int(int(threshold)),
+                        S.ctypes.data_as(C.POINTER(C.c_int)))
+    return S
+
+
+def detect_fast(img_ab, min_contrast=0.2, min_quality=0.1, border=16, cap=16384):
+    """img_ab uint8 (B, A).  Returns ab (n, 2) float32 0-based (a, b), metric (n,), total found."""
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    ab = np.zeros(2 * cap, dtype=np.float32)
+    metric = np.zeros(cap, dtype=np.float32)
+    lib().vo_detect_fast.restype = C.c_int
+    total = lib().vo_detect_fast(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_double(min_contrast),
+                                 C.c_double(min_quality), C.c_int(border), ab.ctypes.data_as(C.POINTER(C.c_float)),
+                                 metric.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(cap))
+    n = min(total, cap)
+    return np.stack([ab[:n], ab[cap:cap + n]], axis=1).copy(), metric[:n].copy(), total
+
+
+def detect(img_ab, method, options, border=16):
+    """genKeypoints.m:1-33 for the three detectors: options as the name-value dict of the reference."""
+    if method == "FAST":
+        return detect_fast(img_ab, options.get("MinContrast", 0.2), options.get("MinQuality", 0.1), border)
+    return detect_corners(img_ab, min_quality=options.get("MinQuality", 0.01), filter_size=5, border=border,
+                          method=0 if method == "Harris" else 1)
+
+
 # ---- bundle adjustment / pose refinement ----------------------------------------------------
 
 def ba_error(state, obs, K):

@@ -80,7 +80,7 @@ def test_main_eval_grid_is_independent_of_world_size(vo, ctx, tmp_path):
         sequences.append(dict(name="corridor%d" % k, images=[scene.render(T) for T in poses], K=K,
                               ground_truth=np.array([[T[0, 3], T[2, 3]] for T in poses]),
                               hyper_paras=vo.default_hyper_paras("kitti")))
-    feats = ("Harris", "MinEigen")
+    feats = ("Harris", "FAST")                                               # two of main_eval.m:19's variants
     whole = vo.main_eval(sequences, feats=feats, repetition=1, save_dir=str(tmp_path / "w1"), seed=9, ctx=ctx)
     assert len(whole) == 4 and all(r is not None for r in whole)
     parts = [vo.main_eval(sequences, feats=feats, repetition=1, save_dir=str(tmp_path / "w2"), seed=9, ctx=ctx, rank=r,

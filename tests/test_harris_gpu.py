@@ -50,3 +50,55 @@ def test_capacity_flat_and_errors(vo, ctx):
         vo.genKeypoints(g["img"], "SURF", ["MetricThreshold", 200], ctx=ctx)
     with pytest.raises(ValueError):
         vo.genKeypoints(g["img"], "Harris", ["Bogus", 1], ctx=ctx)
+
+
+@pytest.mark.parametrize("shape,seed", [((376, 1241), 1), ((97, 131), 2), ((64, 64), 3), ((600, 800), 4)])
+def test_fast_matches_oracle(vo, ctx, oracle, shape, seed):
+    """genKeypoints(image, 'FAST', {'MinContrast', 0.11}) (main_eval.m:172-173) against the CPU statement of
+    the segment test.  Bar: bit-exact (integer arithmetic), both storage orders, host and device images."""
+    import torch
+    img = vo.synth.to_uint8(vo.synth.textured_image(shape[0], shape[1], seed=seed))
+    for contrast, quality in ((0.11, 0.1), (0.04, 0.3)):
+        ab, metric, total = oracle.detect_fast(img, min_contrast=contrast, min_quality=quality, border=16)
+        assert total > 10
+        opts = ["MinContrast", contrast, "MinQuality", quality]
+        _, kp = vo.genKeypoints(img, "FAST", opts, ctx=ctx)
+        assert kp.Count == total
+        np.testing.assert_array_equal(kp.Location, ab + 1.0)
+        np.testing.assert_array_equal(kp.Metric, metric)
+        _, kpd = vo.genKeypoints(torch.from_numpy(img).cuda(), "FAST", opts, ctx=ctx)
+        np.testing.assert_array_equal(kpd.Location, kp.Location)
+        np.testing.assert_array_equal(kpd.Metric, kp.Metric)
+    abT, metricT, totalT = oracle.detect_fast(np.ascontiguousarray(img.T), min_contrast=0.11, min_quality=0.1, border=16)
+    _, kpF = vo.genKeypoints(np.asfortranarray(img), "FAST", ["MinContrast", 0.11], ctx=ctx)
+    assert kpF.Count == totalT
+    np.testing.assert_array_equal(kpF.Location, abT[:, ::-1] + 1.0)
+    np.testing.assert_array_equal(kpF.Metric, metricT)
+
+
+def test_fast_edge_cases(vo, ctx, oracle):
+    # noise: nearly every pixel passes the segment test somewhere; flat: nothing does; detections near the
+    # image edge (border 3 = the circle's own reach)
+    rng = np.random.default_rng(11)
+    noise = rng.integers(0, 256, (70, 90), dtype=np.uint8)
+    ab, metric, total = oracle.detect_fast(noise, min_contrast=0.05, min_quality=0.05, border=3)
+    _, kp = vo.genKeypoints(noise, "FAST", ["MinContrast", 0.05, "MinQuality", 0.05, "Border", 3], ctx=ctx)
+    assert kp.Count == total and total > 50
+    np.testing.assert_array_equal(kp.Location, ab + 1.0)
+    np.testing.assert_array_equal(kp.Metric, metric)
+    assert kp.Location.min() >= 4.0
+    _, kp = vo.genKeypoints(np.full((64, 64), 7, np.uint8), "FAST", None, ctx=ctx)
+    assert kp.Count == 0 and kp.Location.shape == (0, 2)
+    with pytest.raises(vo.VohipError):
+        vo.genKeypoints(noise, "FAST", ["MinContrast", 1.5], ctx=ctx)
+    with pytest.raises(ValueError):
+        vo.genKeypoints(noise, "FAST", ["FilterSize", 5], ctx=ctx)
+    # the two detectors share scratch memory and the alternating maximum slots: interleaved calls stay exact
+    g = np.load(os.path.join(GOLD, "harris_320x240.npz"))
+    for _ in range(3):
+        _, kh = vo.genKeypoints(g["img"], "Harris", ["MinQuality", 2e-4], ctx=ctx)
+        np.testing.assert_array_equal(kh.Location, g["xy"])
+        abf, mf, _ = oracle.detect_fast(g["img"], min_contrast=0.11, min_quality=0.1, border=16)
+        _, kf = vo.genKeypoints(g["img"], "FAST", ["MinContrast", 0.11], ctx=ctx)
+        np.testing.assert_array_equal(kf.Location, abf + 1.0)
+        np.testing.assert_array_equal(kf.Metric, mf)

@@ -12,4 +12,4 @@ vo = importlib.import_module("visual_odometry_pipeline_amd")
 ctx = vo.Context(0)
 scene, frames, poses = bench.make_sequence(vo, 8)
 out = bench.bench_image_kernels(vo, torch, ctx, torch.from_numpy(frames[0]).cuda(), reps=200)
-print(out["corner_detection"], out["pyramid_build"])
+print(out["corner_detection"], out["fast_detection"], out["pyramid_build"])

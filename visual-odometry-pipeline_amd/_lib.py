@@ -43,7 +43,8 @@ class FrameParams(C.Structure):
                 ("refine_pose", C.c_int), ("refine_max_iter", C.c_int), ("fm_trials", C.c_int),
                 ("fm_threshold", C.c_double), ("fm_confidence", C.c_double), ("cap_landmarks", C.c_int),
                 ("cap_candidates", C.c_int), ("cap_corners", C.c_int), ("max_hypotheses", C.c_int),
-                ("slot_a", C.c_int), ("slot_b", C.c_int), ("slot_c", C.c_int), ("is_BA", C.c_int)]
+                ("slot_a", C.c_int), ("slot_b", C.c_int), ("slot_c", C.c_int), ("is_BA", C.c_int),
+                ("min_contrast", C.c_double)]
 
 
 class FramePose(C.Structure):
@@ -140,6 +141,10 @@ SIGNATURES = {
                                         C.c_int, C.c_int, c_float_p, c_float_p, C.c_int, c_int_p]),
     "vohip_detect_corners_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_detect_fast": (C.c_int, [C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                     c_float_p, c_float_p, C.c_int, c_int_p]),
+    "vohip_detect_fast_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                         C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_pyramid_build": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vohip_pyramid_build_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vohip_pyramid_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_int_p, c_int_p]),

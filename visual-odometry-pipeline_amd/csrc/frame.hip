@@ -898,7 +898,7 @@ int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t 
     VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, ready, 0));
     VOHIP_TRY(vohip_detect_corners_enqueue(ctx, f->side2, f->corner_scratch, &f->det_calls, d_img, f->rows, f->cols,
                                            f->colmajor, p.min_quality, p.filter_size, p.border, p.detector,
-                                           f->corner_xy[par], f->corner_metric[par], f->capK, f->cnt + N_DET + par));
+                                           p.min_contrast, f->corner_xy[par], f->corner_metric[par], f->capK, f->cnt + N_DET + par));
     if (table_free) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, table_free, 0));
     // (the candidate tracker, when it last ran as a launch of its own; complete long ago otherwise)
     if (table_free) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, f->ev_advC[par ^ 1], 0));
@@ -1162,6 +1162,7 @@ void vohip_frame_default_params(vohip_frame_params *p)
     p->slot_b = 7;
     p->slot_c = 5;
     p->is_BA = 0;
+    p->min_contrast = 0.2;        // detectFASTFeatures' default
 }
 
 int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor,

@@ -22,6 +22,15 @@
 //                        go to their ranks: ordered and deterministic, no atomics.
 // Per image: the uint8 image is read once (plus the halos), ~16 bytes are written and read per local
 // maximum and 12 bytes written per corner.
+//
+// FAST (detectFASTFeatures as genKeypoints.m:19 calls it, options 'MinContrast' / 'MinQuality',
+// main_eval.m:172-173) shares everything but the response: fast_tile_kernel scores the segment test of
+// Rosten & Drummond on the 16-pixel circle of radius 3 (9 contiguous pixels all brighter than the
+// centre + t or all darker than the centre - t, t = round(255 MinContrast)):
+//   score = max over the 16 arcs of 9 of max(min(I_q - I_p), min(I_p - I_q)) - 1,
+// the largest t for which the pixel still passes; R = score where score >= t, else 0; pixels closer than
+// 3 px to an edge score 0; then the same strict 3x3 maxima, R > MinQuality * max(R), border margin and
+// ordered emit as above, at integer positions.  Exact integer arithmetic.
 #include "vohip_internal.h"
 
 #include <cmath>
@@ -55,6 +64,72 @@ __device__ __forceinline__ float from_ordered_bits(unsigned k)
 
 #pragma clang fp contract(off)
 
+// The second half of a tile kernel: sR holds the responses of the tile and a 1 px ring, `best` the
+// thread's maximum over the tile's own pixels.  Image maximum by one atomic per workgroup, then the
+// strict 3x3 maxima of the tile inside the border margin become records in pixel order.
+template <bool SUBPIXEL>
+__device__ __forceinline__ void tile_maxima(const float *sR, float best, unsigned *sMaxp, int *sCnt, int A, int B, int a0,
+                                            int b0, int lo, int tile, corner_rec *__restrict__ recs,
+                                            int *__restrict__ tile_count, unsigned *__restrict__ max_now)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned kb = ordered_bits(best);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) kb = max(kb, (unsigned)__shfl_xor((int)kb, m, 64));
+    if (lane == 0) atomicMax(sMaxp, kb);
+    __syncthreads();
+    if (tid == 0) atomicMax(max_now, *sMaxp);
+    // strict 3x3 maxima of the tile, in pixel order: pixel q = 256 k + tid of the tile is (row q / 64,
+    // column q % 64), so wavefront `wave` of round k holds one tile row and the order is (k, wave, lane)
+    bool is_max[4];
+    unsigned long long bal[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int rb = 4 * k + wave, ra = lane;
+        const int a = a0 + ra, b = b0 + rb;
+        bool m = false;
+        if (a >= lo && a < A - lo && b >= lo && b < B - lo) {
+            const float *c = sR + (rb + 1) * RA + (ra + 1);
+            const float r = c[0];
+            m = r > c[-1] && r > c[1] && r > c[-RA] && r > c[RA] && r > c[-RA - 1] && r > c[-RA + 1] && r > c[RA - 1] &&
+                r > c[RA + 1];
+        }
+        is_max[k] = m;
+        bal[k] = __ballot(m);
+        if (lane == 0) sCnt[4 * k + wave] = __popcll(bal[k]);
+    }
+    __syncthreads();
+    corner_rec *out = recs + (size_t)tile * TILE_CAP;
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int before = 0;
+        for (int w = 0; w < 4 * k + wave; ++w) before += sCnt[w];
+        if (is_max[k]) {
+            const int rb = 4 * k + wave, ra = lane;
+            const int a = a0 + ra, b = b0 + rb;
+            const float *cc = sR + (rb + 1) * RA + (ra + 1);
+            const float r = cc[0];
+            const float da = cc[1] - cc[-1], dda = (cc[1] - 2.0f * r) + cc[-1];
+            const float db = cc[RA] - cc[-RA], ddb = (cc[RA] - 2.0f * r) + cc[-RA];
+            float oa = dda < 0.0f ? -0.5f * da / dda : 0.0f;
+            float ob = ddb < 0.0f ? -0.5f * db / ddb : 0.0f;
+            oa = SUBPIXEL ? fminf(fmaxf(oa, -0.5f), 0.5f) : 0.0f;
+            ob = SUBPIXEL ? fminf(fmaxf(ob, -0.5f), 0.5f) : 0.0f;
+            corner_rec rec;
+            rec.key = b * A + a;
+            rec.r = r;
+            rec.pa = (float)a + oa;
+            rec.pb = (float)b + ob;
+            out[before + __popcll(bal[k] & ((1ull << lane) - 1ull))] = rec;
+        }
+    }
+    if (tid == 0) {
+        for (int w = 0; w < 16; ++w) total += sCnt[w];
+        tile_count[tile] = total;
+    }
+}
+
 // max_bits[0 / 1]: the maximum of this call / cleared here for the next call (the two alternate).
 __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restrict__ img, int A, int B, int tiles_a,
                                                           int tiles_b, taps5 G, int method, int lo,
@@ -69,7 +144,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restr
     __shared__ float sR[RA * RB];
     __shared__ unsigned sMax;
     __shared__ int sCnt[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     // Workgroups are dealt to the 8 XCDs in turn and each XCD has its own L2: workgroup w takes tile
     // (w % 8) * per_xcd + w / 8, so that an XCD works on a contiguous band of the image and the halos its
     // tiles share are fetched into its L2 once.
@@ -137,61 +212,80 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restr
         const int a = a0 - 1 + ra, b = b0 - 1 + rb;
         if (ra >= 1 && ra <= TA && rb >= 1 && rb <= TB && a < A && b < B) best = fmaxf(best, r);
     }
-    unsigned kb = ordered_bits(best);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) kb = max(kb, (unsigned)__shfl_xor((int)kb, m, 64));
-    if (lane == 0) atomicMax(&sMax, kb);
-    __syncthreads();
-    if (tid == 0) atomicMax(max_now, sMax);
-    // strict 3x3 maxima of the tile, in pixel order: pixel q = 256 k + tid of the tile is (row q / 64,
-    // column q % 64), so wavefront `wave` of round k holds one tile row and the order is (k, wave, lane)
-    bool is_max[4];
-    unsigned long long bal[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int rb = 4 * k + wave, ra = lane;
-        const int a = a0 + ra, b = b0 + rb;
-        bool m = false;
-        if (a >= lo && a < A - lo && b >= lo && b < B - lo) {
-            const float *c = sR + (rb + 1) * RA + (ra + 1);
-            const float r = c[0];
-            m = r > c[-1] && r > c[1] && r > c[-RA] && r > c[RA] && r > c[-RA - 1] && r > c[-RA + 1] && r > c[RA - 1] &&
-                r > c[RA + 1];
-        }
-        is_max[k] = m;
-        bal[k] = __ballot(m);
-        if (lane == 0) sCnt[4 * k + wave] = __popcll(bal[k]);
-    }
-    __syncthreads();
-    corner_rec *out = recs + (size_t)tile * TILE_CAP;
-    int total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int before = 0;
-        for (int w = 0; w < 4 * k + wave; ++w) before += sCnt[w];
-        if (is_max[k]) {
-            const int rb = 4 * k + wave, ra = lane;
-            const int a = a0 + ra, b = b0 + rb;
-            const float *cc = sR + (rb + 1) * RA + (ra + 1);
-            const float r = cc[0];
-            const float da = cc[1] - cc[-1], dda = (cc[1] - 2.0f * r) + cc[-1];
-            const float db = cc[RA] - cc[-RA], ddb = (cc[RA] - 2.0f * r) + cc[-RA];
-            float oa = dda < 0.0f ? -0.5f * da / dda : 0.0f;
-            float ob = ddb < 0.0f ? -0.5f * db / ddb : 0.0f;
-            oa = fminf(fmaxf(oa, -0.5f), 0.5f);
-            ob = fminf(fmaxf(ob, -0.5f), 0.5f);
-            corner_rec rec;
-            rec.key = b * A + a;
-            rec.r = r;
-            rec.pa = (float)a + oa;
-            rec.pb = (float)b + ob;
-            out[before + __popcll(bal[k] & ((1ull << lane) - 1ull))] = rec;
-        }
-    }
+    tile_maxima<true>(sR, best, &sMax, sCnt, A, B, a0, b0, lo, tile, recs, tile_count, max_now);
+}
+
+// FAST: the segment-test score of every pixel of the tile and its 1 px ring from the uint8 tile with a
+// 4 px halo (3 for the circle + 1 for the ring).  Sliding minima over 9 of the 16 differences by doubling
+// (windows of 2, 4, 8, then one more): 4 x 16 min per polarity.
+__global__ __launch_bounds__(256) void fast_tile_kernel(const uint8_t *__restrict__ img, int A, int B, int tiles_a,
+                                                        int tiles_b, int threshold, int lo,
+                                                        corner_rec *__restrict__ recs, int *__restrict__ tile_count,
+                                                        unsigned *__restrict__ max_now,
+                                                        unsigned *__restrict__ max_next)
+{
+    constexpr int FA = TA + 8, FB = TB + 8;
+    __shared__ int sI[FA * FB];
+    __shared__ float sR[RA * RB];
+    __shared__ unsigned sMax;
+    __shared__ int sCnt[16];
+    const int tid = threadIdx.x;
+    const int ntiles = tiles_a * tiles_b, per_xcd = (ntiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);   // (an XCD takes a contiguous band, as above)
+    if ((int)(blockIdx.x >> 3) >= per_xcd || tile >= ntiles) return;
+    const int a0 = (tile % tiles_a) * TA, b0 = (tile / tiles_a) * TB;
     if (tid == 0) {
-        for (int w = 0; w < 16; ++w) total += sCnt[w];
-        tile_count[tile] = total;
+        sMax = 0u;
+        if (tile == 0) *max_next = 0u;
     }
+    for (int q = tid; q < FA * FB; q += 256) {
+        const int rb = q / FA, ra = q - rb * FA;
+        const int a = min(max(a0 - 4 + ra, 0), A - 1);
+        const int b = min(max(b0 - 4 + rb, 0), B - 1);
+        sI[q] = (int)img[(size_t)b * A + a];
+    }
+    __syncthreads();
+    // circle of radius 3, clockwise from the top: offsets (da, db)
+    constexpr int CA[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+    constexpr int CB[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+    float best = -INFINITY;
+    for (int q = tid; q < RA * RB; q += 256) {
+        const int rb = q / RA, ra = q - rb * RA;
+        const int a = a0 - 1 + ra, b = b0 - 1 + rb;
+        int score = 0;
+        if (a >= 3 && a < A - 3 && b >= 3 && b < B - 3) {
+            const int *c = sI + (rb + 3) * FA + (ra + 3);
+            const int p = c[0];
+            int d[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k] = c[CB[k] * FA + CA[k]] - p;
+            int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                lo2[k] = min(d[k], d[(k + 1) & 15]);
+                hi2[k] = max(d[k], d[(k + 1) & 15]);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
+                hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
+            }
+            int bright = -255, dark = -255;   // max over the arcs of min(d) and of min(-d) = -max(d)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+                const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+                bright = max(bright, lo9);
+                dark = max(dark, -hi9);
+            }
+            const int sc = max(bright, dark) - 1;
+            score = sc >= threshold ? sc : 0;
+        }
+        const float r = (float)score;
+        sR[q] = r;
+        if (ra >= 1 && ra <= TA && rb >= 1 && rb <= TB && a < A && b < B) best = fmaxf(best, r);
+    }
+    tile_maxima<false>(sR, best, &sMax, sCnt, A, B, a0, b0, lo, tile, recs, tile_count, max_now);
 }
 
 // Survivors of the quality threshold per cell (tile, image row): one wavefront per tile.  cells: 16 ints
@@ -334,12 +428,13 @@ size_t vohip_corner_scratch_bytes(int rows, int cols)
 // counts the uses of this scratch (the two maximum slots alternate: a call clears the other one).
 int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, unsigned *calls, const uint8_t *d_img,
                                  int rows, int cols, int colmajor, double min_quality, int filter_size, int border,
-                                 int method, float *d_xy, float *d_metric, int cap, int *d_count)
+                                 int method, double min_contrast, float *d_xy, float *d_metric, int cap, int *d_count)
 {
     VOHIP_REQUIRE(ctx, d_img && d_xy && d_metric && d_count && scratch && calls, "NULL argument");
     VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
-    VOHIP_REQUIRE(ctx, filter_size == FS, "only FilterSize 5 (the toolbox default) is built");
-    VOHIP_REQUIRE(ctx, method == 0 || method == 1, "method: 0 = Harris, 1 = MinEigen");
+    VOHIP_REQUIRE(ctx, method >= 0 && method <= 2, "method: 0 = Harris, 1 = MinEigen, 2 = FAST");
+    VOHIP_REQUIRE(ctx, method == 2 || filter_size == FS, "only FilterSize 5 (the toolbox default) is built");
+    VOHIP_REQUIRE(ctx, method != 2 || (min_contrast > 0.0 && min_contrast < 1.0), "MinContrast must lie in (0, 1)");
     VOHIP_REQUIRE(ctx, cap >= 1 && cap <= 16384, "cap must be 1..16384");
     VOHIP_REQUIRE(ctx, border >= 0, "negative border");
     const int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
@@ -359,8 +454,13 @@ int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, 
     taps5 G;
     gaussian_taps(filter_size, G.w);
     const int lo = border < 1 ? 1 : border;
-    hipLaunchKernelGGL(corner_tile_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, st, d_img, A, B, tiles_a, tiles_b, G,
-                       method, lo, recs, tile_count, max2 + slot, max2 + (slot ^ 1u));
+    if (method == 2)   // the contrast threshold on the uint8 scale, rounded as MATLAB's uint8() rounds
+        hipLaunchKernelGGL(fast_tile_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, st, d_img, A, B, tiles_a, tiles_b,
+                           (int)std::floor(min_contrast * 255.0 + 0.5), lo, recs, tile_count, max2 + slot,
+                           max2 + (slot ^ 1u));
+    else
+        hipLaunchKernelGGL(corner_tile_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, st, d_img, A, B, tiles_a,
+                           tiles_b, G, method, lo, recs, tile_count, max2 + slot, max2 + (slot ^ 1u));
     hipLaunchKernelGGL(corner_count_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, (const corner_rec *)recs,
                        (const int *)tile_count, ntiles, tiles_a, A, (float)min_quality, (const unsigned *)(max2 + slot),
                        cells, totals);
@@ -371,15 +471,12 @@ int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, 
     return VOHIP_OK;
 }
 
-extern "C" {
+namespace {
 
-// d_xy: cap x 2 floats (x column then y column), d_metric: cap floats, d_count: 1 int (total
-// found, may exceed cap).  Asynchronous.
-int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor,
-                             double min_quality, int filter_size, int border, int method, float *d_xy,
-                             float *d_metric, int cap, int *d_count)
+int detect_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, double min_quality,
+               int filter_size, int border, int method, double min_contrast, float *d_xy, float *d_metric, int cap,
+               int *d_count)
 {
-    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
     const size_t bytes = vohip_corner_scratch_bytes(rows, cols) + 256;
     vohip_buf &b = ctx->bufs[B_HARRIS_SCRATCH];
@@ -388,14 +485,14 @@ int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int
         VOHIP_HIP(ctx, hipMemsetAsync(b.ptr, 0, 256, ctx->stream));
     }
     return vohip_detect_corners_enqueue(ctx, ctx->stream, b.ptr, &ctx->harris_calls, d_img, rows, cols, colmajor,
-                                        min_quality, filter_size, border, method, d_xy, d_metric, cap, d_count);
+                                        min_quality, filter_size, border, method, min_contrast, d_xy, d_metric, cap,
+                                        d_count);
 }
 
-int vohip_detect_corners(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double min_quality,
-                         int filter_size, int border, int method, float *xy_out, float *metric_out, int cap,
-                         int *n_out)
+int detect_host(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double min_quality,
+                int filter_size, int border, int method, double min_contrast, float *xy_out, float *metric_out, int cap,
+                int *n_out)
 {
-    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, img && xy_out && metric_out && n_out, "NULL argument");
     VOHIP_REQUIRE(ctx, rows >= 1 && cols >= 1 && cap >= 1, "bad size");
     void *d_img, *d_xy, *d_metric, *d_count;
@@ -403,8 +500,8 @@ int vohip_detect_corners(vohip_ctx *ctx, const uint8_t *img, int rows, int cols,
     VOHIP_TRY(vohip_upload(ctx, B_STAGE0, nullptr, sizeof(float) * 2 * (size_t)cap, &d_xy));
     VOHIP_TRY(vohip_upload(ctx, B_STAGE1, nullptr, sizeof(float) * (size_t)cap, &d_metric));
     VOHIP_TRY(vohip_upload(ctx, B_STAGE2, nullptr, 256, &d_count));
-    VOHIP_TRY(vohip_detect_corners_dev(ctx, (const uint8_t *)d_img, rows, cols, colmajor, min_quality, filter_size,
-                                       border, method, (float *)d_xy, (float *)d_metric, cap, (int *)d_count));
+    VOHIP_TRY(detect_dev(ctx, (const uint8_t *)d_img, rows, cols, colmajor, min_quality, filter_size, border, method,
+                         min_contrast, (float *)d_xy, (float *)d_metric, cap, (int *)d_count));
     int total = 0;
     VOHIP_TRY(vohip_download(ctx, &total, d_count, sizeof(int)));
     VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -419,6 +516,48 @@ int vohip_detect_corners(vohip_ctx *ctx, const uint8_t *img, int rows, int cols,
         return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "%d corners found, capacity %d: raise cap or MinQuality", total,
                           cap);
     return VOHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// d_xy: cap x 2 floats (x column then y column), d_metric: cap floats, d_count: 1 int (total
+// found, may exceed cap).  Asynchronous.
+int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor,
+                             double min_quality, int filter_size, int border, int method, float *d_xy,
+                             float *d_metric, int cap, int *d_count)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, method == 0 || method == 1, "method: 0 = Harris, 1 = MinEigen");
+    return detect_dev(ctx, d_img, rows, cols, colmajor, min_quality, filter_size, border, method, 0.0, d_xy, d_metric,
+                      cap, d_count);
+}
+
+int vohip_detect_corners(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double min_quality,
+                         int filter_size, int border, int method, float *xy_out, float *metric_out, int cap,
+                         int *n_out)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, method == 0 || method == 1, "method: 0 = Harris, 1 = MinEigen");
+    return detect_host(ctx, img, rows, cols, colmajor, min_quality, filter_size, border, method, 0.0, xy_out,
+                       metric_out, cap, n_out);
+}
+
+int vohip_detect_fast_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, double min_contrast,
+                          double min_quality, int border, float *d_xy, float *d_metric, int cap, int *d_count)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    return detect_dev(ctx, d_img, rows, cols, colmajor, min_quality, FS, border, 2, min_contrast, d_xy, d_metric, cap,
+                      d_count);
+}
+
+int vohip_detect_fast(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double min_contrast,
+                      double min_quality, int border, float *xy_out, float *metric_out, int cap, int *n_out)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    return detect_host(ctx, img, rows, cols, colmajor, min_quality, FS, border, 2, min_contrast, xy_out, metric_out, cap,
+                       n_out);
 }
 
 }  // extern "C"

@@ -148,7 +148,7 @@ int vohip_candidate_triangulate_enqueue(vohip_ctx *ctx, const double *d_cur_rc, 
 size_t vohip_corner_scratch_bytes(int rows, int cols);
 int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, unsigned *calls, const uint8_t *d_img,
                                  int rows, int cols, int colmajor, double min_quality, int filter_size, int border,
-                                 int method, float *d_xy, float *d_metric, int cap, int *d_count);
+                                 int method, double min_contrast, float *d_xy, float *d_metric, int cap, int *d_count);
 int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, const double *d_X, int n,
                               const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
                               double *d_stats);

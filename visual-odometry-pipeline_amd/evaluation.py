@@ -184,7 +184,8 @@ def run_sequence(images, K, hyper_paras, ground_truth=None, bootstrap_frames=(0,
 
 
 EVAL_FEATURE_OPTIONS = {"Harris": ["MinQuality", 2e-4],      # main_eval.m:168-169
-                        "MinEigen": ["MinQuality", 1e-2]}    # genKeypoints.m:18 (no entry in main_eval's switch)
+                        "MinEigen": ["MinQuality", 1e-2],    # genKeypoints.m:18 (no entry in main_eval's switch)
+                        "FAST": ["MinContrast", 0.11]}       # main_eval.m:172-173
 
 
 def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0, device=None, rank=None, world=None,

@@ -19,6 +19,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import VOHIP_NO_MODEL, VOHIP_SAMPLES_EXHAUSTED, colmajor, dptr
+from .keypoints import DEFAULT_MIN_QUALITY, DETECTORS
 from .pipeline import VO_bundle_adjust, default_hyper_paras, init_state
 from .ransac import MAX_ITERATIONS
 
@@ -30,7 +31,7 @@ class VOPipelineDevice:
         self.ctx = ctx or _lib.default_context()
         self.K = np.asarray(K, dtype=np.float64)
         self.hp = hyper_paras or default_hyper_paras()
-        if self.hp.feature_extract not in ("Harris", "MinEigen"):
+        if self.hp.feature_extract not in DETECTORS:
             raise NotImplementedError("detector '%s' is not built" % self.hp.feature_extract)
         self.rng = rng or np.random.default_rng()
         self.rng_map = rng_map or self.rng.spawn(1)[0]
@@ -45,8 +46,9 @@ class VOPipelineDevice:
         e = float(opts["MaxBidirectionalError"])
         prm.klt_max_bidir_error = e if np.isfinite(e) else 1e300
         fo = dict(zip(self.hp.feature_extract_options[::2], self.hp.feature_extract_options[1::2]))
-        prm.detector = 0 if self.hp.feature_extract == "Harris" else 1
-        prm.min_quality = float(fo.get("MinQuality", 0.01))
+        prm.detector = DETECTORS[self.hp.feature_extract]
+        prm.min_quality = float(fo.get("MinQuality", DEFAULT_MIN_QUALITY[self.hp.feature_extract]))
+        prm.min_contrast = float(fo.get("MinContrast", 0.2))
         prm.filter_size = int(fo.get("FilterSize", 5))
         prm.r_discard_redundant = float(self.hp.r_discard_redundant)
         prm.angle_threshold_deg = float(self.hp.angle_threshold)

@@ -1,5 +1,5 @@
 """Host-side mirror of utils/genKeypoints.m:1-33 for the detectors built natively
-('Harris', 'MinEigen').  Detection runs in libvohip.so on the GPU; no CPU fallback."""
+('Harris', 'MinEigen', 'FAST').  Detection runs in libvohip.so on the GPU; no CPU fallback."""
 import ctypes as C
 
 import numpy as np
@@ -8,6 +8,8 @@ from . import _lib
 
 DEFAULT_BORDER = 16     # px dropped at the image edge, the stand-in for extractFeatures' margin
 DEFAULT_CAPACITY = 16384
+DETECTORS = {"Harris": 0, "MinEigen": 1, "FAST": 2}       # rows of the dispatch table, genKeypoints.m:17-19
+DEFAULT_MIN_QUALITY = {"Harris": 0.01, "MinEigen": 0.01, "FAST": 0.1}   # the toolbox defaults
 
 
 class cornerPoints:
@@ -38,7 +40,7 @@ def _options(options):
     return {opts[i]: opts[i + 1] for i in range(0, len(opts), 2)}
 
 
-def _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap):
+def _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap, min_contrast):
     """Detection on a uint8 image already resident on the GPU (an object with data_ptr() and
     shape, row-major): only the keypoint list crosses the bus."""
     import torch
@@ -50,9 +52,13 @@ def _detect_device_image(ctx, image, min_quality, filter_size, border, method, c
         scratch["metric"] = torch.empty(cap, dtype=torch.float32, device=image.device)
         scratch["count"] = torch.zeros(1, dtype=torch.int32, device=image.device)
     xy, metric, count = scratch["xy"], scratch["metric"], scratch["count"]
-    ctx.check(_lib.load().vohip_detect_corners_dev(ctx.handle, image.data_ptr(), rows, cols, 0, min_quality,
-                                                   filter_size, border, 0 if method == "Harris" else 1,
-                                                   xy.data_ptr(), metric.data_ptr(), cap, count.data_ptr()))
+    if method == "FAST":
+        ctx.check(_lib.load().vohip_detect_fast_dev(ctx.handle, image.data_ptr(), rows, cols, 0, min_contrast, min_quality,
+                                                    border, xy.data_ptr(), metric.data_ptr(), cap, count.data_ptr()))
+    else:
+        ctx.check(_lib.load().vohip_detect_corners_dev(ctx.handle, image.data_ptr(), rows, cols, 0, min_quality,
+                                                       filter_size, border, DETECTORS[method],
+                                                       xy.data_ptr(), metric.data_ptr(), cap, count.data_ptr()))
     ctx.synchronize()
     total = int(count.item())
     if total > cap:
@@ -64,23 +70,26 @@ def _detect_device_image(ctx, image, min_quality, filter_size, border, method, c
 def genKeypoints(image, method="SURF", options=None, ctx=None):
     """[features, valid_key_points] = genKeypoints(image, method, options)
 
-    method 'Harris' or 'MinEigen'; options {'MinQuality', q, 'FilterSize', 5}.  Two extra options
-    have no MATLAB counterpart: 'Border' (default 16) and 'Capacity'.  `features` is None: the
+    method 'Harris' or 'MinEigen' with options {'MinQuality', q, 'FilterSize', 5}, or 'FAST' with
+    {'MinContrast', c, 'MinQuality', q} (main_eval.m:172-173).  Two extra options have no MATLAB
+    counterpart: 'Border' (default 16) and 'Capacity'.  `features` is None: the
     continuous-operation loop never reads it (main_demo.m:377 discards it).  The other detectors
-    of the reference's table (SURF, FAST, BRISK, ORB, SIFT) are closed-source toolbox functions
+    of the reference's table (SURF, BRISK, ORB, SIFT) are closed-source toolbox functions
     that are not rebuilt here."""
-    if method not in ("Harris", "MinEigen"):
-        raise NotImplementedError("genKeypoints: method '%s' is not built natively (Harris, MinEigen are)" % method)
+    if method not in DETECTORS:
+        raise NotImplementedError("genKeypoints: method '%s' is not built natively (%s are)"
+                                  % (method, ", ".join(DETECTORS)))
     ctx = ctx or _lib.default_context()
     opts = _options(options)
-    min_quality = float(opts.pop("MinQuality", 0.01))
-    filter_size = int(opts.pop("FilterSize", 5))
+    min_quality = float(opts.pop("MinQuality", DEFAULT_MIN_QUALITY[method]))
+    min_contrast = float(opts.pop("MinContrast", 0.2)) if method == "FAST" else 0.0
+    filter_size = int(opts.pop("FilterSize", 5)) if method != "FAST" else 5
     border = int(opts.pop("Border", DEFAULT_BORDER))
     cap = int(opts.pop("Capacity", DEFAULT_CAPACITY))
     if opts:
         raise ValueError("unknown option(s): %s" % ", ".join(opts))
     if hasattr(image, "data_ptr"):
-        return None, _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap)
+        return None, _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap, min_contrast)
     img = np.asarray(image)
     if img.dtype != np.uint8 or img.ndim != 2:
         raise TypeError("image must be a 2-D uint8 array")
@@ -90,10 +99,16 @@ def genKeypoints(image, method="SURF", options=None, ctx=None):
     xy = np.zeros(2 * cap, dtype=np.float32)
     metric = np.zeros(cap, dtype=np.float32)
     n = C.c_int(0)
-    ctx.check(_lib.load().vohip_detect_corners(
-        ctx.handle, img.ctypes.data_as(_lib.c_uint8_p), img.shape[0], img.shape[1], int(colmajor), min_quality,
-        filter_size, border, 0 if method == "Harris" else 1, xy.ctypes.data_as(_lib.c_float_p),
-        metric.ctypes.data_as(_lib.c_float_p), cap, C.byref(n)))
+    if method == "FAST":
+        ctx.check(_lib.load().vohip_detect_fast(
+            ctx.handle, img.ctypes.data_as(_lib.c_uint8_p), img.shape[0], img.shape[1], int(colmajor), min_contrast,
+            min_quality, border, xy.ctypes.data_as(_lib.c_float_p), metric.ctypes.data_as(_lib.c_float_p), cap,
+            C.byref(n)))
+    else:
+        ctx.check(_lib.load().vohip_detect_corners(
+            ctx.handle, img.ctypes.data_as(_lib.c_uint8_p), img.shape[0], img.shape[1], int(colmajor), min_quality,
+            filter_size, border, DETECTORS[method], xy.ctypes.data_as(_lib.c_float_p),
+            metric.ctypes.data_as(_lib.c_float_p), cap, C.byref(n)))
     k = n.value
     loc = np.stack([xy[:k], xy[k:2 * k]], axis=1).copy()
     return None, cornerPoints(loc, metric[:k].copy())

@@ -253,6 +253,20 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         std::memcpy(mxGetSingles(plhs[1]), metric, sizeof(float) * n);
         mxFree(xy);
         mxFree(metric);
+    } else if (is("detect_fast")) {
+        // [Location, Metric] = vohip_mex('detect_fast', image uint8, min_contrast, min_quality, border)
+        if (!mxIsUint8(in[0])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
+        const int cap = 16384;
+        float *xy = scratch<float>((size_t)2 * cap), *metric = scratch<float>((size_t)cap);
+        int n = 0;
+        check(vohip_detect_fast(c, mxGetUint8s(in[0]), rows(in[0]), cols(in[0]), 1, mxGetScalar(in[1]), mxGetScalar(in[2]),
+                                (int)mxGetScalar(in[3]), xy, metric, cap, &n));
+        plhs[0] = mxCreateNumericMatrix(n, 2, mxSINGLE_CLASS, mxREAL);
+        plhs[1] = mxCreateNumericMatrix(n, 1, mxSINGLE_CLASS, mxREAL);
+        std::memcpy(mxGetSingles(plhs[0]), xy, sizeof(float) * 2 * n);   // n x 2, x column then y column
+        std::memcpy(mxGetSingles(plhs[1]), metric, sizeof(float) * n);
+        mxFree(xy);
+        mxFree(metric);
     } else if (is("pyramid_build")) {
         // vohip_mex('pyramid_build', slot, image uint8, levels)
         if (!mxIsUint8(in[1])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
@@ -271,7 +285,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         // vohip_mex('frame_create', K, rows, cols, params struct): the loop body of main_demo.m:377-427 as
         // one call per frame, state resident on the GPU (one loop per MATLAB session).  params fields
         // (all optional): r_discard_redundant, angle_threshold_deg, min_depth, max_depth, min_quality,
-        // filter_size, detector, refine_pose.
+        // filter_size, detector, min_contrast, refine_pose, is_BA.
         if (g_frame) { vohip_frame_destroy(g_frame); g_frame = nullptr; }
         vohip_frame_params p;
         vohip_frame_default_params(&p);
@@ -289,6 +303,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
             p.detector = (int)field("detector", p.detector);
             p.refine_pose = (int)field("refine_pose", p.refine_pose);
             p.is_BA = (int)field("is_BA", p.is_BA);
+            p.min_contrast = field("min_contrast", p.min_contrast);
         }
         check(vohip_frame_create(c, dbl(in[0], "K"), (int)mxGetScalar(in[1]), (int)mxGetScalar(in[2]), 1, &p, &g_frame));
     } else if (is("frame_reset")) {
