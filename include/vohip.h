@@ -411,6 +411,13 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
  * [accepted iterations, initial cost, final cost]. */
 int vohip_pose_refine(vohip_ctx *ctx, double T_W_C[16], const double *kp_uv, const double *X, int n,
                       const double K[9], int max_iter, double ftol, double xtol, double *stats);
+/* T_refinement for k independent frames in one launch and one synchronisation, as VO_bundle_adjust.m:71-86
+ * re-refines the buffered normal frames after a window was optimised (the reference calls T_refinement once per
+ * frame there; the frames do not depend on each other).  Frame b has n[b] points; its columns follow frame
+ * b - 1's in kp_uv (2 x sum n) and X (3 x sum n); T holds k 4x4 matrices (in/out), stats 3k doubles or NULL.
+ * The results are those of k calls of vohip_pose_refine, bit for bit. */
+int vohip_pose_refine_batch(vohip_ctx *ctx, int k, double *T_W_C, const double *kp_uv, const double *X, const int *n,
+                            const double K[9], int max_iter, double ftol, double xtol, double *stats);
 /* Device-resident form (d_T 16 doubles in/out, d_stats 3 doubles or NULL).  Asynchronous. */
 int vohip_pose_refine_dev(vohip_ctx *ctx, double *d_T_W_C, const double *d_kp_uv, const double *d_X, int n,
                           const double K[9], int max_iter, double ftol, double xtol, double *d_stats);

@@ -99,3 +99,29 @@ def test_pose_refinement_matches_golden_and_oracle(vo, ctx, oracle):
         assert np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)) < 1e-5
         assert np.linalg.norm(want[:3, 3] - got[:3, 3]) < 1e-5
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-8)
+
+
+def test_batched_pose_refinement_equals_single_calls(vo, ctx):
+    """VO_bundle_adjust.m:71-86 re-refines the buffered normal frames one T_refinement call after the other;
+    here they go out as one launch.  Bar: bit-identical to the single calls, whatever the mix of sizes
+    (an empty frame keeps its pose)."""
+    K = vo.synth.K_KITTI
+    problems = []
+    for n, seed in [(900, 51), (64, 52), (0, 53), (1500, 54), (7, 55)]:
+        kp_rc, X, R, t, _ = vo.synth.pnp_problem(max(n, 6), inlier_ratio=1.0, seed=seed)
+        T_C_W = np.eye(4)
+        T_C_W[:3, :3] = R
+        T_C_W[:3, 3] = t
+        T0 = np.linalg.inv(T_C_W) @ vo.synth.pose_matrix([0.01, -0.02, 0.01], [0.1, -0.1, 0.05])
+        problems.append((T0, kp_rc[::-1][:, :n], X[:, :n]))
+    single = [vo.T_refinement(T, kp, X, K, ctx=ctx) if kp.shape[1] else np.array(T) for T, kp, X in problems]
+    batch = vo.T_refinement_batch(problems, K, ctx=ctx)
+    assert len(batch) == len(problems)
+    for a, b in zip(single, batch):
+        np.testing.assert_array_equal(a, b)
+    assert vo.T_refinement_batch([], K, ctx=ctx) == []
+    # twist2HomogMatrix for a window of twists in one call
+    tw = np.random.default_rng(5).normal(size=(5, 6)) * 0.3
+    many = vo.geometry.twist2HomogMatrix_many(tw, ctx=ctx)
+    for k in range(5):
+        np.testing.assert_array_equal(many[k], vo.twist2HomogMatrix(tw[k], ctx=ctx))

@@ -5,7 +5,7 @@ pipeline, behind the reference's own function names.  All arithmetic runs in lib
 from . import _lib
 from ._lib import Context, VohipError, default_context
 from . import batch, synth
-from .ba import T_refinement, baError, runBA
+from .ba import T_refinement, T_refinement_batch, baError, runBA
 from .bootstrap import (bootstrap, compProjMat, matching_init, pose_estimation_init, relativeCameraPose,
                         triangulation_init)
 from .evaluation import (alignError, alignEstimateToGroundTruth, experiment_name, load_results, main_eval,

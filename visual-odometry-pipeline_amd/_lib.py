@@ -135,6 +135,8 @@ SIGNATURES = {
                                 C.c_double, C.c_double, c_double_p]),
     "vohip_pose_refine": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, C.c_int,
                                      C.c_double, C.c_double, c_double_p]),
+    "vohip_pose_refine_batch": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p, c_double_p,
+                                           C.c_int, C.c_double, C.c_double, c_double_p]),
     "vohip_pose_refine_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
                                          C.c_int, C.c_double, C.c_double, C.c_void_p]),
     "vohip_detect_corners": (C.c_int, [C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,

@@ -61,3 +61,24 @@ def T_refinement(T_W_C, keypoints, landmarks, K, max_iter=POSE_MAX_ITER, ftol=PO
     if return_stats:
         return out, dict(iterations=int(stats[0]), cost0=stats[1], cost=stats[2])
     return out
+
+
+def T_refinement_batch(problems, K, max_iter=POSE_MAX_ITER, ftol=POSE_FTOL, xtol=POSE_XTOL, ctx=None):
+    """[T_refinement(T, kp, X, K) for (T, kp, X) in problems] in one launch and one synchronisation (the
+    re-refinement of the buffered normal frames, VO_bundle_adjust.m:71-86): the same results, bit for bit."""
+    ctx = ctx or _lib.default_context()
+    if not problems:
+        return []
+    T = np.concatenate([colmajor(p[0]).reshape(-1) for p in problems])
+    kps = [colmajor(np.asarray(p[1], dtype=np.float64).reshape(2, -1)) for p in problems]
+    Xs = [colmajor(np.asarray(p[2], dtype=np.float64).reshape(3, -1)) for p in problems]
+    for kp, X in zip(kps, Xs):
+        if kp.shape[0] != X.shape[0]:
+            raise ValueError("keypoints and landmarks differ in count")
+    n = np.array([kp.shape[0] for kp in kps], dtype=np.int32)
+    kp_all = np.ascontiguousarray(np.concatenate(kps).reshape(-1)) if n.sum() else np.zeros(2)
+    X_all = np.ascontiguousarray(np.concatenate(Xs).reshape(-1)) if n.sum() else np.zeros(3)
+    ctx.check(_lib.load().vohip_pose_refine_batch(ctx.handle, len(problems), dptr(T), dptr(kp_all), dptr(X_all),
+                                                  n.ctypes.data_as(_lib.c_int_p), dptr(colmajor(K)), int(max_iter),
+                                                  float(ftol), float(xtol), None))
+    return [T[16 * b:16 * b + 16].reshape(4, 4).T.copy() for b in range(len(problems))]

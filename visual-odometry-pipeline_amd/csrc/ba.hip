@@ -620,12 +620,24 @@ struct pr_params {
     double ftol, xtol;
 };
 
+// offsets (may be NULL): several independent problems in one launch, one workgroup each -- problem b owns
+// points [offsets[b], offsets[b + 1]) of kp_uv and X, pose b of T_io and statistics b.
 __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, const int *__restrict__ n_dev,
                                                                  const double *__restrict__ kp_uv,
                                                                  const double *__restrict__ X,
                                                                  double *__restrict__ T_io /*16*/,
-                                                                 double *__restrict__ stats /*3*/)
+                                                                 double *__restrict__ stats /*3*/,
+                                                                 const int *__restrict__ offsets)
 {
+    if (offsets) {
+        const int b = blockIdx.x, first = offsets[b];
+        P.n = offsets[b + 1] - first;
+        if (P.n == 0) return;   // (an empty problem leaves its pose as it is, like the single call)
+        kp_uv += 2 * (size_t)first;
+        X += 3 * (size_t)first;
+        T_io += 16 * (size_t)b;
+        if (stats) stats += 3 * (size_t)b;
+    }
     // Two slots (frame, twist, normal equations, cost): the current estimate and the trial step.  One
     // pass over the points gives a slot its cost AND its normal equations, so an accepted step needs
     // no second pass (the next step is solved from the trial slot's own system).
@@ -1007,7 +1019,7 @@ int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv
     P.ftol = ftol;
     P.xtol = xtol;
     hipLaunchKernelGGL(pose_refine_kernel, dim3(1), dim3(PR_THREADS), 0, ctx->stream, P, d_n, d_kp_uv, d_X, d_T,
-                       d_stats);
+                       d_stats, (const int *)nullptr);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
@@ -1033,6 +1045,57 @@ int vohip_pose_refine(vohip_ctx *ctx, double T[16], const double *kp_uv, const d
     if (stats) VOHIP_TRY(vohip_download(ctx, stats, d_stats, sizeof(double) * 3));
     VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VOHIP_OK;
+}
+
+int vohip_pose_refine_batch(vohip_ctx *ctx, int k, double *T, const double *kp_uv, const double *X, const int *n,
+                            const double K[9], int max_iter, double ftol, double xtol, double *stats)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, k >= 0 && K, "bad argument");
+    if (k == 0) return VOHIP_OK;
+    VOHIP_REQUIRE(ctx, k <= 4096 && T && n, "bad argument");
+    int *off = (int *)std::malloc(sizeof(int) * ((size_t)k + 1));
+    if (!off) return vohip_fail(ctx, VOHIP_ERR_HIP, "out of host memory");
+    off[0] = 0;
+    bool ok = true;
+    for (int b = 0; b < k; ++b) {
+        ok = ok && n[b] >= 0 && off[b] <= 0x3fffffff - (n[b] > 0 ? n[b] : 0);
+        off[b + 1] = off[b] + (n[b] > 0 ? n[b] : 0);
+    }
+    const int total = off[k];
+    int st = VOHIP_OK;
+    if (!ok || (total > 0 && (!kp_uv || !X))) st = vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "bad point counts or NULL array");
+    if (stats) std::memset(stats, 0, sizeof(double) * 3 * (size_t)k);
+    void *d_T = nullptr, *d_kp = nullptr, *d_X = nullptr, *d_stats = nullptr, *d_off = nullptr;
+    if (st == VOHIP_OK && total > 0) {
+        // (the staging buffers are filled by stream-ordered copies from the caller's arrays; `off` is read by its
+        // copy before the synchronisation below, after which it is released)
+        st = vohip_upload(ctx, B_STAGE0, T, sizeof(double) * 16 * (size_t)k, &d_T);
+        if (st == VOHIP_OK) st = vohip_upload(ctx, B_STAGE1, kp_uv, sizeof(double) * 2 * (size_t)total, &d_kp);
+        if (st == VOHIP_OK) st = vohip_upload(ctx, B_STAGE2, X, sizeof(double) * 3 * (size_t)total, &d_X);
+        if (st == VOHIP_OK) st = vohip_upload(ctx, B_STAGE3, nullptr, sizeof(double) * 3 * (size_t)k + 8, &d_stats);
+        if (st == VOHIP_OK) st = vohip_upload(ctx, B_STAGE4, off, sizeof(int) * ((size_t)k + 1), &d_off);
+        if (st == VOHIP_OK) {
+            pr_params P;
+            std::memcpy(P.K, K, sizeof(P.K));
+            P.n = 0;
+            P.max_iter = max_iter;
+            P.ftol = ftol;
+            P.xtol = xtol;
+            if (hipMemsetAsync(d_stats, 0, sizeof(double) * 3 * (size_t)k, ctx->stream) != hipSuccess)
+                st = vohip_fail(ctx, VOHIP_ERR_HIP, "hipMemsetAsync failed");
+            hipLaunchKernelGGL(pose_refine_kernel, dim3(k), dim3(PR_THREADS), 0, ctx->stream, P, (const int *)nullptr,
+                               (const double *)d_kp, (const double *)d_X, (double *)d_T, (double *)d_stats,
+                               (const int *)d_off);
+            if (st == VOHIP_OK && hipGetLastError() != hipSuccess) st = vohip_fail(ctx, VOHIP_ERR_HIP, "launch failed");
+        }
+        if (st == VOHIP_OK) st = vohip_download(ctx, T, d_T, sizeof(double) * 16 * (size_t)k);
+        if (st == VOHIP_OK && stats) st = vohip_download(ctx, stats, d_stats, sizeof(double) * 3 * (size_t)k);
+        const hipError_t e = hipStreamSynchronize(ctx->stream);   // (also when a step failed: `off` may still be read)
+        if (st == VOHIP_OK && e != hipSuccess) st = vohip_fail(ctx, VOHIP_ERR_HIP, "%s", hipGetErrorString(e));
+    }
+    std::free(off);
+    return st;
 }
 
 }  // extern "C"

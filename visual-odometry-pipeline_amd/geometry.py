@@ -21,6 +21,17 @@ def twist2HomogMatrix(twist, ctx=None):
     return H.reshape(4, 4).T.copy()
 
 
+def twist2HomogMatrix_many(twists, ctx=None):
+    """[twist2HomogMatrix(t) for t in twists] in one call (twists n x 6): n x 4 x 4."""
+    ctx = ctx or _lib.default_context()
+    t = as_f64(np.ascontiguousarray(np.asarray(twists, dtype=np.float64).reshape(-1, 6)))
+    n = t.shape[0]
+    H = np.zeros(16 * max(n, 1))
+    if n:
+        ctx.check(_lib.load().vohip_twist2homog(ctx.handle, dptr(t), n, dptr(H)))
+    return H[:16 * n].reshape(n, 4, 4).transpose(0, 2, 1).copy()
+
+
 def HomogMatrix2twist(H, ctx=None):
     """twist = HomogMatrix2twist(H): 4x4 rigid transform -> 6x1 [v; w], |w| in [0, pi]."""
     ctx = ctx or _lib.default_context()

@@ -16,9 +16,10 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import _lib
-from .ba import T_refinement, runBA
+from .ba import T_refinement, T_refinement_batch, runBA
 from .fmatrix import estimateFundamentalMatrix
-from .geometry import HomogMatrix2twist, candidate_filter, candidate_triangulate, twist2HomogMatrix
+from .geometry import (HomogMatrix2twist, candidate_filter, candidate_triangulate, twist2HomogMatrix,
+                       twist2HomogMatrix_many)
 from .keypoints import genKeypoints
 from .klt import PointTracker, Pyramid
 from .ransac import ransacLocalization
@@ -173,8 +174,9 @@ def VO_bundle_adjust(S, B, T_W_C, K, hyper_paras, ctx=None):
             opt = runBA(state, Obs, K, ctx=ctx)                 # :51
             step = B.keyframe_d + 1
             ncol = S.est_rot.shape[1]
+            Ts = twist2HomogMatrix_many(opt[:6 * B.num_key].reshape(B.num_key, 6), ctx=ctx)   # (one call for the window)
             for i in range(1, B.num_key + 1):                   # :53-57
-                T = twist2HomogMatrix(opt[(i - 1) * 6:(i - 1) * 6 + 6], ctx=ctx)
+                T = Ts[i - 1]
                 col = ncol - 1 - step * (B.num_key - i)
                 S.est_rot[:, col] = T[:3, :3].reshape(-1, order="F")
                 S.est_trans[:, col] = T[:3, 3]
@@ -188,15 +190,18 @@ def VO_bundle_adjust(S, B, T_W_C, K, hyper_paras, ctx=None):
             ok = (depth > hyper_paras.min_depth) & (depth < 1.5 * hyper_paras.max_depth)
             S.X[:3, ok] = B.landmarks[:3, cols[ok]]
             B.landmarks[:3, cols[~ok]] = S.X[:3, ~ok]
-            # re-refine the buffered normal frames against the optimised landmarks, :71-86
+            # re-refine the buffered normal frames against the optimised landmarks, :71-86 (the frames are
+            # independent of each other: one launch and one synchronisation for all of them)
+            problems, cols_out = [], []
             for i in range(1, B.num_key):
                 for j in range(1, B.keyframe_d + 1):
                     T_f, kp_f, ids_f = B.normal_frame_refine[B.keyframe_d * (i - 1) + j - 1]
                     idx = _columns_with_ids(B.landmarks[3], ids_f)
-                    T_r = T_refinement(T_f, kp_f, B.landmarks[:3, idx], K, ctx=ctx)
-                    col = ncol - 1 - step * (B.num_key - i) + j
-                    S.est_rot[:, col] = T_r[:3, :3].reshape(-1, order="F")
-                    S.est_trans[:, col] = T_r[:3, 3]
+                    problems.append((T_f, kp_f, B.landmarks[:3, idx]))
+                    cols_out.append(ncol - 1 - step * (B.num_key - i) + j)
+            for col, T_r in zip(cols_out, T_refinement_batch(problems, K, ctx=ctx)):
+                S.est_rot[:, col] = T_r[:3, :3].reshape(-1, order="F")
+                S.est_trans[:, col] = T_r[:3, 3]
         B.count_frame = 0
     else:                                                       # normal frame, :89-98
         entry = (np.array(T_W_C, dtype=np.float64), S.P[::-1].copy(), S.X[3].copy())
