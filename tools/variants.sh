@@ -3,7 +3,7 @@
 for tag in "$@"; do
   lib=visual-odometry-pipeline_amd/lib/libvohip_$tag.so
   [ "$tag" = base ] && lib=visual-odometry-pipeline_amd/lib/libvohip.so
-  for n in 2000 8192; do
+  for n in 1 2000 8192; do
     VOHIP_LIB=$PWD/$lib timeout -k 10 100 python3 tools/tune_klt.py $n 2>/dev/null | grep "max_iter=20" | sed "s/^/$tag /" || exit 1
   done
   for rep in 1 2; do

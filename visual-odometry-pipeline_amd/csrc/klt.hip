@@ -122,10 +122,24 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int A
         const int col = lane & 31, half = lane >> 5;
         const int a = min(max(a0 + col, 0), A - 1);
         float tmp[NLD];
+        // (a level image has fewer than 2^31 pixels and fewer than 2^24 rows and columns: 32-bit offsets,
+        // 24-bit products)
+        const int b0u = __builtin_amdgcn_readfirstlane(b0);   // (the same in every lane: a scalar branch)
+        if (b0u >= 0 && b0u + 2 * NLD - 1 <= B - 1) {
+            // every row of the patch lies inside the image (nearly always): the rows are a constant stride apart
+            unsigned off = (unsigned)(__mul24(b0u + half, A) + a);
+            const unsigned stride = 2u * (unsigned)A;
 #pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int b = min(max(b0 + 2 * k + half, 0), B - 1);
-            tmp[k] = img[(size_t)b * A + a];   // columns / rows past the patch are clamped reads, never stored
+            for (int k = 0; k < NLD; ++k) {
+                tmp[k] = img[off];
+                off += stride;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int b = min(max(b0 + 2 * k + half, 0), B - 1);
+                tmp[k] = img[(unsigned)(__mul24(b, A) + a)];   // columns / rows past the patch are clamped reads, never stored
+            }
         }
         if (col < S) {   // (one branch: only the last row pair can reach past the patch)
 #pragma unroll
@@ -218,7 +232,7 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                     if (r >= 1 && r <= C::RPL) {
                         const int k = r - 1;
                         const float gx = live[k] ? (sp - sm) * 0.5f : 0.f;
-                        T[k] = live[k] ? s_next : 0.f;
+                        T[k] = s_next;   // (a masked pixel's gradients are zero: its template value never counts)
                         GX[k] = gx;
                         gxx += (double)gx * (double)gx;
                     }

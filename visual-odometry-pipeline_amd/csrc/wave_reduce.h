@@ -9,12 +9,14 @@
 
 namespace vohip_dev {
 
+// (only used with controls that give every lane a source lane -- quad permutations and mirrors -- so the
+// bound-control bit changes nothing but spares the compiler a zero-initialised destination per move)
 template <int CTRL>
 __device__ __forceinline__ double dpp_move_f64(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
