@@ -62,10 +62,19 @@ __device__ __forceinline__ void wave_sum2_f32(float &a, float &b)
     b = dpp_add_f32<0x141>(b);
     a = dpp_add_f32<0x140>(a);
     b = dpp_add_f32<0x140>(b);
-    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x142, 0xA, 0xF, false));
-    b += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x142, 0xA, 0xF, false));
-    a += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a), 0x143, 0xC, 0xF, false));
-    b += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b), 0x143, 0xC, 0xF, false));
+    // The two row broadcasts as adds that write only the rows they concern (rows 1 and 3 += lane 15 of the
+    // row before, then rows 2 and 3 += lane 31): one instruction per step and sum.  Written out because the
+    // compiler may not fold "other rows add zero" into the row mask (x + 0 is not x for x = -0); the rows
+    // that are masked off never reach the total, which is read from the last lane.  A DPP operand must
+    // have been written two instructions earlier: hence the idle slots.
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(a), "+v"(b));
     a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
     b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
 }
