@@ -280,8 +280,13 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                     // positions far outside the image cannot come back; keep integer math bounded
                     const int ja = bounded_int(fta), jb = bounded_int(ftb);
                     if (!staged || abs(ja - cja) > C::MARG || abs(jb - cjb) > C::MARG) {
-                        cja = ja;
-                        cjb = jb;
+                        // an estimate that walked out of the region is likely to walk on: the new region is
+                        // centred ahead of it, in the direction it left by (where a region lies does not
+                        // change what is read from it)
+                        const int la = staged ? min(max(ja - cja, -C::MARG), C::MARG) : 0;
+                        const int lb = staged ? min(max(jb - cjb, -C::MARG), C::MARG) : 0;
+                        cja = ja + la;
+                        cjb = jb + lb;
                         staged = true;
                         __syncthreads();
                         stage_patch<C::SJ>(Ql, A, B, cja - C::HALF - C::MARG, cjb - C::HALF - C::MARG, sJ);
