@@ -29,6 +29,17 @@ classdef FrameLoop < handle
                        'refine_pose', double(hyper_paras.is_refine_pose));
             if nargin > 3 && isfield(feature_params, 'MinQuality'), p.min_quality = feature_params.MinQuality; end
             if nargin > 3 && isfield(feature_params, 'FilterSize'), p.filter_size = feature_params.FilterSize; end
+            if nargin > 3 && isfield(feature_params, 'MinContrast'), p.min_contrast = feature_params.MinContrast; end
+            if isfield(hyper_paras, 'feature_extract')   % genKeypoints.m:17-19
+                switch hyper_paras.feature_extract
+                    case 'Harris',   p.detector = 0;
+                    case 'MinEigen', p.detector = 1;
+                    case 'FAST',     p.detector = 2;
+                        if ~isfield(p, 'min_quality'), p.min_quality = 0.1; end   % detectFASTFeatures' default
+                    otherwise, error('vohip:FrameLoop', 'detector %s is not built natively', hyper_paras.feature_extract);
+                end
+            end
+            if isfield(hyper_paras, 'is_BA'), p.is_BA = double(hyper_paras.is_BA); end
             vohip_mex('frame_create', K, image_size(1), image_size(2), p);
             obj.MapStream = RandStream('mt19937ar', 'Seed', 'shuffle');
         end
