@@ -299,8 +299,10 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                         t0[r] = org[r * C::SJ];
                         t1[r] = org[r * C::SJ + 1];
                     }
+                    // (one subtraction each: left to itself the compiler pairs them up for the packed
+                    // instruction and spends three moves per pair on lining the operands up)
 #pragma unroll
-                    for (int r = 0; r <= C::RPL; ++r) dt[r] = t1[r] - t0[r];
+                    for (int r = 0; r <= C::RPL; ++r) asm("v_sub_f32 %0, %1, %2" : "=v"(dt[r]) : "v"(t1[r]), "v"(t0[r]));
                 }
                 // per-lane partial sums in fp32 (RPL fused multiply-adds, rows in increasing order), then
                 // a fixed fp32 tree across the wavefront
