@@ -711,6 +711,7 @@ struct vohip_frame {
     hipEvent_t ev_advA[2] = {nullptr, nullptr};  // after the early tracker of the kept landmarks INTO the table of that parity
     hipEvent_t tr[8] = {nullptr};   // timing events of the trace option
     hipEvent_t tr_trk[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // ... around the trackers into table [parity]
+    hipEvent_t tr_det[2] = {nullptr, nullptr};                            // ... after the detection in the image of [parity]
     bool trace = false;
     void *block = nullptr;       // one device allocation, carved up below
     void *pinned = nullptr;      // host mirror of the counters and doubles
@@ -906,7 +907,7 @@ int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t 
                        f->cnt + N_DET + par, f->capL + f->capC, f->capU, f->U_xy[par], f->U_live[par]);
     VOHIP_HIP(ctx, hipGetLastError());
     VOHIP_HIP(ctx, hipEventRecord(f->ev_det[par], f->side2));
-    if (f->trace && par == f->par) (void)hipEventRecord(f->tr[5], f->side2);   // detection done
+    if (f->trace) (void)hipEventRecord(f->tr_det[par], f->side2);   // detection done
     return VOHIP_OK;
 }
 
@@ -967,8 +968,8 @@ int enqueue_tail(vohip_frame *f)
                        f->keep, f->cnt, f->dv, f->capC, f->capL + f->capC, f->C_rc, f->F_rc, f->T12, f->srcC, pin_dv(f),
                        pin_cnt(f));
     VOHIP_HIP(ctx, hipGetLastError());
+    if (f->trace) (void)hipEventRecord(f->tr[6], s);   // tail done (before the event the host waits for: it is read right after)
     VOHIP_HIP(ctx, hipEventRecord(f->ev_tail, s));     // what the frame's single synchronisation waits for
-    if (f->trace) (void)hipEventRecord(f->tr[6], s);   // tail done
     return VOHIP_OK;
 }
 
@@ -1088,10 +1089,13 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
     out->host_wait_us = std::chrono::duration<double, std::micro>(t_done - t_wait).count();
     if (f->trace) {
         float ms[8] = {0};
-        for (int q = 2; q < 7; ++q) (void)hipEventElapsedTime(&ms[q], f->tr[0], f->tr[q]);
+        for (int q = 2; q < 7; ++q)
+            if (q != 5) (void)hipEventElapsedTime(&ms[q], f->tr[0], f->tr[q]);
         // (negative when the previous call enqueued this frame's trackers behind its own last kernel)
         (void)hipEventElapsedTime(&ms[7], f->tr[0], f->tr_trk[f->par][0]);
         (void)hipEventElapsedTime(&ms[1], f->tr[0], f->tr_trk[f->par][1]);
+        (void)hipEventElapsedTime(&ms[5], f->tr[0], f->tr_det[f->par]);   // (negative too when the detection ran ahead)
+        (void)hipGetLastError();   // (an event that was not recorded in this frame is no error of the frame)
         std::fprintf(stderr, "vohip frame trace (us from start): tracks %.0f-%.0f  refined %.0f  filter %.0f-%.0f  detect %.0f  tail %.0f | host enqueue %.0f wait %.0f",
                      1e3 * ms[7], 1e3 * ms[1], 1e3 * ms[2], 1e3 * ms[3], 1e3 * ms[4], 1e3 * ms[5], 1e3 * ms[6], out->host_enqueue_us,
                      out->host_wait_us);
@@ -1230,6 +1234,7 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
         f->trace = true;
         for (int q = 0; q < 8; ++q) (void)hipEventCreate(&f->tr[q]);
         for (int q = 0; q < 4; ++q) (void)hipEventCreate(&f->tr_trk[q >> 1][q & 1]);
+        for (int q = 0; q < 2; ++q) (void)hipEventCreate(&f->tr_det[q]);
     }
     *out = f;
     return VOHIP_OK;
@@ -1269,6 +1274,8 @@ int vohip_frame_destroy(vohip_frame *f)
         if (f->tr[q]) (void)hipEventDestroy(f->tr[q]);
     for (int q = 0; q < 4; ++q)
         if (f->tr_trk[q >> 1][q & 1]) (void)hipEventDestroy(f->tr_trk[q >> 1][q & 1]);
+    for (int q = 0; q < 2; ++q)
+        if (f->tr_det[q]) (void)hipEventDestroy(f->tr_det[q]);
     if (f->ev_side) (void)hipEventDestroy(f->ev_side);
     if (f->ev_img) (void)hipEventDestroy(f->ev_img);
     if (f->block) (void)hipFree(f->block);

@@ -292,7 +292,7 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
                         stage_patch<C::SJ>(Ql, A, B, cja - C::HALF - C::MARG, cjb - C::HALF - C::MARG, sJ);
                         __syncthreads();
                     }
-                    const float *org = sJ + (jb - cjb + C::MARG) * C::SJ + (ja - cja + C::MARG) + offJ;
+                    const float *org = sJ + __mul24(jb - cjb + C::MARG, C::SJ) + (ja - cja + C::MARG) + offJ;
                     float t1[C::RPL + 1];
 #pragma unroll
                     for (int r = 0; r <= C::RPL; ++r) {   // all LDS reads first, so that their latencies overlap
