@@ -30,6 +30,7 @@
 #include "vohip_internal.h"
 #include "wave_reduce.h"
 
+#include <cmath>
 #include <cstring>
 
 namespace {
@@ -169,7 +170,7 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int A
 
 // Tracks (pa, pb) from pyramid P to pyramid Q.  sI / sJ: this wavefront's LDS.
 template <int W>
-__device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, double pa, double pb,
+__device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, double min_lmin, double pa, double pb,
                           double &qa, double &qb, float *sI, float *sJ, int &iters)
 {
     using C = klt_cfg<W>;
@@ -255,7 +256,10 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
         }
         const double det = gxx * gyy - gxy * gxy;
         const double lmin = 0.5 * ((gxx + gyy) - sqrt((gxx - gyy) * (gxx - gyy) + 4.0 * gxy * gxy));
-        const bool good = (lmin / (double)(W * W) >= KLT_MIN_EIG) && det > 0.0;
+        // lambda_min / W^2 >= KLT_MIN_EIG, without the division: min_lmin is the smallest double whose
+        // quotient by W^2 rounds to at least KLT_MIN_EIG (the rounded quotient is monotone in lambda_min), so
+        // the comparison below decides exactly as the quotient would
+        const bool good = lmin >= min_lmin && det > 0.0;
         const double inv_det = 1.0 / det;
         // the inverse of the gradient matrix, formed once per level: a step is then two products and two
         // fused multiply-adds
@@ -357,7 +361,7 @@ struct klt_sets {
 
 template <int W>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 21 ? KLT_WAVES_21 : 2, W <= 21 ? KLT_WAVES_21 : 2)))
-void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_iter, double max_bidir,
+void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_iter, double max_bidir, double min_lmin,
                       unsigned long long *__restrict__ stats)
 {
     using C = klt_cfg<W>;
@@ -403,7 +407,7 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
     const double pa = swap_xy ? y : x, pb = swap_xy ? x : y;
     double qa, qb, ra, rb;
     int iters = 0;
-    const bool ok_f = track_dir<W>(P, Q, max_iter, pa, pb, qa, qb, sI, sJ, iters);
+    const bool ok_f = track_dir<W>(P, Q, max_iter, min_lmin, pa, pb, qa, qb, sI, sJ, iters);
     const bool inside = qa >= 0.0 && qa <= (double)(P.A[0] - 1) && qb >= 0.0 && qb <= (double)(P.B[0] - 1);
     // A track that is already invalid after the forward pass (untrackable at level 0, or outside the image)
     // is not tracked back: its forward-backward distance is reported as infinite.  (qa, qb are the same in
@@ -411,7 +415,7 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
     bool ok_b = false;
     double err = __builtin_inf();
     if (ok_f && inside) {
-        ok_b = track_dir<W>(Q, P, max_iter, qa, qb, ra, rb, sI, sJ, iters);
+        ok_b = track_dir<W>(Q, P, max_iter, min_lmin, qa, qb, ra, rb, sI, sJ, iters);
         const double ea = ra - pa, eb = rb - pb;
         err = sqrt(ea * ea + eb * eb);
     }
@@ -433,6 +437,16 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// The smallest double x with x / W^2 >= KLT_MIN_EIG as the division rounds it.
+static double lmin_threshold(int W)
+{
+    const double d = (double)(W * W);
+    double c = KLT_MIN_EIG * d;
+    while (c / d >= KLT_MIN_EIG) c = std::nextafter(c, 0.0);
+    while (!(c / d >= KLT_MIN_EIG)) c = std::nextafter(c, INFINITY);
+    return c;
+}
+
 int vohip_pyramid_desc(vohip_ctx *ctx, int slot, pyr_desc &d)
 {
     VOHIP_REQUIRE(ctx, slot >= 0 && slot < VOHIP_PYR_SLOTS, "pyramid slot out of range");
@@ -557,10 +571,10 @@ int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vo
     unsigned long long *d_stats = ctx->opt_klt_stats ? (unsigned long long *)ctx->bufs[B_KLT_STATS].ptr : nullptr;
     if (block_size == 21)
         hipLaunchKernelGGL(klt_track_kernel<21>, dim3(total), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
-                           max_bidir_error, d_stats);
+                           max_bidir_error, lmin_threshold(21), d_stats);
     else if (block_size == 31)
         hipLaunchKernelGGL(klt_track_kernel<31>, dim3(total), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
-                           max_bidir_error, d_stats);
+                           max_bidir_error, lmin_threshold(31), d_stats);
     else
         return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "BlockSize %d not built (21 and 31 are)", block_size);
     VOHIP_HIP(ctx, hipGetLastError());
