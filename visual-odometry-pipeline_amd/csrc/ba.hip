@@ -379,6 +379,12 @@ __device__ __forceinline__ bool cholesky_solve_rows(double *S, const double *g, 
     for (int c = 0; c < NP; ++c) A[c] = (row && c <= i) ? S[i * NP + c] : 0.0;
     bool pos = true;
     double diag = 1.0;
+    // Column j of the factor travels through LDS: every lane writes its entry and reads the entries of the
+    // rows below the pivot back (all lanes read the same address: a broadcast), which costs half the
+    // instructions of one register broadcast per entry and none of its waits.  `col`: NP doubles of LDS that
+    // nothing else uses meanwhile (the wavefront runs alone by now; LDS operations of one wavefront complete
+    // in order).
+    double *col = S + NP * NP;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const double d = readlane_f64(A[j], j);
@@ -387,11 +393,21 @@ __device__ __forceinline__ bool cholesky_solve_rows(double *S, const double *g, 
         const double Lij = i > j ? A[j] / r : (i == j ? r : 0.0);
         A[j] = Lij;
         if (i == j) diag = r;
+        if (j + 1 < NP) {
+            if (row) col[i] = Lij;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int k = j + 1; k < NP; ++k) {
-            const double Lkj = readlane_f64(Lij, k);
-            A[k] -= i >= k ? Lij * Lkj : 0.0;
-            if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // (keeps the broadcasts next to their use)
+            for (int c = 0; c < (NP + 7) / 8; ++c) {   // eight reads in flight, then their eight updates
+                double Lk[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) Lk[q] = (8 * c + q > j && 8 * c + q < NP) ? col[8 * c + q] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (8 * c + q > j && 8 * c + q < NP) A[8 * c + q] -= i >= 8 * c + q ? Lij * Lk[q] : 0.0;
+            }
+            __builtin_amdgcn_wave_barrier();   // (the next column is written after every lane has read this one)
         }
     }
     // the factor goes back to LDS: the backward substitution reads it by columns
@@ -453,13 +469,16 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(int np, int nblocks, in
         g_red[(size_t)blockIdx.x * np + e] = count > 0 ? ordered_partial_sum(g_part + (size_t)first * np, (size_t)np, count, e) : 0.0;
 }
 
-// 1024 threads: every entry of the reduced system (900 at 5 frames) has a thread of its own for the ordered
-// sum over the partial systems, which is what this kernel's time is (one wavefront then factorises).
-__global__ __launch_bounds__(1024) void ba_solve_kernel(int np, int nblocks, const double *__restrict__ S_part,
+// 256 threads share the entries of the reduced system (900 at 5 frames) for the ordered sum over the partial
+// systems; one wavefront then factorises.  Not more threads: the register budget of a kernel shrinks with its
+// workgroup size, and the factorisation (a row of up to 48 doubles per lane, fully unrolled) spills below
+// 256 registers -- measured at 5 frames: 1024 threads 29.7 us, 512 29.0, 256 20.6, 128 23.9.
+constexpr int BA_SOLVE_THREADS = 256;
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_kernel(int np, int nblocks, const double *__restrict__ S_part,
                                                        const double *__restrict__ g_part, ba_status *__restrict__ st,
                                                        const int *__restrict__ fail_flag, double *__restrict__ dp)
 {
-    __shared__ double S[6 * FMAX * 6 * FMAX];
+    __shared__ double S[6 * FMAX * 6 * FMAX + 6 * FMAX];   // (+ one column for the factorisation)
     __shared__ double g[6 * FMAX];
     __shared__ int ok;
     const int tid = threadIdx.x;
@@ -963,10 +982,10 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
             hipLaunchKernelGGL(ba_reduce_kernel, dim3(RED_GROUPS), dim3(1024), 0, s, np, nb_lin, red_chunk,
                                (const double *)d_Sp, (const double *)d_gp, (const ba_status *)d_st, (double *)d_Sr,
                                (double *)d_gr);
-            hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(1024), 0, s, np, RED_GROUPS, (const double *)d_Sr,
+            hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(BA_SOLVE_THREADS), 0, s, np, RED_GROUPS, (const double *)d_Sr,
                                (const double *)d_gr, (ba_status *)d_st, (const int *)d_fail, (double *)d_dp);
         } else {
-            hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(1024), 0, s, np, nb_lin, (const double *)d_Sp,
+            hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(BA_SOLVE_THREADS), 0, s, np, nb_lin, (const double *)d_Sp,
                                (const double *)d_gp, (ba_status *)d_st, (const int *)d_fail, (double *)d_dp);
         }
         hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, s, P, (double *)d_state, (double *)d_trial,
