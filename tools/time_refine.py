@@ -13,7 +13,7 @@ ctx = vo.Context(0)
 lib = vo._lib.load()
 K = vo.synth.K_KITTI
 Kc = vo._lib.colmajor(K)
-for n in (300, 1300, 3000, 8000):
+for n in [int(a) for a in sys.argv[1:]] or (300, 1300, 3000, 8000):
     kp_rc, X, R, t, inl = vo.synth.pnp_problem(n, inlier_ratio=1.0, seed=3)
     T_C_W = np.eye(4)
     T_C_W[:3, :3], T_C_W[:3, 3] = R, t

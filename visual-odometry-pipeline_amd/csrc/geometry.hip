@@ -173,7 +173,8 @@ __global__ __launch_bounds__(128) void candidate_triangulate_kernel(const double
                                                                     double *__restrict__ X_out,
                                                                     double *__restrict__ angles)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // four lanes per candidate (the triangulation is shared by the quad; the rest is cheap and repeated)
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     if (n_dev) n = *n_dev;  // count and pose kept on the device (the frame pipeline)
     if (i >= n) return;
     if (T_dev)
@@ -183,8 +184,9 @@ __global__ __launch_bounds__(128) void candidate_triangulate_kernel(const double
     const double cur[2] = {cur_rc[2 * (size_t)i], cur_rc[2 * (size_t)i + 1]};
     const double fst[2] = {first_rc[2 * (size_t)i], first_rc[2 * (size_t)i + 1]};
     double X[3], ang;
-    const int st = candidate_point(cur, fst, Tf, prm.T_W_C, prm.K, prm.angle_threshold_deg, prm.min_depth,
-                                   prm.max_depth, prm.is_BA, X, ang);
+    const int st = candidate_point<true>(cur, fst, Tf, prm.T_W_C, prm.K, prm.angle_threshold_deg, prm.min_depth,
+                                         prm.max_depth, prm.is_BA, X, ang);
+    if ((threadIdx.x & 3) != 0) return;
     status[i] = (uint8_t)st;
     for (int k = 0; k < 3; ++k) X_out[3 * (size_t)i + k] = X[k];
     if (angles) angles[i] = ang;
@@ -320,7 +322,7 @@ int vohip_candidate_triangulate_enqueue(vohip_ctx *ctx, const double *d_cur_rc, 
     prm.min_depth = min_depth;
     prm.max_depth = max_depth;
     prm.is_BA = is_BA;
-    hipLaunchKernelGGL(candidate_triangulate_kernel, dim3((n_cap + 127) / 128), dim3(128), 0, ctx->stream, d_cur_rc,
+    hipLaunchKernelGGL(candidate_triangulate_kernel, dim3((n_cap + 31) / 32), dim3(128), 0, ctx->stream, d_cur_rc,
                        d_first_rc, d_T_first, n_cap, d_n, d_T_W_C, prm, d_status, d_X, (double *)nullptr);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
@@ -362,7 +364,7 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
     prm.min_depth = min_depth;
     prm.max_depth = max_depth;
     prm.is_BA = is_BA;
-    hipLaunchKernelGGL(candidate_triangulate_kernel, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, d_cur_rc,
+    hipLaunchKernelGGL(candidate_triangulate_kernel, dim3((n + 31) / 32), dim3(128), 0, ctx->stream, d_cur_rc,
                        d_first_rc, d_T_first, n, (const int *)nullptr, (const double *)nullptr, prm, d_status, d_X,
                        d_angles);
     VOHIP_HIP(ctx, hipGetLastError());

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "se3_device.h"
+#include "wave_reduce.h"
 
 namespace vohip_dev {
 
@@ -82,6 +83,105 @@ __device__ inline void triangulate_point(const double p1[3], const double p2[3],
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) P[r] = v[r] / v[3];
+}
+
+// The same decomposition by FOUR lanes, an aligned quad of a one-dimensional workgroup whose size is a
+// multiple of 64: lane c of the quad owns column c of A and of V, and in each of the three rounds of a sweep
+// two disjoint pairs of columns rotate at once ((0,1) (2,3), then (0,2) (1,3), then (0,3) (1,2)); the partner's
+// column crosses by DPP quad permutations.  A point's dependent instruction chain, which is what a launch of
+// few points lasts, is half as long as in the single-lane routine.  The order of the rotations differs from
+// that routine's (cyclic by rows), so the singular vector agrees with it to rounding, not bit for bit.
+// Every lane of the quad calls it with the same arguments and receives the same P.
+template <int CTRL>
+__device__ __forceinline__ int dpp_move_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+template <int CTRL, int MASK>
+__device__ __forceinline__ bool quad_jacobi_round(int c, double a[6], double v[4])
+{
+    double b[6], w[4];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) b[r] = dpp_move_f64<CTRL>(a[r]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = dpp_move_f64<CTRL>(v[r]);
+    const bool lo = (c & (MASK == 1 ? 1 : 2)) == 0;   // this lane owns the pair's column of lower index
+    double n_own = 0, n_par = 0, ga = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        n_own += a[r] * a[r];
+        n_par += b[r] * b[r];
+        ga += a[r] * b[r];
+    }
+    const double al = lo ? n_own : n_par, be = lo ? n_par : n_own;   // (both lanes of a pair hold the same three sums)
+    if (!(ga * ga > 1e-30 * (al * be))) return false;
+    const double d = be - al, g2 = 2.0 * ga;
+    const double sg = (d == 0.0 || (d > 0.0) == (ga > 0.0)) ? fabs(g2) : -fabs(g2);
+    const double t = sg / (fabs(d) + sqrt(__builtin_fma(d, d, g2 * g2)));
+    const double cs = rsqrt(__builtin_fma(t, t, 1.0)), sn = cs * t;
+    const double ss = lo ? -sn : sn;   // column i becomes c a_i - s a_j, column j becomes s a_i + c a_j
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a[r] = cs * a[r] + ss * b[r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = cs * v[r] + ss * w[r];
+    return true;
+}
+
+__device__ inline void triangulate_point_quad(const double p1[3], const double p2[3], const double m[3],
+                                              const double q[3], double P[4])
+{
+    // m, q: column c of M1 and of M2 (c = this lane's place in its quad)
+    const int lane = threadIdx.x & 63, c = lane & 3;
+    double a[6], v[4];
+    a[0] = -p1[2] * m[1] + p1[1] * m[2];
+    a[1] = p1[2] * m[0] - p1[0] * m[2];
+    a[2] = -p1[1] * m[0] + p1[0] * m[1];
+    a[3] = -p2[2] * q[1] + p2[1] * q[2];
+    a[4] = p2[2] * q[0] - p2[0] * q[2];
+    a[5] = -p2[1] * q[0] + p2[0] * q[1];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (r == c) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        bool rotated = quad_jacobi_round<0xB1, 1>(c, a, v);    // quad_perm [1,0,3,2]
+        rotated |= quad_jacobi_round<0x4E, 2>(c, a, v);        // quad_perm [2,3,0,1]
+        rotated |= quad_jacobi_round<0x1B, 3>(c, a, v);        // quad_perm [3,2,1,0]
+        const unsigned long long any = __ballot(rotated);
+        if (((any >> (lane & ~3)) & 0xFull) == 0) break;       // (the same decision in the four lanes)
+    }
+    // the column of least norm, the first of equals (a norm that is not finite never wins: P = (0, 0, 0, 1) then)
+    double nn = 0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) nn += a[r] * a[r];
+    const bool finite = nn < INFINITY;
+    double bn = finite ? nn : INFINITY;
+    int bi = finite ? c : 4;
+    {
+        const double on = dpp_move_f64<0xB1>(bn);
+        const int oi = dpp_move_i32<0xB1>(bi);
+        if (on < bn || (on == bn && oi < bi)) {
+            bn = on;
+            bi = oi;
+        }
+    }
+    {
+        const double on = dpp_move_f64<0x4E>(bn);
+        const int oi = dpp_move_i32<0x4E>(bi);
+        if (on < bn || (on == bn && oi < bi)) {
+            bn = on;
+            bi = oi;
+        }
+    }
+    const int src = (lane & ~3) | (bi & 3);
+    double vs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vs[r] = __shfl(v[r], src, 64);
+    if (bi > 3) {
+        vs[0] = vs[1] = vs[2] = 0.0;
+        vs[3] = 1.0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) P[r] = vs[r] / vs[3];
 }
 
 // 4 reprojection residuals of a 3-D point in two views and, optionally, their 4x3 Jacobian
@@ -194,6 +294,8 @@ __device__ inline void refine_point(double P[3], const double p1[2], const doubl
 // update_landmarks.m:27-97 for one candidate that survived tracking and the epipolar filter.
 // cur, first: (row, col); Tf = [R_W_Cf(:); t_W_Cf]; T_W_C 4x4 column-major; K column-major.
 // Returns 0 = keep as candidate, 1 = new landmark (X valid), 2 = dropped.
+// QUAD: called by the four lanes of an aligned quad with the same arguments (triangulate_point_quad).
+template <bool QUAD = false>
 __device__ inline int candidate_point(const double cur[2], const double first[2], const double Tf[12],
                                       const double *T_W_C, const double *K, double angle_threshold_deg,
                                       double min_depth, double max_depth, int is_BA, double X[3], double &angle_deg)
@@ -249,7 +351,18 @@ __device__ inline int candidate_point(const double cur[2], const double first[2]
             Mf[3 * c + a] = K[a] * f0 + K[3 + a] * f1 + K[6 + a] * f2;
         }
     double P[4];
-    triangulate_point(pc, pf, Mc, Mf, P);
+    if constexpr (QUAD) {
+        const int c = threadIdx.x & 3;
+        double mc[3], mf[3];   // (selected, not indexed: an index that is not a constant would send the matrices to scratch)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mc[a] = c == 0 ? Mc[a] : c == 1 ? Mc[3 + a] : c == 2 ? Mc[6 + a] : Mc[9 + a];
+            mf[a] = c == 0 ? Mf[a] : c == 1 ? Mf[3 + a] : c == 2 ? Mf[6 + a] : Mf[9 + a];
+        }
+        triangulate_point_quad(pc, pf, mc, mf, P);
+    } else {
+        triangulate_point(pc, pf, Mc, Mf, P);
+    }
     const double depth = Tcw.R[2][0] * P[0] + Tcw.R[2][1] * P[1] + Tcw.R[2][2] * P[2] + Tcw.t[2] * P[3];
     bool ok = depth > min_depth && depth < max_depth;
     if (ok && is_BA) {
