@@ -41,7 +41,8 @@ def test_run_ba_matches_golden(vo, ctx):
     assert s1.shape == g["state0"].shape
 
 
-@pytest.mark.parametrize("F,m,seed", [(5, 1000, 21), (3, 80, 22), (8, 400, 23), (2, 17, 24), (5, 16, 25)])
+@pytest.mark.parametrize("F,m,seed", [(5, 1000, 21), (3, 80, 22), (8, 400, 23), (2, 17, 24), (5, 16, 25), (1, 60, 26), (4, 120, 27),
+                                      (6, 200, 28), (7, 150, 29)])
 def test_run_ba_matches_oracle(vo, ctx, oracle, F, m, seed):
     K = vo.synth.K_KITTI
     s0, obs, st = vo.synth.ba_problem(F=F, m=m, seed=seed)

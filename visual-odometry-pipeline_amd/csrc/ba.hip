@@ -366,9 +366,14 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(ba_problem P, const d
 // Sums the partial systems, Cholesky in LDS, pose step dp (np doubles).
 // Solves S x = g (S symmetric positive definite, NP x NP row-major in LDS, g in LDS) with the calling
 // wavefront: lane i keeps row i of the lower triangle in registers (every loop is unrolled, so the
-// row is never indexed dynamically), pivots and multipliers travel by register broadcast.
+// row is never indexed dynamically), pivots travel by register broadcast, a column's multipliers through LDS.
 // Right-looking Cholesky, then the two substitutions column by column.  Returns false (in every
 // lane) when a pivot is not positive; x = this lane's unknown.
+// (At 42 and 48 rows the compiler declines to unroll the column loop -- the unrolled code would be too large --
+// and the row lives in scratch memory instead: correct, slower, and its warning is switched off from here to the
+// end of the kernel the routine is inlined into.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
 template <int NP>
 __device__ __forceinline__ bool cholesky_solve_rows(double *S, const double *g, double &x)
 {
@@ -473,38 +478,56 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(int np, int nblocks, in
 // systems; one wavefront then factorises.  Not more threads: the register budget of a kernel shrinks with its
 // workgroup size, and the factorisation (a row of up to 48 doubles per lane, fully unrolled) spills below
 // 256 registers -- measured at 5 frames: 1024 threads 29.7 us, 512 29.0, 256 20.6, 128 23.9.
+// One kernel per window size (NP = 6 F unknowns): a kernel's registers are those of its largest code path, so
+// one kernel that switches over the sizes would carry the 48-row factorisation's spills at every size.
 constexpr int BA_SOLVE_THREADS = 256;
-__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_kernel(int np, int nblocks, const double *__restrict__ S_part,
-                                                       const double *__restrict__ g_part, ba_status *__restrict__ st,
-                                                       const int *__restrict__ fail_flag, double *__restrict__ dp)
+template <int NP>
+__global__ __launch_bounds__(BA_SOLVE_THREADS) void ba_solve_kernel(int nblocks, const double *__restrict__ S_part,
+                                                                    const double *__restrict__ g_part,
+                                                                    ba_status *__restrict__ st,
+                                                                    const int *__restrict__ fail_flag,
+                                                                    double *__restrict__ dp)
 {
-    __shared__ double S[6 * FMAX * 6 * FMAX + 6 * FMAX];   // (+ one column for the factorisation)
-    __shared__ double g[6 * FMAX];
+    __shared__ double S[NP * NP + NP];   // (+ one column for the factorisation)
+    __shared__ double g[NP];
     __shared__ int ok;
     const int tid = threadIdx.x;
     if (st->done) return;
-    for (int e = tid; e < np * np; e += blockDim.x) S[e] = ordered_partial_sum(S_part, (size_t)np * np, nblocks, e);
-    for (int e = tid; e < np; e += blockDim.x) g[e] = -ordered_partial_sum(g_part, (size_t)np, nblocks, e);
+    for (int e = tid; e < NP * NP; e += BA_SOLVE_THREADS) S[e] = ordered_partial_sum(S_part, (size_t)NP * NP, nblocks, e);
+    for (int e = tid; e < NP; e += BA_SOLVE_THREADS) g[e] = -ordered_partial_sum(g_part, (size_t)NP, nblocks, e);
     if (tid == 0) ok = *fail_flag ? 0 : 1;
     __syncthreads();
-    // The factorisation and the two substitutions are one wavefront's work (np <= 48 rows, lane i owns
+    // The factorisation and the two substitutions are one wavefront's work (NP <= 48 rows, lane i owns
     // row i, in registers); the other wavefronts leave.
     if (tid >= 64) return;
-    bool good = false;
     double x = 0.0;
-    switch (np / 6) {
-    case 1: good = cholesky_solve_rows<6>(S, g, x); break;
-    case 2: good = cholesky_solve_rows<12>(S, g, x); break;
-    case 3: good = cholesky_solve_rows<18>(S, g, x); break;
-    case 4: good = cholesky_solve_rows<24>(S, g, x); break;
-    case 5: good = cholesky_solve_rows<30>(S, g, x); break;
-    case 6: good = cholesky_solve_rows<36>(S, g, x); break;
-    case 7: good = cholesky_solve_rows<42>(S, g, x); break;
-    default: good = cholesky_solve_rows<48>(S, g, x); break;
-    }
-    good = good && ok;
-    if (good && tid < np) dp[tid] = x;
+    const bool good = cholesky_solve_rows<NP>(S, g, x) && ok;
+    if (good && tid < NP) dp[tid] = x;
     if (tid == 0) st->solve_failed = good ? 0 : 1;
+}
+
+#pragma clang diagnostic pop
+
+void launch_ba_solve(hipStream_t s, int F, int nblocks, const double *S_part, const double *g_part, ba_status *st,
+                     const int *fail_flag, double *dp)
+{
+#define BA_SOLVE_CASE(f)                                                                                              \
+    case f:                                                                                                           \
+        hipLaunchKernelGGL(ba_solve_kernel<6 * f>, dim3(1), dim3(BA_SOLVE_THREADS), 0, s, nblocks, S_part, g_part, st, \
+                           fail_flag, dp);                                                                            \
+        break;
+    switch (F) {
+        BA_SOLVE_CASE(1)
+        BA_SOLVE_CASE(2)
+        BA_SOLVE_CASE(3)
+        BA_SOLVE_CASE(4)
+        BA_SOLVE_CASE(5)
+        BA_SOLVE_CASE(6)
+        BA_SOLVE_CASE(7)
+        BA_SOLVE_CASE(8)
+    }
+#undef BA_SOLVE_CASE
+    static_assert(FMAX == 8, "one case per window size");
 }
 
 // Back-substitution, trial state and its cost.  One thread per landmark.
@@ -982,11 +1005,11 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
             hipLaunchKernelGGL(ba_reduce_kernel, dim3(RED_GROUPS), dim3(1024), 0, s, np, nb_lin, red_chunk,
                                (const double *)d_Sp, (const double *)d_gp, (const ba_status *)d_st, (double *)d_Sr,
                                (double *)d_gr);
-            hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(BA_SOLVE_THREADS), 0, s, np, RED_GROUPS, (const double *)d_Sr,
-                               (const double *)d_gr, (ba_status *)d_st, (const int *)d_fail, (double *)d_dp);
+            launch_ba_solve(s, np / 6, RED_GROUPS, (const double *)d_Sr, (const double *)d_gr, (ba_status *)d_st,
+                            (const int *)d_fail, (double *)d_dp);
         } else {
-            hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(BA_SOLVE_THREADS), 0, s, np, nb_lin, (const double *)d_Sp,
-                               (const double *)d_gp, (ba_status *)d_st, (const int *)d_fail, (double *)d_dp);
+            launch_ba_solve(s, np / 6, nb_lin, (const double *)d_Sp, (const double *)d_gp, (ba_status *)d_st,
+                            (const int *)d_fail, (double *)d_dp);
         }
         hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, s, P, (double *)d_state, (double *)d_trial,
                            (const double *)d_dp, (const double *)d_E, (const double *)d_gl, (const double *)d_W,
