@@ -735,6 +735,7 @@ struct vohip_frame {
     int slot_prev = 0, slot_cur = 0, slot_next = 0;   // pyramids of the previous, the current and the following image
     int par = 0;                 // parity of the frame being processed
     bool ahead_launched = false; // this call prepares the next image
+    bool split_used[2] = {false, false};   // the last trackers INTO the table of that parity ran as two launches (ev_advC recorded)
     bool ahead = false;          // the previous call left this image's pyramid and corners on the device and
                                  // enqueued this frame's trackers behind its own last kernel
     int n_L = 0, n_C = 0;        // counts at the start of the frame (known to the host)
@@ -896,13 +897,13 @@ int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t 
 {
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
-    VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, ready, 0));
+    if (ready) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, ready, 0));   // (NULL: the image was on the device all along)
     VOHIP_TRY(vohip_detect_corners_enqueue(ctx, f->side2, f->corner_scratch, &f->det_calls, d_img, f->rows, f->cols,
                                            f->colmajor, p.min_quality, p.filter_size, p.border, p.detector,
                                            p.min_contrast, f->corner_xy[par], f->corner_metric[par], f->capK, f->cnt + N_DET + par));
     if (table_free) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, table_free, 0));
     // (the candidate tracker, when it last ran as a launch of its own; complete long ago otherwise)
-    if (table_free) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, f->ev_advC[par ^ 1], 0));
+    if (table_free && f->split_used[par ^ 1]) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, f->ev_advC[par ^ 1], 0));
     hipLaunchKernelGGL(detection_rows_kernel, dim3(blocks256(f->capK)), dim3(256), 0, f->side2, f->corner_xy[par], f->capK,
                        f->cnt + N_DET + par, f->capL + f->capC, f->capU, f->U_xy[par], f->U_live[par]);
     VOHIP_HIP(ctx, hipGetLastError());
@@ -1005,8 +1006,10 @@ int enqueue_trackers(vohip_frame *f, int par, int slot_from, int slot_to, int nL
         VOHIP_TRY(vohip_klt_enqueue_sets(ctx, slot_from, slot_to, sets + 1, 1, p.klt_block, p.klt_max_iter,
                                          p.klt_max_bidir_error));
         VOHIP_HIP(ctx, hipEventRecord(f->ev_advC[par], f->side));
+        f->split_used[par] = true;
         return VOHIP_OK;
     }
+    f->split_used[par] = false;
     VOHIP_TRY(vohip_klt_enqueue_sets(ctx, slot_from, slot_to, sets, 2, p.klt_block, p.klt_max_iter, p.klt_max_bidir_error));
     if (f->trace) (void)hipEventRecord(f->tr_trk[par][1], ctx->stream);
     VOHIP_HIP(ctx, hipEventRecord(f->ev_adv[par], ctx->stream));   // the other streams start from here
@@ -1299,6 +1302,7 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     VOHIP_HIP(ctx, hipStreamSynchronize(f->trk));
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
     f->ahead = f->ahead_launched = false;
+    f->split_used[0] = f->split_used[1] = false;
     f->par = 1;   // the first image of a sequence counts as an even frame
     const uint8_t *d_img = image;
     if (!image_on_device) {
@@ -1439,8 +1443,10 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
         // streams of their own, beside the trackers (which leave most of the GPU idle): the next image,
         // its pyramid (third slot) and its corners, so that the next call starts with its trackers
         stream_swap sw(ctx, f->trk);
-        if (!next_on_device) VOHIP_TRY(enqueue_image_transfer(f, next_image, f->img[par ^ 1], f->trk));
-        VOHIP_HIP(ctx, hipEventRecord(f->ev_next, f->trk));
+        if (!next_on_device) {
+            VOHIP_TRY(enqueue_image_transfer(f, next_image, f->img[par ^ 1], f->trk));
+            VOHIP_HIP(ctx, hipEventRecord(f->ev_next, f->trk));   // (the corner detection waits for the transfer)
+        }
         VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_next, d_next, f->rows, f->cols, f->colmajor, p.klt_levels));
         VOHIP_HIP(ctx, hipEventRecord(f->ev_img, f->trk));
     }
@@ -1448,7 +1454,7 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     VOHIP_TRY(enqueue_tail(f));
     if (next_image) VOHIP_TRY(enqueue_trackers_ahead(f));
     // (last: nothing waits for the following image's corners before the next call's final kernels)
-    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, f->ev_next, f->ev_adv[par]));
+    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, next_on_device ? nullptr : f->ev_next, f->ev_adv[par]));
     f->h_cur = h;
     f->stage = 2;
     f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
