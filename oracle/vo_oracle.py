@@ -303,7 +303,7 @@ def ba_error(state, obs, K):
     return r[:2 * n].reshape(n, 2).T.copy()
 
 
-def run_ba(state, obs, K, max_iter=21, ftol=1e-10, xtol=1e-10):
+def run_ba(state, obs, K, max_iter=21, ftol=1e-6, xtol=1e-6):   # lsqnonlin's default tolerances (runBA.m:77-78)
     s = _f64(state).reshape(-1).copy()
     o = _f64(obs).reshape(-1)
     Kc = _f64(np.asarray(K).T)

@@ -130,7 +130,7 @@ def make_ba():
     K = vo_synth.K_KITTI
     s0, obs, st = vo_synth.ba_problem(F=5, m=300, seed=9)
     r0 = orc.ba_error(s0, obs, K)
-    s1, info = orc.run_ba(s0, obs, K)
+    s1, info = orc.run_ba(s0, obs, K, ftol=1e-10, xtol=1e-10)
     kp_rc, X, R, t, _ = vo_synth.pnp_problem(500, inlier_ratio=1.0, seed=13)
     T_C_W = np.eye(4)
     T_C_W[:3, :3] = R

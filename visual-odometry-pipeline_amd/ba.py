@@ -10,8 +10,10 @@ from ._lib import as_f64, colmajor, dptr
 
 BA_MAX_ITER = 21          # the reference's budget: lsqnonlin MaxIter 1 + MaxIter 20 (runBA.m:65-78)
 POSE_MAX_ITER = 100       # T_refinement.m:4
-FTOL = 1e-10
-XTOL = 1e-10
+# runBA.m:77-78 leaves the tolerances of its second, 20-iteration stage at lsqnonlin's defaults
+# (FunctionTolerance = StepTolerance = 1e-6)
+FTOL = 1e-6
+XTOL = 1e-6
 # T_refinement.m:4 leaves lsqnonlin's tolerances at their defaults (FunctionTolerance = StepTolerance = 1e-6)
 POSE_FTOL = 1e-6
 POSE_XTOL = 1e-6

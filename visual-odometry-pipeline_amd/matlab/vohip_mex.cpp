@@ -232,7 +232,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         // state = vohip_mex('ba_run', state, observations, K, max_iter)
         plhs[0] = mxDuplicateArray(in[0]);
         check(vohip_ba_run(c, mxGetDoubles(plhs[0]), numel(in[0]), dbl(in[1], "observations"), numel(in[1]),
-                           dbl(in[2], "K"), (int)mxGetScalar(in[3]), 1e-10, 1e-10, nullptr));
+                           dbl(in[2], "K"), (int)mxGetScalar(in[3]), 1e-6, 1e-6, nullptr));
     } else if (is("pose_refine")) {
         // T = vohip_mex('pose_refine', T_W_C, keypoints_uv 2xN, landmarks 3xN, K, max_iter)
         plhs[0] = mxDuplicateArray(in[0]);
