@@ -305,6 +305,50 @@ int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, doub
  * stream only: trackers already enqueued for the following frame keep running. */
 int vohip_frame_apply_ba(vohip_frame *f, const double *X, int n, const double T_W_C[16]);
 
+/* ---- the bundle-adjustment window ---------------------------------------------------------------
+ * Continuous_operation/VO_bundle_adjust.m:1-98 with the struct B of main_demo.m:288-303 kept by the
+ * library: keyframe / normal-frame bookkeeping, window slide, global landmark ids -> columns of the
+ * state vector on the host (the reference's find(row == column) look-ups as binary searches: id rows
+ * ascend, update_landmarks.m:83-87), runBA (:51) and the re-refinement of the buffered normal frames
+ * (:71-86, one batched launch) on the GPU.
+ */
+typedef struct vohip_window vohip_window;
+
+typedef struct vohip_window_params {
+    int window_size, keyframe_d;        /* main_BA.m:197-198 (5, 1); main_demo.m:288-289 */
+    double min_depth, max_depth;        /* hyper_paras, VO_bundle_adjust.m:65 */
+    int ba_max_iter;                    /* 21 = runBA.m:65-78 */
+    double ba_ftol, ba_xtol;            /* lsqnonlin's defaults, 1e-6 */
+    int refine_max_iter;                /* T_refinement.m:4 */
+    double refine_ftol, refine_xtol;
+} vohip_window_params;
+
+void vohip_window_default_params(vohip_window_params *p);
+/* K 3x3 column-major. */
+int vohip_window_create(vohip_ctx *ctx, const double K[9], const vohip_window_params *params, vohip_window **out);
+int vohip_window_destroy(vohip_window *w);
+/* main_demo.m:288-303: the window holds the bootstrap keyframe; X 3xn (ids 1..n), P_rc 2xn (row; col),
+ * T_W_C 4x4 column-major. */
+int vohip_window_reset(vohip_window *w, const double *X, const double *P_rc, int n, const double T_W_C[16]);
+/* [S, B] = VO_bundle_adjust(S, B, T_W_C, K, hyper_paras) for the frame whose landmarks are P_rc (S.P, 2xn),
+ * X (S.X(1:3,:), 3xn, updated in place by :62-70) and ids (S.X(4,:), ascending), after update_landmarks
+ * (ids at or above B.new_idx join the window first, update_landmarks.m:83-95).  When the frame is a
+ * keyframe of a full window, *optimised = 1 and the poses VO_bundle_adjust.m:53-57,80-84 rewrites come
+ * back as *n_poses pairs: offsets[k] <= 0 is the column of S.est_trans / S.est_rot counted from the
+ * last one (0 = this frame), poses + 16 k its 4x4 column-major T_W_C; cap >= window_size +
+ * (window_size - 1) keyframe_d entries. */
+int vohip_window_step(vohip_window *w, const double *P_rc, double *X, const double *ids, int n, const double T_W_C[16],
+                      int *optimised, int *n_poses, int *offsets, double *poses, int cap);
+/* Copies of B.num_key, B.m = size(B.landmarks, 2), B.tau (6 x num_key) and B.landmarks (4 x m, [X; id]);
+ * any pointer may be NULL (call once for the sizes). */
+int vohip_window_state(vohip_window *w, int *num_key, int *m, double *tau, double *landmarks);
+/* vohip_window_step for a loop whose state lives on the GPU (main_BA.m:288-291): S.P and S.X come down
+ * in one round trip, and after an optimised window the landmarks and the keyframe's pose go back up
+ * (vohip_frame_apply_ba).  Call it between frames; it runs on a side stream, beside the trackers
+ * already enqueued for the following frame. */
+int vohip_frame_bundle_adjust(vohip_frame *f, vohip_window *w, const double T_W_C[16], int *optimised, int *n_poses,
+                              int *offsets, double *poses, int cap);
+
 /* ---- trajectory alignment (evaluation) ---------------------------------------------------------
  * utils/exe9_BA/alignEstimateToGroundTruth.m:1-27 with the residual of alignError.m:1-17, as
  * utils/quantitative_eval.m:23-24 calls it: finds x = [twist of T_G_V (v; w); scale] minimising

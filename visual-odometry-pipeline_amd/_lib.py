@@ -63,8 +63,24 @@ class FrameCounts(C.Structure):
                 ("host_wait_us", C.c_double)]
 
 
+class WindowParams(C.Structure):
+    """vohip_window_params"""
+    _fields_ = [("window_size", C.c_int), ("keyframe_d", C.c_int), ("min_depth", C.c_double), ("max_depth", C.c_double),
+                ("ba_max_iter", C.c_int), ("ba_ftol", C.c_double), ("ba_xtol", C.c_double), ("refine_max_iter", C.c_int),
+                ("refine_ftol", C.c_double), ("refine_xtol", C.c_double)]
+
+
 # name -> (restype, argtypes); mirrors include/vohip.h one to one
 SIGNATURES = {
+    "vohip_window_default_params": (None, [C.POINTER(WindowParams)]),
+    "vohip_window_create": (C.c_int, [C.c_void_p, c_double_p, C.POINTER(WindowParams), C.POINTER(C.c_void_p)]),
+    "vohip_window_destroy": (C.c_int, [C.c_void_p]),
+    "vohip_window_reset": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, c_double_p]),
+    "vohip_window_step": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p, c_int_p, c_int_p,
+                                     c_int_p, c_double_p, C.c_int]),
+    "vohip_window_state": (C.c_int, [C.c_void_p, c_int_p, c_int_p, c_double_p, c_double_p]),
+    "vohip_frame_bundle_adjust": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, c_int_p, c_int_p, c_int_p, c_double_p,
+                                             C.c_int]),
     "vohip_klt_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
     "vohip_frame_default_params": (None, [C.POINTER(FrameParams)]),
     "vohip_frame_create": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams),

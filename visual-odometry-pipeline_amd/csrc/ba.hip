@@ -31,6 +31,8 @@
 #include "se3_device.h"
 #include "wave_reduce.h"
 
+#include <chrono>
+#include <cstdlib>
 #include <vector>
 
 using namespace vohip_dev;
@@ -956,6 +958,8 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, state && obs && K, "NULL argument");
     VOHIP_REQUIRE(ctx, max_iter >= 0, "negative max_iter");
+    static const bool trace = std::getenv("VOHIP_WINDOW_TRACE") != nullptr;
+    const auto t_in = std::chrono::steady_clock::now();
     host_obs o;
     VOHIP_TRY(parse_observations(ctx, obs, obs_len, state_len, o));
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0.0;
@@ -997,7 +1001,10 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
     ba_status hs;
     std::memset(&hs, 0, sizeof(hs));
     const int max_trials = max_iter + 12 * (max_iter + 1);
+    const auto t_loop = std::chrono::steady_clock::now();
+    int trials_enqueued = 0;
     for (int trial = 0; trial < max_trials; ++trial) {
+        ++trials_enqueued;
         hipLaunchKernelGGL(ba_linearize_kernel, dim3(nb_lin), dim3(256), lds_lin, s, P, (const double *)d_state,
                            (const double *)d_trial, (const ba_status *)d_st, (double *)d_Sp, (double *)d_gp, (double *)d_E,
                            (double *)d_gl, (double *)d_W, (int *)d_fail);
@@ -1026,8 +1033,17 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
         std::memcpy(&hs, h_st, sizeof(hs));
         if (hs.done) break;
     }
+    const auto t_done = std::chrono::steady_clock::now();
     VOHIP_TRY(vohip_download(ctx, state, hs.cur ? d_trial : d_state, sizeof(double) * nx));
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    if (trace) {
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::micro>(b - a).count();
+        };
+        std::fprintf(stderr, "vohip runBA trace (us): parse + upload %.0f  LM loop %.0f (%d trials enqueued, %d run, %d accepted)  download %.0f\n",
+                     us(t_in, t_loop), us(t_loop, t_done), trials_enqueued, hs.trials, hs.iter,
+                     us(t_done, std::chrono::steady_clock::now()));
+    }
     if (stats) {
         stats[0] = hs.iter;
         stats[1] = hs.cost0;

@@ -715,6 +715,7 @@ struct vohip_frame {
     bool trace = false;
     void *block = nullptr;       // one device allocation, carved up below
     void *pinned = nullptr;      // host mirror of the counters and doubles
+    double *ba_stage = nullptr;  // pinned host copies of S.P, S.X(1:3,:), S.X(4,:) for the bundle adjustment (6 x capL doubles)
     uint8_t *img[2] = {nullptr, nullptr};   // image staging (host images), by frame parity
     double *L_rc, *L_X, *L_id, *C_rc, *F_rc, *T12;
     double *mv_rc, *Xv, *idv, *kp_uv;
@@ -1283,6 +1284,7 @@ int vohip_frame_destroy(vohip_frame *f)
     if (f->ev_img) (void)hipEventDestroy(f->ev_img);
     if (f->block) (void)hipFree(f->block);
     if (f->pinned) (void)hipHostFree(f->pinned);
+    if (f->ba_stage) (void)hipHostFree(f->ba_stage);
     delete f;
     return VOHIP_OK;
 }
@@ -1532,6 +1534,37 @@ int vohip_frame_apply_ba(vohip_frame *f, const double *X, int n, const double T_
     VOHIP_HIP(ctx, hipGetLastError());
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
     return VOHIP_OK;
+}
+
+int vohip_frame_bundle_adjust(vohip_frame *f, vohip_window *w, const double T_W_C[16], int *optimised, int *n_poses,
+                              int *offsets, double *poses, int cap)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, w && T_W_C && optimised && n_poses, "NULL argument");
+    VOHIP_REQUIRE(ctx, vohip_window_context(w) == ctx, "the window belongs to another context");
+    VOHIP_REQUIRE(ctx, f->stage == 0, "the state is complete only between frames");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    if (!f->ba_stage) VOHIP_HIP(ctx, hipHostMalloc((void **)&f->ba_stage, sizeof(double) * 6 * (size_t)f->capL, hipHostMallocDefault));
+    // The second stream is idle between frames; the context's own may already hold the following frame's
+    // trackers, which touch neither the landmarks nor the solvers' buffers, so the window is optimised
+    // beside them.
+    hipStream_t s = f->side;
+    stream_swap sw(ctx, s);
+    const size_t n = f->n_L;
+    double *P = f->ba_stage, *X = P + 2 * (size_t)f->capL, *ids = X + 3 * (size_t)f->capL;
+    if (n) {
+        VOHIP_HIP(ctx, hipMemcpyAsync(P, f->L_rc, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
+        VOHIP_HIP(ctx, hipMemcpyAsync(X, f->L_X, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
+        VOHIP_HIP(ctx, hipMemcpyAsync(ids, f->L_id, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    }
+    VOHIP_TRY(vohip_window_step(w, P, X, ids, (int)n, T_W_C, optimised, n_poses, offsets, poses, cap));
+    if (!*optimised) return VOHIP_OK;
+    // VO_bundle_adjust.m:53-57: the pose of the current keyframe is the entry with offset 0
+    for (int k = 0; k < *n_poses; ++k)
+        if (offsets[k] == 0) return vohip_frame_apply_ba(f, X, (int)n, poses + 16 * (size_t)k);
+    return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "the optimised window holds no pose for the current frame");
 }
 
 }  // extern "C"

@@ -153,6 +153,8 @@ int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv
                               const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
                               double *d_stats);
 
+vohip_ctx *vohip_window_context(vohip_window *w);
+
 // Camera matrix passed to kernels by value (column-major, as MATLAB stores it).
 struct vohip_K {
     double k[9];

@@ -3,9 +3,10 @@ the GPU: a thin driver over the vohip_frame_* entry points of libvohip.so.  Same
 methods as pipeline.VOPipeline; the state S is downloaded only when asked for.
 
 With hyper_paras.is_BA the window bookkeeping of VO_bundle_adjust.m stays on the host, as in the
-reference: after each frame S.P and S.X come down in one copy, pipeline.VO_bundle_adjust runs (runBA
-and the normal-frame re-refinements on the GPU), and when a window was optimised the landmarks and
-the keyframe's pose go back up in one copy (vohip_frame_apply_ba).
+reference, inside the library (vohip_frame_bundle_adjust: S.P and S.X come down in one round trip, the
+window struct B lives in a vohip_window, runBA and the normal-frame re-refinements run on the GPU, and
+when a window was optimised the landmarks and the keyframe's pose go back up); this driver only applies
+the poses the call hands back to its trajectory.
 
 Per frame the host does one library call (one synchronisation) and draws the random numbers the two
 RANSAC stages consume, from the same two generators as VOPipeline: `rng` gives 3 uniforms per P3P
@@ -20,7 +21,7 @@ import numpy as np
 from . import _lib
 from ._lib import VOHIP_NO_MODEL, VOHIP_SAMPLES_EXHAUSTED, colmajor, dptr
 from .keypoints import DEFAULT_MIN_QUALITY, DETECTORS
-from .pipeline import VO_bundle_adjust, default_hyper_paras, init_state
+from .pipeline import default_hyper_paras
 from .ransac import MAX_ITERATIONS
 
 
@@ -89,10 +90,20 @@ class VOPipelineDevice:
         self.num_X, self.num_C, self.num_new = [X.shape[0]], [0], [0]
         self.frames = 0
         self.first_hypotheses = 104   # supplied with the frame; the adaptive bound asks for more when it needs them
-        self.B = None
+        self._window = None
         self.ba_runs = 0
-        if self.hp.is_BA:   # main_demo.m:288-303: the window struct (its S is only a container here)
-            _, self.B = init_state(p_W_landmarks, keypoints_xy, T_init_WC, window_size, keyframe_d, ctx=self.ctx)
+        if self.hp.is_BA:   # main_demo.m:288-303: the window struct B, kept by the library
+            wp = _lib.WindowParams()
+            lib.vohip_window_default_params(C.byref(wp))
+            wp.window_size, wp.keyframe_d = int(window_size), int(keyframe_d)
+            wp.min_depth, wp.max_depth = float(self.hp.min_depth), float(self.hp.max_depth)
+            wh = C.c_void_p()
+            self.ctx.check(lib.vohip_window_create(self.ctx.handle, dptr(colmajor(self.K)), C.byref(wp), C.byref(wh)))
+            self._window = wh
+            self.ctx.check(lib.vohip_window_reset(wh, dptr(X), dptr(P_rc), X.shape[0], dptr(colmajor(T))))
+            self._ba_cap = wp.window_size * (wp.keyframe_d + 1)
+            self._ba_offsets = (C.c_int * self._ba_cap)()
+            self._ba_poses = np.zeros((self._ba_cap, 16))
         self.last_pose = None
         self.last_counts = None
 
@@ -187,40 +198,35 @@ class VOPipelineDevice:
             self._bundle_adjust(T_W_C)
         return T_W_C
 
-    def _landmarks(self):
-        """S.P (2xn, (row; col)) and S.X (4xn) from the GPU."""
-        lib = _lib.load()
-        n = self.num_X[-1]
-        P, X, ids = np.zeros((max(n, 1), 2)), np.zeros((max(n, 1), 3)), np.zeros(max(n, 1))
-        self.ctx.check(lib.vohip_frame_state(self._h, dptr(P), dptr(X), dptr(ids), None, None, None))
-        return P[:n].T.copy(), np.vstack([X[:n].T, ids[:n]])
-
     def _bundle_adjust(self, T_W_C):
-        """VO_bundle_adjust.m:1-98 on the host copy of the landmarks; what it changes goes back to the GPU."""
-        B = self.B
-        S = SimpleNamespace()
-        S.P, S.X = self._landmarks()
-        S.est_trans, S.est_rot = self.trajectory()
-        new = S.X[3] >= B.new_idx                     # update_landmarks.m:83-95: B.landmarks grows with S.X
-        k = int(new.sum())
-        if k:
-            B.landmarks = np.hstack([B.landmarks, S.X[:, new]])
-            B.new_idx += k
-        B.m = B.landmarks.shape[1]
-        X_before = S.X[:3].copy()
-        optimise = B.count_frame == B.keyframe_d and B.num_key >= B.window_size   # VO_bundle_adjust.m:3,17
-        S, self.B = VO_bundle_adjust(S, B, T_W_C, self.K, self.hp, ctx=self.ctx)
-        if not optimise:
+        """VO_bundle_adjust.m:1-98 for the frame just finished; the poses it rewrites (:53-57, :80-84) come back
+        as (column offset from the end of the trajectory, T_W_C) pairs."""
+        opt, npose = C.c_int(0), C.c_int(0)
+        self.ctx.check(_lib.load().vohip_frame_bundle_adjust(self._h, self._window, dptr(colmajor(T_W_C)), C.byref(opt),
+                                                             C.byref(npose), self._ba_offsets, dptr(self._ba_poses),
+                                                             self._ba_cap))
+        if not opt.value:
             return
         self.ba_runs += 1
-        self.est_trans = [c.copy() for c in S.est_trans.T]
-        self.est_rot = [c.copy() for c in S.est_rot.T]
-        T_new = np.eye(4)                             # :53-57, the current keyframe's optimised pose
-        T_new[:3, :3] = S.est_rot[:, -1].reshape(3, 3, order="F")
-        T_new[:3, 3] = S.est_trans[:, -1]
-        if not np.array_equal(S.X[:3], X_before) or not np.array_equal(T_new, T_W_C):
-            Xc = np.ascontiguousarray(S.X[:3].T)
-            self.ctx.check(_lib.load().vohip_frame_apply_ba(self._h, dptr(Xc), Xc.shape[0], dptr(colmajor(T_new))))
+        last = len(self.est_trans) - 1
+        for k in range(npose.value):
+            T = self._ba_poses[k].reshape(4, 4).T
+            col = last + self._ba_offsets[k]
+            self.est_trans[col] = T[:3, 3].copy()
+            self.est_rot[col] = T[:3, :3].reshape(-1, order="F").copy()
+
+    @property
+    def B(self):
+        """The window struct of main_demo.m:288-303 as the library holds it: num_key, m, tau (6 x num_key),
+        landmarks (4 x m)."""
+        if self._window is None:
+            return None
+        lib = _lib.load()
+        nk, m = C.c_int(0), C.c_int(0)
+        self.ctx.check(lib.vohip_window_state(self._window, C.byref(nk), C.byref(m), None, None))
+        tau, lm = np.zeros((max(nk.value, 1), 6)), np.zeros((max(m.value, 1), 4))
+        self.ctx.check(lib.vohip_window_state(self._window, None, None, dptr(tau), dptr(lm)))
+        return SimpleNamespace(num_key=nk.value, m=m.value, tau=tau[:nk.value].T.copy(), landmarks=lm[:m.value].T.copy())
 
     def trajectory(self):
         """est_trans (3 x T) and est_rot (9 x T), as saved by main_demo.m:473-476."""
@@ -242,6 +248,9 @@ class VOPipelineDevice:
                                num_new=list(self.num_new))
 
     def close(self):
+        if getattr(self, "_window", None) is not None:
+            _lib.load().vohip_window_destroy(self._window)
+            self._window = None
         if getattr(self, "_h", None) is not None:
             _lib.load().vohip_frame_destroy(self._h)
             self._h = None
