@@ -25,6 +25,7 @@
 // supplied, vohip_frame_retry re-runs the context-stream part from the hypotheses onwards.
 #include "vohip_internal.h"
 #include "inlier_test.h"
+#include "ordered_select.h"
 #include "sampson_test.h"
 
 #include <chrono>
@@ -72,46 +73,13 @@ enum {
     N_DOUBLES = 64
 };
 
-__device__ __forceinline__ int wave_sum_i(int v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
-}
+using vohip_dev::wave_sum_i;              // ordered_select.h
+using vohip_dev::triple_from_uniforms;
 
-// Ordered selection inside a grid of 256-thread workgroups: returns the number of flagged
-// elements before element i = blockIdx.x * 256 + threadIdx.x and, in `total`, the number of
-// flagged elements in [0, n).  Every workgroup re-evaluates the flags before its range (at most a few
-// KB, from L2), so there is no inter-workgroup hand-off and the result is deterministic.
-// All 256 threads must call it.  `sh` needs 12 ints.
 template <class Pred>
 __device__ int ordered_rank_if(int n, Pred pred, int &total, int *sh)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int first = blockIdx.x * 256;
-    int before = 0, all = 0;
-    for (int j = tid; j < n; j += 256) {
-        const int f = pred(j) ? 1 : 0;
-        all += f;
-        before += j < first ? f : 0;
-    }
-    before = wave_sum_i(before);
-    all = wave_sum_i(all);
-    const int i = first + tid;
-    const bool mine = i < n && pred(i);
-    const unsigned long long b = __ballot(mine);
-    const int in_wave = __popcll(b & ((1ull << lane) - 1ull));
-    __syncthreads();
-    if (lane == 0) {
-        sh[wave] = before;
-        sh[4 + wave] = all;
-        sh[8 + wave] = __popcll(b);
-    }
-    __syncthreads();
-    int r = sh[0] + sh[1] + sh[2] + sh[3] + in_wave;
-    for (int w = 0; w < wave; ++w) r += sh[8 + w];
-    total = sh[4] + sh[5] + sh[6] + sh[7];
-    return r;
+    return vohip_dev::ordered_rank_if(n, pred, total, sh, blockIdx.x);
 }
 
 template <class Pred>
@@ -129,21 +97,6 @@ struct is_one {
 struct is_zero {
     __device__ bool operator()(uint8_t f) const { return f == 0; }
 };
-
-// uniform draws -> 3 distinct indices in [0, n)
-__device__ __forceinline__ void triple_from_uniforms(const double *r, int n, int32_t *s)
-{
-    int a = min((int)(r[0] * (double)n), n - 1);
-    int b = min((int)(r[1] * (double)(n - 1)), n - 2);
-    int c = min((int)(r[2] * (double)(n - 2)), n - 3);
-    b += b >= a;
-    const int lo = min(a, b), hi = max(a, b);
-    c += c >= lo;
-    c += c >= hi;
-    s[0] = a;
-    s[1] = b;
-    s[2] = c;
-}
 
 // main_demo.m:380-381 + the S.X(:, validity) of :387: tracked landmarks that are still valid.
 __global__ __launch_bounds__(256) void select_tracked_kernel(const double *__restrict__ out_xy, int ld,
@@ -867,7 +820,7 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
     const int T = p.fm_trials;
-    (void)u8;   // already on its way up (the caller's stream order)
+    (void)u8;   // in the pinned block already
     stream_swap sw(ctx, f->side);
     hipStream_t s = f->side;
     // (redundant when the candidate tracker ran on this very stream)
@@ -876,7 +829,7 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
     if (f->have_map) {
         hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->U_xy[f->par] + f->capL,
                            f->capU, f->U_live[f->par] + f->capL, f->C_rc, f->F_rc, f->T12, f->n_C, f->p1_rc, f->m_rc, f->F_t,
-                           f->T_t, f->capL, f->row_t, f->cnt, f->u8, T, f->samples8);
+                           f->T_t, f->capL, f->row_t, f->cnt, pin_u8(f), T, f->samples8);
         VOHIP_TRY(vohip_fm_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->samples8, T, p.fm_threshold,
                                    f->dv + D_NRM, f->fm_F, f->fm_counts));
         hipLaunchKernelGGL(fm_decide_kernel, dim3(1), dim3(FM_DECIDE), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
@@ -918,7 +871,7 @@ int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t 
 // again with more hypotheses when the adaptive bound asks for them.
 // `ready` hypotheses at the front of the range already have their draws on the device and their
 // triples made (by the selection kernel).
-int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready)
+int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready, bool with_selection = false)
 {
     vohip_ctx *ctx = f->ctx;
     hipStream_t s = ctx->stream;
@@ -930,8 +883,12 @@ int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready)
     if (more > ready)
         hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more - ready)), dim3(256), 0, s, pin_u3(f), first + ready,
                            more - ready, f->cnt, f->samples3);
+    // with_selection: the selection of the valid tracks has not been launched; it rides with the solve kernel
+    const vohip_select_tracked sel = {f->U_xy[f->par], f->capU, f->U_live[f->par], f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv,
+                                      f->idv, f->rowv, f->cnt + N_V, f->dv + D_IDX, f->dv + D_IDX_NEXT, pin_u3(f), ready,
+                                      f->samples3};
     VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
-                                   f->counts4, f->Rt_all, f->M_all));
+                                   f->counts4, f->Rt_all, f->M_all, with_selection ? &sel : nullptr));
     f->evaluated = h;
     hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->counts4, h,
                        (const double *)f->Rt_all, (const double *)f->M_all, f->mv_rc,
@@ -1413,14 +1370,10 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     // The order of the enqueues follows the critical paths: what feeds the trackers first, then the
     // context's stream (localisation), the short kernels of the other streams while those run.
     if (f->trace) (void)hipEventRecord(f->tr[0], s);
-    // the P3P draws stay in the pinned block (the kernels read them there); the trial draws go up on
-    // the second stream
+    // the draws of both RANSAC stages stay in the pinned block: the kernels that turn them into index sets
+    // read them there (a few KB each; a copy command would cost the host more than the reads cost the GPU)
     std::memcpy(pin_u3(f), u3, sizeof(double) * 3 * (size_t)h);
-    if (f->have_map) {   // (the second stream's kernels follow this copy in stream order)
-        const size_t T8 = 8 * (size_t)p.fm_trials;
-        std::memcpy(pin_u8(f), u8, sizeof(double) * T8);
-        VOHIP_HIP(ctx, hipMemcpyAsync(f->u8, pin_u8(f), sizeof(double) * T8, hipMemcpyHostToDevice, f->side));
-    }
+    if (f->have_map) std::memcpy(pin_u8(f), u8, sizeof(double) * 8 * (size_t)p.fm_trials);
     const uint8_t *d_img = image_on_device ? image : f->img[par];
     const uint8_t *d_next = next_image ? (next_on_device ? next_image : f->img[par ^ 1]) : nullptr;
     if (!f->ahead) {
@@ -1433,12 +1386,17 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     }   // (else the previous call enqueued all of that, the trackers behind its own last kernel)
     if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, f->ev_pyr, nullptr));
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
+    static const bool fused_off = std::getenv("VOHIP_FRAME_UNFUSED") != nullptr;   // (A/B measurements)
     if (f->ahead) VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_advA[par], 0));   // the kept landmarks' own tracker
-    // the selection of the valid landmark tracks (main_demo.m:381, :387)
-    hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->U_xy[par], f->capU, f->U_live[par],
-                       f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->rowv, f->cnt, f->dv, pin_u3(f), h0, f->samples3);
-    VOHIP_HIP(ctx, hipGetLastError());
-    VOHIP_TRY(enqueue_localize(f, u3, h, h0));
+    // the selection of the valid landmark tracks (main_demo.m:381, :387): in the launch that solves the
+    // hypotheses when all of them have their triples made there (the usual 104), else a launch of its own
+    const bool fused = h <= h0 && f->n_L <= 8192 && !fused_off;
+    if (!fused) {
+        hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->U_xy[par], f->capU, f->U_live[par],
+                           f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->rowv, f->cnt, f->dv, pin_u3(f), h0, f->samples3);
+        VOHIP_HIP(ctx, hipGetLastError());
+    }
+    VOHIP_TRY(enqueue_localize(f, u3, h, h0, fused));
     if (f->trace) (void)hipEventRecord(f->tr[2], s);   // pose refined
     VOHIP_TRY(enqueue_side_filter(f, u8));
     if (next_image) {

@@ -55,6 +55,7 @@
 //   SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
 #include "vohip_internal.h"
 #include "inlier_test.h"
+#include "ordered_select.h"
 
 #include <cmath>
 #include <mutex>
@@ -416,6 +417,148 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double *__restrict_
     }
 }
 
+// p3p_solve_kernel for a frame's first hypotheses, in ONE launch with the ordered selection of the valid
+// landmark tracks they sample from (main_demo.m:380-381, :387): the solve workgroups (the first nb_solve)
+// do not wait for the compacted lists -- they count the valid flags themselves, turn the caller's
+// uniform draws into ranks among the valid tracks exactly as the selection does, find the table rows of
+// those ranks (per 16 flags a bit mask and a count in LDS, prefix over the counts, binary search) and read
+// the sampled points from the track table: the same numbers the compacted lists hold, so the poses are
+// the ones p3p_solve_kernel computes from the lists, bit for bit.  The other workgroups are the
+// selection (what the scoring kernel behind this launch reads).  S.n <= 16 * SEL_GROUPS.
+constexpr int SEL_GROUPS = 512;
+
+__device__ __forceinline__ unsigned nonzero_bytes_to_bits(unsigned w)
+{
+    w |= w >> 4;
+    w |= w >> 2;
+    w |= w >> 1;
+    w &= 0x01010101u;                     // one bit per non-zero byte
+    return (w * 0x01020408u) >> 24;       // ... gathered into the low 4 bits, byte 0 first
+}
+
+__global__ __launch_bounds__(256) void p3p_solve_select_kernel(vohip_select_tracked S, vohip_K K, int h, int nb_solve,
+                                                               double *__restrict__ Rt_out,
+                                                               double *__restrict__ M_out,
+                                                               int32_t *__restrict__ zero_counts)
+{
+    __shared__ int sh[12];
+    __shared__ int sPref[SEL_GROUPS];
+    __shared__ unsigned short sMask[SEL_GROUPS];
+    __shared__ int sTotal;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= nb_solve) {
+        // the selection itself
+        const int block = blockIdx.x - nb_solve;
+        if (block == 0 && tid == 0) *S.idx = *S.idx_next;   // the ids handed out in the previous frame are final now
+        int total;
+        const uint8_t *__restrict__ valid = S.valid;
+        const int r = vohip_dev::ordered_rank_if(S.n, [=](int j) { return valid[j] != 0; }, total, sh, block);
+        const int i = block * 256 + tid;
+        if (i < S.n && valid[i]) {
+            S.mv_rc[2 * r] = S.out_xy[S.ld + i];   // row = y
+            S.mv_rc[2 * r + 1] = S.out_xy[i];      // col = x
+            S.Xv[3 * r] = S.L_X[3 * i];
+            S.Xv[3 * r + 1] = S.L_X[3 * i + 1];
+            S.Xv[3 * r + 2] = S.L_X[3 * i + 2];
+            S.idv[r] = S.L_id[i];
+            S.rowv[r] = i;   // landmark i is row i of the track table
+        }
+        if (block == 0) {
+            if (tid == 0) *S.n_valid = total;
+            for (int k = tid; k < S.h0; k += 256)
+                vohip_dev::triple_from_uniforms(S.u3 + 3 * (size_t)k, total, S.samples + 3 * (size_t)k);
+        }
+        return;
+    }
+    // --- the solve workgroups: where are the valid tracks? ---
+    const int groups = (S.n + 15) >> 4;
+    for (int g = tid; g < groups; g += 256) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(S.valid + 16 * (size_t)g);   // (the flag array is 256-byte aligned and padded)
+        unsigned m = nonzero_bytes_to_bits(w.x) | (nonzero_bytes_to_bits(w.y) << 4) | (nonzero_bytes_to_bits(w.z) << 8) |
+                     (nonzero_bytes_to_bits(w.w) << 12);
+        const int left = S.n - 16 * g;
+        if (left < 16) m &= (1u << left) - 1u;
+        sMask[g] = (unsigned short)m;
+    }
+    __syncthreads();
+    if (tid < 64) {   // exclusive prefix over the groups' counts: 8 consecutive groups per lane
+        int c[8], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int g = 8 * tid + q;
+            c[q] = g < groups ? __popc((unsigned)sMask[g]) : 0;
+            sum += c[q];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += t;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sPref[8 * tid + q] = run;
+            run += c[q];
+        }
+        if (tid == 63) sTotal = incl;
+    }
+    __syncthreads();
+    const int total = sTotal;
+    const int t = blockIdx.x * 256 + tid;
+    const int hyp = t >> 2, sol = t & 3;
+    const bool live = hyp < h;
+    int row = -1;
+    if (live && sol < 3) {
+        int32_t tri[3];
+        vohip_dev::triple_from_uniforms(S.u3 + 3 * (size_t)hyp, total, tri);
+        const int target = sol == 0 ? tri[0] : sol == 1 ? tri[1] : tri[2];
+        if (target >= 0 && target < total) {
+            // the last group whose prefix does not exceed the rank (groups without a valid track share their
+            // successor's prefix and are skipped that way)
+            int lo = 0, hi = groups - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (sPref[mid] <= target) lo = mid;
+                else hi = mid - 1;
+            }
+            unsigned m = sMask[lo];
+            for (int k = target - sPref[lo]; k > 0; --k) m &= m - 1;   // (at most 15 steps)
+            row = 16 * lo + (__ffs((int)m) - 1);
+        }
+    }
+    // lanes 4k, 4k + 1, 4k + 2 hold the three rows of hypothesis k
+    const int q0 = (tid & 63) & ~3;
+    const int id3[3] = {__shfl(row, q0, 64), __shfl(row, q0 + 1, 64), __shfl(row, q0 + 2, 64)};
+    if (!live) return;
+    if (zero_counts) zero_counts[t] = 0;   // (for a scoring kernel that adds partial counts)
+    v3 W[3], bearing[3];
+    bool ok = true;
+    for (int c = 0; c < 3; ++c) {
+        int id = id3[c];
+        if (id < 0) {
+            ok = false;
+            id = 0;
+        }
+        W[c] = {S.L_X[3 * id], S.L_X[3 * id + 1], S.L_X[3 * id + 2]};
+        bearing[c] = unit_bearing(K, S.out_xy[id], S.out_xy[S.ld + id]);
+    }
+    double pose[12];
+    for (int j = 0; j < 12; ++j) pose[j] = 0.0;
+    p3p_shared q;
+    if (p3p_prepare(W[0], W[1], W[2], bearing[0], bearing[1], bearing[2], q)) {
+        const double x = sol == 0 ? q.xr[0] : sol == 1 ? q.xr[1] : sol == 2 ? q.xr[2] : q.xr[3];
+        p3p_solution(q, x, pose);
+    }
+    const double nan = __builtin_nan("");
+    double Rt[12], M[12];
+    decode_pose(K, pose, Rt, M);
+    for (int j = 0; j < 12; ++j) {
+        Rt_out[(size_t)hyp * 48 + 12 * sol + j] = ok ? Rt[j] : nan;
+        M_out[(size_t)hyp * 48 + 12 * sol + j] = ok ? M[j] : nan;
+    }
+}
+
 // Stand-alone p3p.m for `count` problems, reference output layout (3x16 column-major).
 __global__ __launch_bounds__(64) void p3p_batch_kernel(const double *__restrict__ world,
                                                        const double *__restrict__ bearings, int count,
@@ -756,7 +899,7 @@ int launch_count(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n
 // Solve + score hypotheses [first, first + h) for points whose count may live on the device.
 int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                          const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts,
-                         double *d_Rt_all, double *d_M_all)
+                         double *d_Rt_all, double *d_M_all, const vohip_select_tracked *select)
 {
     // the candidate poses go to the caller's arrays (48 doubles per hypothesis each, hypothesis 0 first)
     VOHIP_REQUIRE(ctx, d_Rt_all && d_M_all, "NULL pose buffers");
@@ -766,9 +909,18 @@ int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
     // few hypotheses: several wavefronts share each (their partial counts are added to counts the solve
     // kernel cleared); many: one wavefront per hypothesis over LDS-staged tiles
     const bool split_points = h < 512 && ctx->opt_ransac_variant < 0;
-    hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n, d_n, Kv,
-                       d_samples + 3 * (size_t)first, h, d_Rt, d_M,
-                       split_points ? d_counts + 4 * (size_t)first : (int32_t *)nullptr);
+    if (select) {
+        // the frame's first hypotheses and the selection of the tracks they sample from, as one launch
+        VOHIP_REQUIRE(ctx, first == 0 && h <= select->h0 && select->n <= 16 * SEL_GROUPS && select->n >= 0,
+                      "the selection cannot ride with these hypotheses");
+        const int nb_solve = (4 * h + 255) / 256, nb_select = select->n < 1 ? 1 : (select->n + 255) / 256;
+        hipLaunchKernelGGL(p3p_solve_select_kernel, dim3(nb_solve + nb_select), dim3(256), 0, ctx->stream, *select, Kv, h,
+                           nb_solve, d_Rt, d_M, split_points ? d_counts : (int32_t *)nullptr);
+    } else {
+        hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n, d_n, Kv,
+                           d_samples + 3 * (size_t)first, h, d_Rt, d_M,
+                           split_points ? d_counts + 4 * (size_t)first : (int32_t *)nullptr);
+    }
     if (split_points) {
         const int split = 1024 / h < 1 ? 1 : (1024 / h > 16 ? 16 : 1024 / h);
         hipLaunchKernelGGL(p3p_score_split_kernel, dim3((h * split + 3) / 4), dim3(256), 0, ctx->stream, d_kp_rc, d_X, n,

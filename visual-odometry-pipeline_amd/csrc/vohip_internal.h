@@ -127,9 +127,31 @@ struct vohip_klt_set {
 // it carries).
 int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vohip_klt_set *sets, int nsets,
                            int block_size, int max_iter, double max_bidir_error);
+// The ordered selection of the valid landmark tracks (main_demo.m:380-381, :387) as it rides in the launch
+// that solves a frame's first hypotheses: track i of the table (x column then y column, leading dimension
+// ld) with valid[i] != 0 goes, in order, to mv_rc (row, col), Xv, idv and rowv; *n_valid receives their
+// number, *idx = *idx_next, and the first h0 sample triples are made from the uniform draws u3.
+// `valid` must be 16-byte aligned and readable up to the next multiple of 16 past n.
+struct vohip_select_tracked {
+    const double *out_xy;
+    int ld;
+    const uint8_t *valid;
+    const double *L_X, *L_id;
+    int n;
+    double *mv_rc, *Xv, *idv;
+    int32_t *rowv;
+    int *n_valid;
+    double *idx;
+    const double *idx_next;
+    const double *u3;
+    int h0;
+    int32_t *samples;
+};
+// `select` (may be NULL): see vohip_select_tracked; then first must be 0, h <= select->h0 and d_kp_rc, d_X, d_n
+// name the lists the selection writes.
 int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                          const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts,
-                         double *d_Rt_all, double *d_M_all);
+                         double *d_Rt_all, double *d_M_all, const vohip_select_tracked *select);
 int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                               const double *d_M12, uint8_t *d_mask);
 double vohip_ransac_adaptive_iterations(int max_num_inliers, int n);

@@ -36,6 +36,8 @@ class VOPipelineDevice:
             raise NotImplementedError("detector '%s' is not built" % self.hp.feature_extract)
         self.rng = rng or np.random.default_rng()
         self.rng_map = rng_map or self.rng.spawn(1)[0]
+        # PCG64 steps backwards by a modular advance (one step per double drawn)
+        self._rewind = type(self.rng.bit_generator).__name__ in ("PCG64", "PCG64DXSM")
         lib = _lib.load()
         prm = _lib.FrameParams()
         lib.vohip_frame_default_params(C.byref(prm))
@@ -147,7 +149,8 @@ class VOPipelineDevice:
         if have_map:                                                                        # update_landmarks.m:13
             u8 = self._u8_ahead if self._u8_ahead is not None else self.rng_map.random((self.params.fm_trials, 8))
         self._u8_ahead = None
-        state = self.rng.bit_generator.state
+        # (a generator that can step backwards is rewound after the frame; any other is saved and restored)
+        state = None if self._rewind else self.rng.bit_generator.state
         have = int(self.first_hypotheses)
         u3 = self.rng.random((have, 3))                                                     # :387-388
         self.ctx.check(lib.vohip_frame_begin(self._h, ptr, on_dev, nptr, non_dev, dptr(u3), have,
@@ -167,15 +170,25 @@ class VOPipelineDevice:
         self._pending = None
         pose, counts = _lib.FramePose(), _lib.FrameCounts()
         st = lib.vohip_frame_finish(self._h, C.byref(pose), C.byref(counts))
+        drawn = have
         while st == VOHIP_SAMPLES_EXHAUSTED and have < MAX_ITERATIONS:
             have = min(max(8 * have, int(np.ceil(pose.num_iterations)) + 8), MAX_ITERATIONS)
-            self.rng.bit_generator.state = state
+            if state is None:
+                self.rng.bit_generator.advance(-3 * drawn)
+            else:
+                self.rng.bit_generator.state = state
             u3 = self.rng.random((have, 3))         # the same leading draws, then more
+            drawn = have
             st = lib.vohip_frame_retry(self._h, dptr(u3), have, C.byref(pose), C.byref(counts))
         self._keep_images = (keep, nkeep)   # a host image handed over ahead is read until the next call returns
-        self.rng.bit_generator.state = state
-        if pose.n_iter > 0:
-            self.rng.random((pose.n_iter, 3))       # the generator as n_iter executed iterations leave it
+        # the generator as n_iter executed iterations leave it (ransacLocalization.m:46-47 draws one triple each)
+        if state is None:
+            if drawn != pose.n_iter:
+                self.rng.bit_generator.advance(-3 * (drawn - max(pose.n_iter, 0)))
+        else:
+            self.rng.bit_generator.state = state
+            if pose.n_iter > 0:
+                self.rng.random((pose.n_iter, 3))
         if st != 0:
             self.rng_map.bit_generator.state = state_map
         if st == VOHIP_NO_MODEL:

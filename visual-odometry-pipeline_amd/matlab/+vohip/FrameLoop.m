@@ -7,6 +7,7 @@ classdef FrameLoop < handle
     %   for i = ...
     %       [T_W_C, info] = loop.step(images{i}, images{i + 1}); % the following image is optional
     %       S.est_trans(:, end + 1) = T_W_C(1:3, 4);  ...        % main_demo.m:401-403
+    %       if hyper_paras.is_BA, S = loop.bundle_adjust(S, T_W_C); end   % main_BA.m:288-291
     %   end
     %   S = loop.state(S);                                       % S.P, S.X, S.C, S.F, S.T back on the host
     %
@@ -20,6 +21,7 @@ classdef FrameLoop < handle
         MapStream            % RandStream of the fundamental-matrix trials
         Trials = 500         % update_landmarks.m:13-14
         HaveCandidates = false
+        K                    % camera matrix
     end
     methods
         function obj = FrameLoop(K, image_size, hyper_paras, feature_params)
@@ -41,11 +43,28 @@ classdef FrameLoop < handle
             end
             if isfield(hyper_paras, 'is_BA'), p.is_BA = double(hyper_paras.is_BA); end
             vohip_mex('frame_create', K, image_size(1), image_size(2), p);
+            obj.K = double(K);
             obj.MapStream = RandStream('mt19937ar', 'Seed', 'shuffle');
         end
-        function reset(obj, image, X, P, T_W_C)
+        function reset(obj, image, X, P, T_W_C, window_size, keyframe_d, hyper_paras)
             vohip_mex('frame_reset', image, double(X), double(P), double(T_W_C));
             obj.HaveCandidates = false;
+            if nargin > 5    % with bundle adjustment: the window struct B of main_demo.m:288-303, kept by the library
+                w = struct('window_size', window_size, 'keyframe_d', keyframe_d, ...
+                           'min_depth', hyper_paras.min_depth, 'max_depth', hyper_paras.max_depth);
+                vohip_mex('window_create', obj.K, w);
+                vohip_mex('window_reset', double(X), double(P), double(T_W_C));
+            end
+        end
+        function S = bundle_adjust(~, S, T_W_C)
+            % VO_bundle_adjust.m:1-98 on the device-resident state; rewrites the poses of the optimised
+            % window in S.est_rot / S.est_trans (:53-57, :80-84), whose last column is this frame's
+            [~, offsets, poses] = vohip_mex('frame_bundle_adjust', double(T_W_C));
+            for k = 1:numel(offsets)
+                T = reshape(poses(:, k), 4, 4);
+                S.est_rot(:, end + offsets(k)) = reshape(T(1:3, 1:3), 9, 1);
+                S.est_trans(:, end + offsets(k)) = T(1:3, 4);
+            end
         end
         function [T_W_C, info] = step(obj, image, next_image)
             if nargin < 3, next_image = []; end
@@ -69,6 +88,7 @@ classdef FrameLoop < handle
             [S.P, S.X, S.C, S.F, S.T] = vohip_mex('frame_state');
         end
         function delete(~)
+            vohip_mex('window_destroy');
             vohip_mex('frame_destroy');
         end
     end

@@ -23,9 +23,12 @@
 
 static vohip_ctx *g_ctx = nullptr;
 static vohip_frame *g_frame = nullptr;   // the device-resident loop state ('frame_*' opcodes)
+static vohip_window *g_window = nullptr; // the bundle-adjustment window ('window_*' opcodes)
 
 static void at_exit()
 {
+    if (g_window) vohip_window_destroy(g_window);
+    g_window = nullptr;
     if (g_frame) vohip_frame_destroy(g_frame);
     g_frame = nullptr;
     if (g_ctx) vohip_destroy(g_ctx);
@@ -361,6 +364,72 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         // vohip_mex('frame_apply_ba', X 3xn, T_W_C 4x4): VO_bundle_adjust.m:53-70 put back into the device state
         if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
         check(vohip_frame_apply_ba(g_frame, dbl(in[0], "X"), cols(in[0]), dbl(in[1], "T_W_C")));
+    } else if (is("window_create")) {
+        // vohip_mex('window_create', K, params struct): the struct B of main_demo.m:288-303 kept by the library.
+        // params fields (all optional): window_size, keyframe_d, min_depth, max_depth.
+        if (g_window) { vohip_window_destroy(g_window); g_window = nullptr; }
+        vohip_window_params p;
+        vohip_window_default_params(&p);
+        if (nrhs > 2 && mxIsStruct(in[1])) {
+            auto field = [&](const char *name, double dflt) {
+                const mxArray *f = mxGetField(in[1], 0, name);
+                return f ? mxGetScalar(f) : dflt;
+            };
+            p.window_size = (int)field("window_size", p.window_size);
+            p.keyframe_d = (int)field("keyframe_d", p.keyframe_d);
+            p.min_depth = field("min_depth", p.min_depth);
+            p.max_depth = field("max_depth", p.max_depth);
+        }
+        check(vohip_window_create(c, dbl(in[0], "K"), &p, &g_window));
+    } else if (is("window_reset")) {
+        // vohip_mex('window_reset', X 3xn, P_rc 2xn, T_W_C 4x4)   (main_demo.m:288-303)
+        if (!g_window) mexErrMsgIdAndTxt("vohip:usage", "window_create first");
+        check(vohip_window_reset(g_window, dbl(in[0], "X"), dbl(in[1], "P"), cols(in[0]), dbl(in[2], "T_W_C")));
+    } else if (is("window_step") || is("frame_bundle_adjust")) {
+        // [X 3xn, optimised, offsets 1xk, poses 16xk, num_key] = vohip_mex('window_step', S.P 2xn, S.X 4xn, T_W_C 4x4)
+        // [optimised, offsets 1xk, poses 16xk, num_key] = vohip_mex('frame_bundle_adjust', T_W_C 4x4)
+        // VO_bundle_adjust.m:1-98; offsets count columns of S.est_trans / S.est_rot back from the last one,
+        // poses holds the 4x4 T_W_C (column-major) that belongs in each of them.
+        if (!g_window) mexErrMsgIdAndTxt("vohip:usage", "window_create first");
+        const int cap = 64;   // window_size <= 8: at most 8 + 7 keyframe_d poses
+        int *offsets = scratch<int>(cap);
+        double *poses = scratch<double>((size_t)16 * cap);
+        int optimised = 0, n_poses = 0, out = 0;
+        if (is("window_step")) {
+            const int n = cols(in[1]);
+            const double *SX = dbl(in[1], "S.X");
+            if (rows(in[1]) != 4 || cols(in[0]) != n) mexErrMsgIdAndTxt("vohip:usage", "S.P 2xn and S.X 4xn are needed");
+            double *ids = scratch<double>((size_t)n);
+            plhs[0] = mxCreateDoubleMatrix(3, n, mxREAL);
+            double *X = mxGetDoubles(plhs[0]);
+            for (int k = 0; k < n; ++k) {
+                std::memcpy(X + 3 * (size_t)k, SX + 4 * (size_t)k, sizeof(double) * 3);
+                ids[k] = SX[4 * (size_t)k + 3];
+            }
+            check(vohip_window_step(g_window, dbl(in[0], "S.P"), X, ids, n, dbl(in[2], "T_W_C"), &optimised, &n_poses,
+                                    offsets, poses, cap));
+            out = 1;
+        } else {
+            if (!g_frame) mexErrMsgIdAndTxt("vohip:usage", "frame_create first");
+            check(vohip_frame_bundle_adjust(g_frame, g_window, dbl(in[0], "T_W_C"), &optimised, &n_poses, offsets, poses, cap));
+        }
+        if (nlhs > out) plhs[out] = mxCreateDoubleScalar(optimised);
+        if (nlhs > out + 1) {
+            plhs[out + 1] = mxCreateDoubleMatrix(1, n_poses, mxREAL);
+            for (int k = 0; k < n_poses; ++k) mxGetDoubles(plhs[out + 1])[k] = offsets[k];
+        }
+        if (nlhs > out + 2) {
+            plhs[out + 2] = mxCreateDoubleMatrix(16, n_poses, mxREAL);
+            std::memcpy(mxGetDoubles(plhs[out + 2]), poses, sizeof(double) * 16 * (size_t)n_poses);
+        }
+        if (nlhs > out + 3) {
+            int num_key = 0;
+            check(vohip_window_state(g_window, &num_key, nullptr, nullptr, nullptr));
+            plhs[out + 3] = mxCreateDoubleScalar(num_key);
+        }
+    } else if (is("window_destroy")) {
+        if (g_window) vohip_window_destroy(g_window);
+        g_window = nullptr;
     } else if (is("frame_destroy")) {
         if (g_frame) vohip_frame_destroy(g_frame);
         g_frame = nullptr;
