@@ -609,9 +609,11 @@ __global__ __launch_bounds__(256) void ba_update_kernel(ba_problem P, double *__
 }
 
 // One thread.  An accepted step is not copied anywhere: the two state buffers change roles.
+// `mirror`: the host's pinned copy of the status (the host follows the run by polling it instead of
+// synchronising: the count of decided trials is stored last, with system scope).
 __global__ __launch_bounds__(64) void ba_decide_kernel(int nblocks, const double *__restrict__ partial,
                                                        ba_status *__restrict__ st, int *__restrict__ fail_flag,
-                                                       int max_iter, double ftol, double xtol)
+                                                       int max_iter, double ftol, double xtol, ba_status *mirror)
 {
     if (threadIdx.x != 0 || st->done) return;
     int accept = 0;
@@ -650,6 +652,14 @@ __global__ __launch_bounds__(64) void ba_decide_kernel(int nblocks, const double
         if (accept) st->cur ^= 1;
         st->done = finished ? 1 : 0;
         *fail_flag = 0;
+        if (mirror) {
+            ba_status c = *st;
+            const int decided = c.trials;
+            c.trials = decided - 1;   // (what the host saw last)
+            *mirror = c;
+            __threadfence_system();
+            __hip_atomic_store(&mirror->trials, decided, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1003,7 +1013,23 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
     const int max_trials = max_iter + 12 * (max_iter + 1);
     const auto t_loop = std::chrono::steady_clock::now();
     int trials_enqueued = 0;
+    // The host follows the run in its pinned copy of the status, which every decision updates: it stays
+    // at most two trials ahead of the GPU's decisions (the kernels of a trial return at once when the run
+    // has ended, so at most two idle trials are enqueued) and never synchronises inside the loop.
+    std::memset(h_st, 0, sizeof(ba_status));
+    volatile ba_status *hm = (volatile ba_status *)h_st;
+    bool timed_out = false;
     for (int trial = 0; trial < max_trials; ++trial) {
+        if (trial >= 2) {
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(10);
+            while (__atomic_load_n(&((ba_status *)h_st)->trials, __ATOMIC_ACQUIRE) < trial - 1 && !hm->done) {
+                if (std::chrono::steady_clock::now() > deadline) {
+                    timed_out = true;
+                    break;
+                }
+            }
+            if (timed_out || hm->done) break;
+        }
         ++trials_enqueued;
         hipLaunchKernelGGL(ba_linearize_kernel, dim3(nb_lin), dim3(256), lds_lin, s, P, (const double *)d_state,
                            (const double *)d_trial, (const ba_status *)d_st, (double *)d_Sp, (double *)d_gp, (double *)d_E,
@@ -1022,17 +1048,12 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
                            (const double *)d_dp, (const double *)d_E, (const double *)d_gl, (const double *)d_W,
                            (const ba_status *)d_st, (double *)d_part);
         hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, s, nb_upd, (const double *)d_part, (ba_status *)d_st,
-                           (int *)d_fail, max_iter, ftol, xtol);
+                           (int *)d_fail, max_iter, ftol, xtol, (ba_status *)h_st);
         VOHIP_HIP(ctx, hipGetLastError());
-        // The status comes back after every third trial only: the kernels of a trial return at once
-        // when the run has ended, so at most two idle trials are enqueued, and two of three
-        // synchronisations are saved.
-        if (trial % 3 != 2 && trial + 1 < max_trials) continue;
-        VOHIP_HIP(ctx, hipMemcpyAsync(h_st, d_st, sizeof(ba_status), hipMemcpyDeviceToHost, s));
-        VOHIP_HIP(ctx, hipStreamSynchronize(s));
-        std::memcpy(&hs, h_st, sizeof(hs));
-        if (hs.done) break;
     }
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    if (timed_out) return vohip_fail(ctx, VOHIP_ERR_HIP, "the bundle adjustment did not report a decision within 10 s");
+    std::memcpy(&hs, h_st, sizeof(hs));
     const auto t_done = std::chrono::steady_clock::now();
     VOHIP_TRY(vohip_download(ctx, state, hs.cur ? d_trial : d_state, sizeof(double) * nx));
     VOHIP_HIP(ctx, hipStreamSynchronize(s));

@@ -541,7 +541,11 @@ __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__r
                                                                 int capC, int det_base, double *__restrict__ C_rc,
                                                                 double *__restrict__ F_rc, double *__restrict__ T12,
                                                                 int32_t *__restrict__ srcC, double *__restrict__ mirror_dv,
-                                                                int *__restrict__ mirror_cnt)
+                                                                int *__restrict__ mirror_cnt,
+                                                                const double *__restrict__ L_rc,
+                                                                const double *__restrict__ L_X,
+                                                                const double *__restrict__ L_id, int capL,
+                                                                double *__restrict__ mirror_L)
 {
     __shared__ int sh[12];
     const int n = cnt[FILT0];
@@ -578,6 +582,20 @@ __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__r
         __syncthreads();
         if (threadIdx.x < N_DOUBLES) mirror_dv[threadIdx.x] = dv[threadIdx.x];
         if (threadIdx.x < N_COUNTERS) mirror_cnt[threadIdx.x] = cnt[threadIdx.x];
+    }
+    // With bundle adjustment the host reads S.P and S.X after every frame (VO_bundle_adjust.m:14,29,92):
+    // they go to its pinned copy from here as well ([S.P | S.X(1:3,:) | S.X(4,:)], capL columns each).
+    if (mirror_L) {
+        const int nL = min(cnt[N_L_END], capL);
+        double *mP = mirror_L, *mX = mirror_L + 2 * (size_t)capL, *mI = mX + 3 * (size_t)capL;
+        for (int k = blockIdx.x * 256 + threadIdx.x; k < nL; k += gridDim.x * 256) {
+            mP[2 * k] = L_rc[2 * k];
+            mP[2 * k + 1] = L_rc[2 * k + 1];
+            mX[3 * k] = L_X[3 * k];
+            mX[3 * k + 1] = L_X[3 * k + 1];
+            mX[3 * k + 2] = L_X[3 * k + 2];
+            mI[k] = L_id[k];
+        }
     }
 }
 
@@ -669,6 +687,7 @@ struct vohip_frame {
     void *block = nullptr;       // one device allocation, carved up below
     void *pinned = nullptr;      // host mirror of the counters and doubles
     double *ba_stage = nullptr;  // pinned host copies of S.P, S.X(1:3,:), S.X(4,:) for the bundle adjustment (6 x capL doubles)
+    bool ba_mirrored = false;    // ... written by the last kernel of the frame just finished (is_BA)
     uint8_t *img[2] = {nullptr, nullptr};   // image staging (host images), by frame parity
     double *L_rc, *L_X, *L_id, *C_rc, *F_rc, *T12;
     double *mv_rc, *Xv, *idv, *kp_uv;
@@ -925,7 +944,9 @@ int enqueue_tail(vohip_frame *f)
                                              f->cnt + FILT0, p.r_discard_redundant, f->keep));
     hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s, f->corner_xy[f->par], f->capK,
                        f->keep, f->cnt, f->dv, f->capC, f->capL + f->capC, f->C_rc, f->F_rc, f->T12, f->srcC, pin_dv(f),
-                       pin_cnt(f));
+                       pin_cnt(f), (const double *)f->L_rc, (const double *)f->L_X, (const double *)f->L_id, f->capL,
+                       f->ba_stage);
+    f->ba_mirrored = f->ba_stage != nullptr;
     VOHIP_HIP(ctx, hipGetLastError());
     if (f->trace) (void)hipEventRecord(f->tr[6], s);   // tail done (before the event the host waits for: it is read right after)
     VOHIP_HIP(ctx, hipEventRecord(f->ev_tail, s));     // what the frame's single synchronisation waits for
@@ -1168,6 +1189,8 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     if (e == hipSuccess)
         e = hipHostMalloc(&f->pinned, PIN_U3 + sizeof(double) * (3 * (size_t)f->hmax + 8 * (size_t)p.fm_trials),
                           hipHostMallocDefault);
+    if (e == hipSuccess && p.is_BA)   // the host's copy of S.P and S.X, written by every frame's last kernel
+        e = hipHostMalloc((void **)&f->ba_stage, sizeof(double) * 6 * (size_t)f->capL, hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det[1], hipEventDisableTiming);
@@ -1256,6 +1279,7 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     VOHIP_REQUIRE(ctx, n >= 1 && n <= f->capL, "landmark count outside the capacity");
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    f->ba_mirrored = false;
     VOHIP_HIP(ctx, hipStreamSynchronize(f->side));
     VOHIP_HIP(ctx, hipStreamSynchronize(f->side2));
     VOHIP_HIP(ctx, hipStreamSynchronize(f->trk));
@@ -1511,7 +1535,7 @@ int vohip_frame_bundle_adjust(vohip_frame *f, vohip_window *w, const double T_W_
     stream_swap sw(ctx, s);
     const size_t n = f->n_L;
     double *P = f->ba_stage, *X = P + 2 * (size_t)f->capL, *ids = X + 3 * (size_t)f->capL;
-    if (n) {
+    if (n && !f->ba_mirrored) {
         VOHIP_HIP(ctx, hipMemcpyAsync(P, f->L_rc, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, s));
         VOHIP_HIP(ctx, hipMemcpyAsync(X, f->L_X, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
         VOHIP_HIP(ctx, hipMemcpyAsync(ids, f->L_id, sizeof(double) * n, hipMemcpyDeviceToHost, s));
