@@ -194,9 +194,9 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
  * and S.T (main_demo.m:272-279) stay in GPU memory between frames; the stages are the kernels behind
  * the entry points above, chained through device-side counts, so the state after each frame is the
  * one the stage-by-stage calls produce (genKeypoints.m, ransacLocalization.m, T_refinement.m,
- * update_landmarks.m, update_candidate.m).  With is_BA the caller keeps VO_bundle_adjust.m's window
- * bookkeeping and calls runBA itself between frames (vohip_frame_state, vohip_ba_run,
- * vohip_frame_apply_ba).
+ * update_landmarks.m, update_candidate.m).  With is_BA the caller runs VO_bundle_adjust.m between
+ * frames: vohip_frame_bundle_adjust (the window kept by the library), or its own bookkeeping over
+ * vohip_frame_state, vohip_ba_run and vohip_frame_apply_ba.
  *
  * Random numbers: the caller passes uniform draws in [0, 1) instead of index sets, because the
  * sizes they index are only known on the device: 3 per P3P hypothesis (mapped to 3 distinct

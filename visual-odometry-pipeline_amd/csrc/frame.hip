@@ -1,20 +1,20 @@
 // The continuous-operation loop body with the state resident on the GPU (gfx950).
 //
-// Restates main_demo.m:377-427 (VO_bundle_adjust's window bookkeeping at :409-411 stays with the caller,
-// see vohip_frame_apply_ba) -- detection (genKeypoints.m), the landmark
+// Restates main_demo.m:377-427 (VO_bundle_adjust at :409-411 is a call of its own between frames,
+// vohip_frame_bundle_adjust) -- detection (genKeypoints.m), the landmark
 // tracker, ransacLocalization.m, T_refinement.m, update_landmarks.m, update_candidate.m and the
 // tracker re-initialisation -- as ONE call and ONE synchronisation per frame (vohip_frame_step,
 // vohip_frame_step_ahead):
 //   context stream  [image -> pyramid -> landmark AND candidate tracking (one launch, from the rows of
 //                   the previous frame's track table into this frame's), unless the previous call
 //                   enqueued them ahead] -> ordered selection (+ sample triples from the caller's
-//                   uniform draws) -> P3P solve -> scoring -> the adaptive stopping rule replayed by
+//                   uniform draws) and P3P solve (one launch) -> scoring -> the adaptive stopping rule replayed by
 //                   one wavefront -> inlier selection -> pose refinement -> [join] -> triangulation of
 //                   the filtered candidates -> landmark append -> redundancy filter -> candidate
 //                   append (+ the frame's summary into the caller's pinned mirror; the call waits on
 //                   an event recorded here) -> [step_ahead] the FOLLOWING frame's trackers, with their
 //                   counts read from device memory
-//   second stream   the trial draws go up; (after the trackers) ordered selection of the tracked
+//   second stream   (after the trackers) ordered selection of the tracked
 //                   candidates -> fundamental-matrix RANSAC -> inlier selection
 //   third stream    corner detection; the detections become rows of the track table
 //   fourth stream   (step_ahead) the following image and its pyramid
