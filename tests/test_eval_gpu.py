@@ -94,9 +94,14 @@ def test_main_eval_grid_is_independent_of_world_size(vo, ctx, tmp_path):
         assert a["frames"] == 10 and a["frame_ct"] == 9 and a["frame_init"] == 3
         assert a["fps_ct"] > 0 and a["toc_ct"] > 0 and a["errs"].shape[0] == 3 and a["errs"].shape[1] >= 1
         assert (a["sequence"], a["feat"]) == ("corridor%d" % (k // 2), feats[k % 2])
+    # ... and of how many runs a process keeps in flight on its GPU (a thread and a context per run)
+    together = vo.main_eval(sequences, feats=feats, repetition=1, save_dir=str(tmp_path / "w3"), seed=9, ctx=ctx, concurrent=3)
+    for k in range(4):
+        for key in ("est_trans", "est_rot", "num_X", "num_C", "num_new", "errs"):
+            np.testing.assert_array_equal(whole[k][key], together[k][key], err_msg="concurrent %d %s" % (k, key))
     # the two feature variants are different runs
     assert not np.array_equal(whole[0]["num_C"], whole[1]["num_C"])
-    for d in ("w1", "w2"):
+    for d in ("w1", "w2", "w3"):
         files = sorted(glob.glob(str(tmp_path / d / "*_res.mat")))
         assert len(files) == 4
         back = vo.load_results(files[0])

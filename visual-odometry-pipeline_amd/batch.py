@@ -90,18 +90,31 @@ def gather_records(local_records, n_items, device=None):
     return out
 
 
-def run_batch(items, runner, device=None, rank=None, world=None):
+def run_items(mine, runner, concurrent=1):
+    """[runner(item_id, item) for item_id, item in mine], up to `concurrent` of them at a time (one host
+    thread each).  A single run leaves most of a GPU idle -- every stage of a frame is bound by latency --
+    so independent runs overlap on it; the runner must give every thread a context of its own."""
+    if concurrent <= 1 or len(mine) <= 1:
+        return [runner(item_id, item) for item_id, item in mine]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=int(concurrent)) as pool:
+        return list(pool.map(lambda p: runner(p[0], p[1]), mine))   # (in the order of `mine`)
+
+
+def run_batch(items, runner, device=None, rank=None, world=None, concurrent=1):
     """Runs `runner(item_id, item) -> record` for this rank's share of `items` and gathers all
     records on every rank.  `runner` builds and drives one full pipeline run.
     rank / world given explicitly (without a process group): only that share is run and returned, the
-    other entries of the result are None -- one GPU can then rehearse every rank's share in turn."""
+    other entries of the result are None -- one GPU can then rehearse every rank's share in turn.
+    concurrent: runs a rank has in flight at once (see run_items)."""
     import torch.distributed as dist
     if rank is not None:
         out = [None] * len(items)
-        for item_id, item in shard(list(enumerate(items)), rank, world):
-            out[item_id] = unpack_record(runner(item_id, item))
+        mine = shard(list(enumerate(items)), rank, world)
+        for (item_id, _), rec in zip(mine, run_items(mine, runner, concurrent)):
+            out[item_id] = unpack_record(rec)
         return out
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
     mine = shard(list(enumerate(items)), rank, world)
-    local = [runner(item_id, item) for item_id, item in mine]
+    local = run_items(mine, runner, concurrent)
     return gather_records(local, len(items), device=device)

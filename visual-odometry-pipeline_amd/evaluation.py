@@ -189,7 +189,7 @@ EVAL_FEATURE_OPTIONS = {"Harris": ["MinQuality", 2e-4],      # main_eval.m:168-1
 
 
 def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0, device=None, rank=None, world=None,
-              ctx=None, now=None):
+              ctx=None, now=None, concurrent=1):
     """The batch evaluation of main_eval.m: for every sequence, every feature variant (main_eval.m:19,22,
     165-174) and every repetition (:20,23) one full, independent run (run_sequence: bootstrap, loop,
     timing, quantitative_eval, '<experiment>_res.mat' as :483-494 saves it).
@@ -205,14 +205,29 @@ def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0,
     (main_eval.m:20-23); here run k draws from numpy.random.default_rng([seed, k]), so a run's result
     does not depend on how many processes share the grid.  The reference names a result file after the
     wall-clock second it is saved in; runs here take milliseconds, so run k is stamped `now` + k seconds
-    to keep the names unique and parseable by the evaluation notebook."""
+    to keep the names unique and parseable by the evaluation notebook.
+
+    concurrent: runs a process keeps in flight on its GPU at once, one host thread and one context (own
+    stream, own scratch) each; a single run leaves most of the GPU idle, so the grid finishes sooner, and a
+    run's result does not depend on it."""
     import copy
     import datetime
     from . import batch
     from .pipeline import default_hyper_paras
+    import threading
     ctx = ctx or _lib.default_context()
     now = now or datetime.datetime.now()
     items = [(si, feat, rep) for si in range(len(sequences)) for feat in feats for rep in range(repetition)]
+    per_thread = threading.local()   # concurrent runs: a context per worker thread (a context serves one thread at a time)
+    extra = []
+
+    def context():
+        if concurrent <= 1:
+            return ctx
+        if not hasattr(per_thread, "ctx"):
+            per_thread.ctx = _lib.Context(ctx.device)
+            extra.append(per_thread.ctx)
+        return per_thread.ctx
 
     def runner(item_id, item):
         si, feat, rep = item
@@ -223,14 +238,18 @@ def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0,
         t0 = time.perf_counter()
         out = run_sequence(seq["images"], seq["K"], hp, ground_truth=seq.get("ground_truth"),
                            bootstrap_frames=seq.get("bootstrap_frames", (0, 2)), dataset=seq["name"], save_dir=save_dir,
-                           rng=np.random.default_rng([seed, item_id]), ctx=ctx,
+                           rng=np.random.default_rng([seed, item_id]), ctx=context(),
                            window_size=seq.get("window_size", 3), keyframe_d=seq.get("keyframe_d", 2),
                            now=now + datetime.timedelta(seconds=item_id))
         S = out["S"]
         return batch.pack_record(item_id, time.perf_counter() - t0, S.est_trans, S.est_rot, S.num_X, S.num_C,
                                  S.num_new, errs=out["errs"], timing=out)
 
-    records = batch.run_batch(items, runner, device=device, rank=rank, world=world)
+    try:
+        records = batch.run_batch(items, runner, device=device, rank=rank, world=world, concurrent=concurrent)
+    finally:
+        for c in extra:
+            c.close()
     for (si, feat, rep), r in zip(items, records):
         if r is not None:
             r.update(sequence=sequences[si]["name"], feat=feat, repetition=rep)
