@@ -862,26 +862,26 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
     return VOHIP_OK;
 }
 
-// Third stream: corner detection (main_demo.m:377) needs only the image; the detections also become
-// rows of the track table.  `par`: parity of the frame the image belongs to; `ready`: event after
-// which the image is on the device; `table_free`: event after which the rows may be written (the
-// trackers of the current frame still read the table of that parity), or NULL.
-int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t ready, hipEvent_t table_free)
+// Corner detection (main_demo.m:377) needs only the image; the detections also become rows of the track
+// table.  It shares the second stream with the epipolar filter, and the stream's order does the
+// synchronising that events would otherwise do: enqueued before the frame's filter (plain call) or after it
+// (the following image's, look-ahead), it follows the filter's wait for the trackers that still read the
+// table of that parity, and the event the tail waits for -- recorded behind the NEXT filter on this stream --
+// covers it.  `par`: parity of the frame the image belongs to; `ready`: event after which the image is on
+// the device, or NULL.
+int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t ready)
 {
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
-    if (ready) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, ready, 0));   // (NULL: the image was on the device all along)
-    VOHIP_TRY(vohip_detect_corners_enqueue(ctx, f->side2, f->corner_scratch, &f->det_calls, d_img, f->rows, f->cols,
+    hipStream_t s = f->side;
+    if (ready) VOHIP_HIP(ctx, hipStreamWaitEvent(s, ready, 0));   // (NULL: the image was on the device all along)
+    VOHIP_TRY(vohip_detect_corners_enqueue(ctx, s, f->corner_scratch, &f->det_calls, d_img, f->rows, f->cols,
                                            f->colmajor, p.min_quality, p.filter_size, p.border, p.detector,
                                            p.min_contrast, f->corner_xy[par], f->corner_metric[par], f->capK, f->cnt + N_DET + par));
-    if (table_free) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, table_free, 0));
-    // (the candidate tracker, when it last ran as a launch of its own; complete long ago otherwise)
-    if (table_free && f->split_used[par ^ 1]) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side2, f->ev_advC[par ^ 1], 0));
-    hipLaunchKernelGGL(detection_rows_kernel, dim3(blocks256(f->capK)), dim3(256), 0, f->side2, f->corner_xy[par], f->capK,
+    hipLaunchKernelGGL(detection_rows_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s, f->corner_xy[par], f->capK,
                        f->cnt + N_DET + par, f->capL + f->capC, f->capU, f->U_xy[par], f->U_live[par]);
     VOHIP_HIP(ctx, hipGetLastError());
-    VOHIP_HIP(ctx, hipEventRecord(f->ev_det[par], f->side2));
-    if (f->trace) (void)hipEventRecord(f->tr_det[par], f->side2);   // detection done
+    if (f->trace) (void)hipEventRecord(f->tr_det[par], s);   // detection done
     return VOHIP_OK;
 }
 
@@ -927,8 +927,7 @@ int enqueue_tail(vohip_frame *f)
     vohip_ctx *ctx = f->ctx;
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
-    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_side, 0));
-    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_det[f->par], 0));
+    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_side, 0));   // (the epipolar filter, and this image's corners before it on that stream)
     const int *n_det = f->cnt + N_DET + f->par;
     if (f->have_map) {
         VOHIP_TRY(vohip_candidate_triangulate_enqueue(ctx, f->m2_rc, f->F2, f->T2, f->n_C, f->cnt + N_CI, f->dv + D_T,
@@ -1408,7 +1407,7 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
         VOHIP_HIP(ctx, hipEventRecord(f->ev_feed, s));
         VOHIP_TRY(enqueue_trackers(f, par, f->slot_prev, f->slot_cur, f->n_L, f->have_map ? f->n_C : 0, false, f->ev_feed));
     }   // (else the previous call enqueued all of that, the trackers behind its own last kernel)
-    if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, f->ev_pyr, nullptr));
+    if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, image_on_device ? nullptr : f->ev_pyr));
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
     static const bool fused_off = std::getenv("VOHIP_FRAME_UNFUSED") != nullptr;   // (A/B measurements)
     if (f->ahead) VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_advA[par], 0));   // the kept landmarks' own tracker
@@ -1438,7 +1437,7 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     VOHIP_TRY(enqueue_tail(f));
     if (next_image) VOHIP_TRY(enqueue_trackers_ahead(f));
     // (last: nothing waits for the following image's corners before the next call's final kernels)
-    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, next_on_device ? nullptr : f->ev_next, f->ev_adv[par]));
+    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, next_on_device ? nullptr : f->ev_next));
     f->h_cur = h;
     f->stage = 2;
     f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
