@@ -336,7 +336,9 @@ int vohip_window_reset(vohip_window *w, const double *X, const double *P_rc, int
  * keyframe of a full window, *optimised = 1 and the poses VO_bundle_adjust.m:53-57,80-84 rewrites come
  * back as *n_poses pairs: offsets[k] <= 0 is the column of S.est_trans / S.est_rot counted from the
  * last one (0 = this frame), poses + 16 k its 4x4 column-major T_W_C; cap >= window_size +
- * (window_size - 1) keyframe_d entries. */
+ * (window_size - 1) keyframe_d entries.  A call that fails (ids that do not ascend, a landmark missing
+ * from the window, a solver error) may leave the window half-way through the step: start it again with
+ * vohip_window_reset. */
 int vohip_window_step(vohip_window *w, const double *P_rc, double *X, const double *ids, int n, const double T_W_C[16],
                       int *optimised, int *n_poses, int *offsets, double *poses, int cap);
 /* Copies of B.num_key, B.m = size(B.landmarks, 2), B.tau (6 x num_key) and B.landmarks (4 x m, [X; id]);

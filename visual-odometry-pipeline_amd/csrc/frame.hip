@@ -16,8 +16,9 @@
 //                   counts read from device memory
 //   second stream   (after the trackers) ordered selection of the tracked
 //                   candidates -> fundamental-matrix RANSAC -> inlier selection
-//   third stream    corner detection; the detections become rows of the track table
-//   fourth stream   (step_ahead) the following image and its pyramid
+//                   -> corner detection (of the following image with step_ahead; the detections become
+//                   rows of the track table)
+//   third stream    (step_ahead) the following image, its pyramid and the kept landmarks' tracker
 // S.P, S.X, S.C, S.F, S.T never leave the device; every count between the stages stays in device
 // memory (kernels are launched over capacity-sized grids and read the count themselves), and
 // selections are ordered, so the state is element for element the one the stage-by-stage entry
