@@ -176,6 +176,22 @@ def bench_frames_concurrent(vo, torch, scene, frames, poses, steps, warmup, n_se
     return n_seq * steps / max(seconds)
 
 
+def bench_main_eval(vo, ctx, frames, poses, concurrent):
+    """The batch evaluation of main_eval.m:20-23 on one GPU: a grid of 2 feature variants x 4 repetitions = 8 full
+    runs (bootstrap on the first three frames, continuous operation on the rest, quantitative_eval, result record)
+    of one KITTI-shape sequence whose images live in host memory, `concurrent` runs in flight at a time.
+    Returns runs/s and the frames/s of the grid as a whole (continuous-operation frames / wall time)."""
+    seq = dict(name="kitti", images=frames, K=vo.synth.K_KITTI,
+               ground_truth=np.array([[T[0, 3], T[2, 3]] for T in poses[:len(frames)]]))
+    vo.main_eval([seq], feats=("Harris",), repetition=1, seed=10, ctx=ctx)   # code objects, staging buffers
+    t0 = time.perf_counter()
+    records = vo.main_eval([seq], feats=("Harris", "FAST"), repetition=4, seed=10, ctx=ctx, concurrent=concurrent)
+    dt = time.perf_counter() - t0
+    n_frames = sum(int(r["frame_ct"]) for r in records)
+    return {"runs": len(records), "runs_per_s": len(records) / dt, "frames_per_s": n_frames / dt,
+            "frames_per_run": n_frames // len(records), "mean_fps_ct_of_a_run": float(np.mean([r["fps_ct"] for r in records]))}
+
+
 def bench_parking(vo, torch, ctx, steps, warmup, bundle_adjust):
     """The reference's parking configuration (main_demo.m:100-112; with bundle_adjust main_BA.m:197-198: window of
     5 keyframes, every 2nd frame a keyframe) on a rendered 640 x 480 sequence seen through the parking calibration
@@ -534,6 +550,12 @@ def main():
                 "candidates": info_s["n_candidates"], "final_position_error_m": info_s["final_position_error_m"]}
             extra["frames_per_s_4_sequences_at_once"] = bench_frames_concurrent(vo, torch, scene, frames, poses, args.steps,
                                                                                 args.warmup, 4)
+            # BASELINE's batch configuration on one GPU (with N GPUs the grid is dealt round-robin to the ranks)
+            extra["main_eval_grid_one_gpu"] = {
+                "workload": "main_eval.m:20-23: 2 feature variants (Harris, FAST) x 4 repetitions of one KITTI-shape sequence, "
+                            "images in host memory, bootstrap + loop + evaluation per run",
+                "one_run_at_a_time": bench_main_eval(vo, ctx, frames, poses, 1),
+                "four_runs_in_flight": bench_main_eval(vo, ctx, frames, poses, 4)}
 
         klt_frame = klt_stress = image_kernels = ba_runs = None
         n, h = args.points, args.hypotheses
