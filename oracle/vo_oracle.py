@@ -339,7 +339,7 @@ def align_error(x, gt, est):
     return out
 
 
-def align_sim3(gt, est, max_iter=100, ftol=1e-10, xtol=1e-10):
+def align_sim3(gt, est, max_iter=400, ftol=1e-6, xtol=1e-6):   # lsqnonlin's defaults (alignEstimateToGroundTruth.m:17-18)
     """gt, est 3xn.  Returns (aligned 3xn, x (7,), stats dict)."""
     g = _f64(np.asarray(gt).T)
     e = _f64(np.asarray(est).T)

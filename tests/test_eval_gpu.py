@@ -19,12 +19,15 @@ def _trajectory(vo, n, seed, noise=0.02):
 @pytest.mark.parametrize("n,seed", [(4, 0), (40, 1), (255, 2), (540, 3), (3000, 4)])
 def test_alignment_matches_oracle(vo, ctx, oracle, n, seed):
     gt, est = _trajectory(vo, n, seed)
-    want, xw, sw = oracle.align_sim3(gt, est)
-    got, xg, sg = vo.alignEstimateToGroundTruth(gt, est, return_x=True, ctx=ctx)
-    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
-    np.testing.assert_allclose(xg, xw, rtol=0, atol=1e-6)
-    assert abs(sg["cost"] - sw["cost"]) < 1e-9 * (1 + sw["cost"])
-    assert sg["cost0"] == pytest.approx(sw["cost0"], rel=1e-12)
+    # at lsqnonlin's default tolerances (alignEstimateToGroundTruth.m:17-18, what both sides default to) and at 1e-10
+    for tol in ({}, dict(ftol=1e-10, xtol=1e-10)):
+        want, xw, sw = oracle.align_sim3(gt, est, **tol)
+        got, xg, sg = vo.alignEstimateToGroundTruth(gt, est, return_x=True, ctx=ctx, **tol)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(xg, xw, rtol=0, atol=1e-6)
+        assert abs(sg["cost"] - sw["cost"]) < 1e-9 * (1 + sw["cost"])
+        assert sg["cost0"] == pytest.approx(sw["cost0"], rel=1e-12)
+        assert sg["iterations"] == sw["iterations"]
     # alignError of the mirror agrees with the oracle's
     np.testing.assert_allclose(vo.alignError(xg, gt, est, ctx=ctx), oracle.align_error(xg, gt, est), atol=1e-12)
 

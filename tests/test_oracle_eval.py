@@ -31,7 +31,7 @@ def trajectory(vo, n, seed, noise=0.02):
 @pytest.mark.parametrize("n,seed", [(3, 0), (40, 1), (540, 2)])
 def test_alignment_reaches_the_closed_form_minimum(oracle, vo, n, seed):
     gt, est = trajectory(vo, n, seed)
-    aligned, x, st = oracle.align_sim3(gt, est)
+    aligned, x, st = oracle.align_sim3(gt, est, ftol=1e-10, xtol=1e-10)   # (tighter than the reference's 1e-6: the minimum itself)
     s, R, t = umeyama(gt, est)
     want = s * R @ est + t
     # three nearly collinear points leave the rotation about their line almost free
@@ -45,7 +45,7 @@ def test_alignment_reaches_the_closed_form_minimum(oracle, vo, n, seed):
 
 def test_alignment_matches_scipy_least_squares(oracle, vo):
     gt, est = trajectory(vo, 100, 5, noise=0.1)
-    _, x, st = oracle.align_sim3(gt, est)
+    _, x, st = oracle.align_sim3(gt, est, ftol=1e-10, xtol=1e-10)
     r = least_squares(lambda v: oracle.align_error(v, gt, est), np.array([0, 0, 0, 0, 0, 0, 1.0]), method="lm",
                       xtol=1e-14, ftol=1e-14)
     assert abs(2 * r.cost - st["cost"]) < 1e-8 * (1 + st["cost"])

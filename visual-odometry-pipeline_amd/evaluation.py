@@ -23,7 +23,9 @@ from . import _lib
 from ._lib import colmajor, dptr
 from .geometry import twist2HomogMatrix
 
-ALIGN_MAX_ITER = 100
+ALIGN_MAX_ITER = 400      # lsqnonlin's defaults, which alignEstimateToGroundTruth.m:17-18 leaves in place:
+ALIGN_FTOL = 1e-6         # MaxIterations 400, FunctionTolerance = StepTolerance = 1e-6
+ALIGN_XTOL = 1e-6
 DIST_CHECKPOINTS = np.array([10.0, 40.0, 90.0, 160.0, 250.0, 360.0]) * 0.2   # quantitative_eval.m:11-12
 
 
@@ -35,7 +37,8 @@ def alignError(x, pp_G_C, p_V_C, ctx=None):
     return (np.asarray(pp_G_C, dtype=np.float64) - p_G_C).reshape(-1, order="F")
 
 
-def alignEstimateToGroundTruth(pp_G_C, p_V_C, return_x=False, ctx=None):
+def alignEstimateToGroundTruth(pp_G_C, p_V_C, return_x=False, ctx=None, max_iter=ALIGN_MAX_ITER, ftol=ALIGN_FTOL,
+                               xtol=ALIGN_XTOL):
     """p_G_C = alignEstimateToGroundTruth(pp_G_C, p_V_C): the estimated trajectory p_V_C (3xN)
     under the similarity transform that best maps it onto the ground truth pp_G_C (3xN)."""
     ctx = ctx or _lib.default_context()
@@ -47,7 +50,7 @@ def alignEstimateToGroundTruth(pp_G_C, p_V_C, return_x=False, ctx=None):
     x = np.zeros(7)
     out = np.zeros((max(n, 1), 3))
     stats = np.zeros(3)
-    ctx.check(_lib.load().vohip_align_sim3(ctx.handle, dptr(g), dptr(e), n, ALIGN_MAX_ITER, 1e-10, 1e-10, dptr(x),
+    ctx.check(_lib.load().vohip_align_sim3(ctx.handle, dptr(g), dptr(e), n, int(max_iter), float(ftol), float(xtol), dptr(x),
                                            dptr(out), dptr(stats)))
     p_G_C = out[:n].T.copy()
     if return_x:

@@ -208,7 +208,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         const int n = cols(in[0]);
         plhs[0] = mxCreateDoubleMatrix(3, n, mxREAL);
         plhs[1] = mxCreateDoubleMatrix(7, 1, mxREAL);
-        check(vohip_align_sim3(c, dbl(in[0], "pp_G_C"), dbl(in[1], "p_V_C"), n, 100, 1e-10, 1e-10,
+        check(vohip_align_sim3(c, dbl(in[0], "pp_G_C"), dbl(in[1], "p_V_C"), n, 400, 1e-6, 1e-6,   // lsqnonlin defaults (alignEstimateToGroundTruth.m:17-18)
                                mxGetDoubles(plhs[1]), mxGetDoubles(plhs[0]), nullptr));
     } else if (is("relative_pose")) {
         // [orientation, location, validFraction] = vohip_mex('relative_pose', E, K, p1 (n x 2), p2 (n x 2))
