@@ -46,6 +46,33 @@ def test_uniform_to_index_maps(vo):
             assert list(row) == want
 
 
+@pytest.mark.parametrize("n_start,spoil", [(37, 0), (61, 17), (130, 48), (529, 200)])
+def test_device_loop_with_few_landmarks_and_lost_tracks(vo, ctx, oracle, sequence, n_start, spoil):
+    """The frame's first hypotheses are solved in the launch that also selects the valid tracks; the solve
+    workgroups find the rows of their samples from the valid flags themselves (16 flags per mask).  Sizes
+    that are no multiples of 16, fewer landmarks than a mask group holds lanes, and a run of `spoil`
+    landmarks whose keypoints are wrong by 12 px (lost by the tracker's forward-backward test or rejected as
+    outliers: holes in the flags): poses, counts and generator state as the stage-by-stage loop gives them."""
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    pick = np.sort(np.random.default_rng(n_start).permutation(len(xy))[:n_start])
+    X0, xy = X0[pick], xy[pick].copy()
+    xy[5:5 + spoil] += 12.0
+    hp = vo.default_hyper_paras("kitti")
+    ref = vo.VOPipeline(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(2), ctx=ctx)
+    dev = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(2), ctx=ctx)
+    for i in range(1, 5):
+        Tr = ref.process_frame(frames[i])
+        Td = dev.process_frame(frames[i], next_image=frames[i + 1])
+        assert dev.num_X[-1] == ref.S.num_X[-1] and dev.num_C[-1] == ref.S.num_C[-1], i
+        assert dev.last_pose.n_tracked <= (n_start if i == 1 else 10 ** 6)
+        np.testing.assert_allclose(Td, Tr, rtol=0, atol=1e-8)
+    assert dev.rng.bit_generator.state == ref.rng.bit_generator.state
+    np.testing.assert_array_equal(dev.S.X[3], ref.S.X[3])
+    ref.close()
+    dev.close()
+
+
 def test_device_loop_matches_stage_by_stage_loop(vo, ctx, oracle, sequence):
     scene, poses, frames = sequence
     X0, xy = _start(vo, oracle, sequence)
