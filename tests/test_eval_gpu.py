@@ -110,3 +110,27 @@ def test_main_eval_grid_is_independent_of_world_size(vo, ctx, tmp_path):
         back = vo.load_results(files[0])
         assert {"errs", "S", "total_time", "frame_init", "frame_ct", "toc_param", "toc_bootstrap", "toc_ct",
                 "fps_ct"} <= set(back)
+
+
+def test_main_eval_records_a_failed_run(vo, ctx, tmp_path):
+    """A run in which the scene disappears (blank frames: every track is lost) ends where the reference's script
+    stops with an error (main_demo.m:389-391).  on_error="raise" passes that on; on_error="record" marks the run
+    failed, goes on with the grid, and the failed run has given its device state and pyramid slots back."""
+    K = np.array([[400.0, 0, 320], [0, 400.0, 120], [0, 0, 1]])
+    scene = vo.synth.CorridorScene(seed=100, K=K, width=640, height=240)
+    poses = vo.synth.corridor_trajectory(10, step=0.5)
+    good = [scene.render(T) for T in poses]
+    bad = [f.copy() for f in good]
+    for f in bad[6:]:
+        f[:] = 128
+    gt = np.array([[T[0, 3], T[2, 3]] for T in poses])
+    sequences = [dict(name="blank", images=bad, K=K, ground_truth=gt, hyper_paras=vo.default_hyper_paras("kitti")),
+                 dict(name="corridor", images=good, K=K, ground_truth=gt, hyper_paras=vo.default_hyper_paras("kitti"))]
+    with pytest.raises((RuntimeError, vo.VohipError)):
+        vo.main_eval(sequences, feats=("Harris",), repetition=1, seed=9, ctx=ctx)
+    for _ in range(3):   # (more failed runs than the context has spare pyramid slots for, were they not released)
+        recs = vo.main_eval(sequences, feats=("Harris",), repetition=2, seed=9, ctx=ctx, on_error="record",
+                            save_dir=str(tmp_path / "runs"))
+        assert [r["failed"] for r in recs] == [True, True, False, False]
+        assert recs[0]["frames"] == 0 and recs[0]["est_trans"].shape == (3, 0) and recs[0]["sequence"] == "blank"
+        assert recs[2]["frames"] == 8 and recs[2]["fps_ct"] > 0 and recs[2]["errs"].shape[0] == 3

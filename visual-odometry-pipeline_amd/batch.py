@@ -11,7 +11,8 @@ import numpy as np
 
 T_MAX = 600           # frames a record can hold (the reference's longest run has 598)
 HEADER = 16           # [item id, frames, seconds, fps, errs columns, total_time, frame_init, frame_ct, toc_param,
-                      #  toc_bootstrap, toc_ct, fps_ct, 4 spare] -- the scalars main_eval.m:491-494 saves
+                      #  toc_bootstrap, toc_ct, fps_ct, failed, 3 spare] -- the scalars main_eval.m:491-494 saves; failed = 1
+                      #  marks a run that ended with an error (main_eval(on_error="record"))
 ERRS = 18             # errs 3 x 6 (quantitative_eval.m:27), column-major, unused columns NaN
 RECORD_DOUBLES = HEADER + ERRS + 15 * T_MAX   # ... + est_trans 3xT + est_rot 9xT + num_X, num_C, num_new
 
@@ -22,6 +23,15 @@ TIMING_KEYS = ("total_time", "frame_init", "frame_ct", "toc_param", "toc_bootstr
 def shard(items, rank, world):
     """Round-robin assignment of work items to ranks (static, so results do not depend on timing)."""
     return [it for k, it in enumerate(items) if k % world == rank]
+
+
+def failed_record(item_id, seconds):
+    """The record of a run that ended with an error (the reference's script would have stopped there,
+    main_demo.m:389-391): no trajectory, failed = 1."""
+    rec = pack_record(item_id, seconds, np.zeros((3, 0)), np.zeros((9, 0)), [], [], [])
+    rec[3] = 0.0
+    rec[12] = 1.0
+    return rec
 
 
 def pack_record(item_id, seconds, est_trans, est_rot, num_X, num_C, num_new, errs=None, timing=None):
@@ -58,6 +68,7 @@ def unpack_record(rec):
                num_new=body[14, :T].copy(), errs=rec[HEADER:HEADER + ERRS].reshape(6, 3)[:int(rec[4])].T.copy())
     for k, name in enumerate(TIMING_KEYS):
         out[name] = float(rec[5 + k])
+    out["failed"] = bool(rec[12])
     return out
 
 

@@ -159,16 +159,19 @@ def run_sequence(images, K, hyper_paras, ground_truth=None, bootstrap_frames=(0,
     if device_loop:
         pipe = VOPipelineDevice(K, img_seqs[-1], p_W_landmarks, keypoints, T_init_WC, hyper_paras=hyper_paras,
                                 window_size=window_size, keyframe_d=keyframe_d, rng=rng, ctx=ctx)
-        for i in frame_range:
-            pipe.process_frame(images[i], next_image=images[i + 1] if i + 1 < len(images) else None)
     else:
         pipe = VOPipeline(K, img_seqs[-1], p_W_landmarks, keypoints, T_init_WC, hyper_paras=hyper_paras,
                           window_size=window_size, keyframe_d=keyframe_d, rng=rng, ctx=ctx)
+    try:   # (a run that fails gives its pyramid slots and device state back all the same)
         for i in frame_range:
-            pipe.process_frame(images[i])
-    toc_ct = time.perf_counter() - t_ct                                     # :446
-    S = pipe.S
-    pipe.close()
+            if device_loop:
+                pipe.process_frame(images[i], next_image=images[i + 1] if i + 1 < len(images) else None)
+            else:
+                pipe.process_frame(images[i])
+        toc_ct = time.perf_counter() - t_ct                                 # :446
+        S = pipe.S
+    finally:
+        pipe.close()
     frame_init = len(img_seqs) + 1                                          # :447
     frame_ct = len(frame_range)                                             # :448
     fps_ct = frame_ct / toc_ct if toc_ct > 0 else 0.0                       # :449
@@ -192,7 +195,7 @@ EVAL_FEATURE_OPTIONS = {"Harris": ["MinQuality", 2e-4],      # main_eval.m:168-1
 
 
 def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0, device=None, rank=None, world=None,
-              ctx=None, now=None, concurrent=1):
+              ctx=None, now=None, concurrent=1, on_error="raise"):
     """The batch evaluation of main_eval.m: for every sequence, every feature variant (main_eval.m:19,22,
     165-174) and every repetition (:20,23) one full, independent run (run_sequence: bootstrap, loop,
     timing, quantitative_eval, '<experiment>_res.mat' as :483-494 saves it).
@@ -212,7 +215,10 @@ def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0,
 
     concurrent: runs a process keeps in flight on its GPU at once, one host thread and one context (own
     stream, own scratch) each; a single run leaves most of the GPU idle, so the grid finishes sooner, and a
-    run's result does not depend on it."""
+    run's result does not depend on it.
+    on_error: "raise" -- a run that fails (the localisation finds no pose, too few tracks: where the reference's
+    script stops with an error, main_demo.m:389-391) ends the grid, as in the reference; "record" -- its record
+    is marked failed (no trajectory) and the grid goes on."""
     import copy
     import datetime
     from . import batch
@@ -239,11 +245,17 @@ def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0,
         hp.feature_extract = feat                                           # main_eval.m:162-163
         hp.feature_extract_options = list(EVAL_FEATURE_OPTIONS[feat])       # :165-174
         t0 = time.perf_counter()
-        out = run_sequence(seq["images"], seq["K"], hp, ground_truth=seq.get("ground_truth"),
-                           bootstrap_frames=seq.get("bootstrap_frames", (0, 2)), dataset=seq["name"], save_dir=save_dir,
-                           rng=np.random.default_rng([seed, item_id]), ctx=context(),
-                           window_size=seq.get("window_size", 3), keyframe_d=seq.get("keyframe_d", 2),
-                           now=now + datetime.timedelta(seconds=item_id))
+        try:
+            out = run_sequence(seq["images"], seq["K"], hp, ground_truth=seq.get("ground_truth"),
+                               bootstrap_frames=seq.get("bootstrap_frames", (0, 2)), dataset=seq["name"],
+                               save_dir=save_dir,
+                               rng=np.random.default_rng([seed, item_id]), ctx=context(),
+                               window_size=seq.get("window_size", 3), keyframe_d=seq.get("keyframe_d", 2),
+                               now=now + datetime.timedelta(seconds=item_id))
+        except (RuntimeError, _lib.VohipError):
+            if on_error != "record":
+                raise
+            return batch.failed_record(item_id, time.perf_counter() - t0)
         S = out["S"]
         return batch.pack_record(item_id, time.perf_counter() - t0, S.est_trans, S.est_rot, S.num_X, S.num_C,
                                  S.num_new, errs=out["errs"], timing=out)
