@@ -673,9 +673,8 @@ struct vohip_frame {
     double K[9];
     int rows = 0, cols = 0, colmajor = 0;
     int capL = 0, capC = 0, capK = 0, hmax = 0;
-    hipStream_t side = nullptr, side2 = nullptr, trk = nullptr;
+    hipStream_t side = nullptr, trk = nullptr;
     hipEvent_t ev_pyr = nullptr, ev_side = nullptr, ev_img = nullptr, ev_next = nullptr, ev_tail = nullptr;
-    hipEvent_t ev_det[2] = {nullptr, nullptr};
     hipEvent_t ev_adv[2] = {nullptr, nullptr};   // after the trackers INTO the table of that parity
     hipEvent_t ev_advC[2] = {nullptr, nullptr};  // ... the candidate tracker, when it runs on the second stream
     hipEvent_t ev_feed = nullptr;                // what a tracker launch of this call waits for
@@ -1191,9 +1190,6 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
                           hipHostMallocDefault);
     if (e == hipSuccess && p.is_BA)   // the host's copy of S.P and S.X, written by every frame's last kernel
         e = hipHostMalloc((void **)&f->ba_stage, sizeof(double) * 6 * (size_t)f->capL, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->side2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det[0], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_det[1], hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->trk, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_adv[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&f->ev_adv[1], hipEventDisableTiming);
@@ -1232,16 +1228,10 @@ int vohip_frame_destroy(vohip_frame *f)
         (void)hipStreamSynchronize(f->side);
         (void)hipStreamDestroy(f->side);
     }
-    if (f->side2) {
-        (void)hipStreamSynchronize(f->side2);
-        (void)hipStreamDestroy(f->side2);
-    }
     if (f->trk) {
         (void)hipStreamSynchronize(f->trk);
         (void)hipStreamDestroy(f->trk);
     }
-    for (int q = 0; q < 2; ++q)
-        if (f->ev_det[q]) (void)hipEventDestroy(f->ev_det[q]);
     for (int q = 0; q < 2; ++q)
         if (f->ev_adv[q]) (void)hipEventDestroy(f->ev_adv[q]);
     for (int q = 0; q < 2; ++q)
@@ -1281,7 +1271,6 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
     hipStream_t s = ctx->stream;
     f->ba_mirrored = false;
     VOHIP_HIP(ctx, hipStreamSynchronize(f->side));
-    VOHIP_HIP(ctx, hipStreamSynchronize(f->side2));
     VOHIP_HIP(ctx, hipStreamSynchronize(f->trk));
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
     f->ahead = f->ahead_launched = false;

@@ -911,7 +911,8 @@ int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
     const bool split_points = h < 512 && ctx->opt_ransac_variant < 0;
     if (select) {
         // the frame's first hypotheses and the selection of the tracks they sample from, as one launch
-        VOHIP_REQUIRE(ctx, first == 0 && h <= select->h0 && select->n <= 16 * SEL_GROUPS && select->n >= 0,
+        VOHIP_REQUIRE(ctx, first == 0 && h <= select->h0 && select->n <= 16 * SEL_GROUPS && select->n >= 0 &&
+                               (reinterpret_cast<uintptr_t>(select->valid) & 15) == 0,
                       "the selection cannot ride with these hypotheses");
         const int nb_solve = (4 * h + 255) / 256, nb_select = select->n < 1 ? 1 : (select->n + 255) / 256;
         hipLaunchKernelGGL(p3p_solve_select_kernel, dim3(nb_solve + nb_select), dim3(256), 0, ctx->stream, *select, Kv, h,
