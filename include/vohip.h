@@ -389,6 +389,13 @@ int vohip_pyramid_build(vohip_ctx *ctx, int slot, const uint8_t *img, int rows, 
                         int levels);
 int vohip_pyramid_build_dev(vohip_ctx *ctx, int slot, const uint8_t *d_img, int rows, int cols,
                             int colmajor, int levels);
+/* Pyramids of n images of one size in one set of launches (no counterpart in the reference, as above):
+ * d_pyramids receives n x vohip_pyramid_floats(...) floats, each pyramid laid out as a slot's (levels back to
+ * back, each starting on a multiple of 64 floats; level l has ceil(A / 2^l) x ceil(B / 2^l) samples).
+ * Asynchronous. */
+size_t vohip_pyramid_floats(int rows, int cols, int colmajor, int levels);
+int vohip_pyramid_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                            int levels, float *d_pyramids);
 /* Copies one level (float, fast-axis-major) to `out` (may be NULL to query the size only);
  * A = fast-axis length, B = slow-axis length. */
 int vohip_pyramid_level(vohip_ctx *ctx, int slot, int level, float *out, int *A, int *B);
@@ -490,6 +497,14 @@ int vohip_detect_corners(vohip_ctx *ctx, const uint8_t *img, int rows, int cols,
 int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor,
                              double min_quality, int filter_size, int border, int method, float *d_xy,
                              float *d_metric, int cap, int *d_count);
+/* vohip_detect_corners_dev for n images of one size at once (d_imgs: image after image), for a caller that
+ * holds a whole stored sequence (main_eval.m reads one image per iteration of its loop; no counterpart there):
+ * d_xy n x (cap x 2), d_metric n x cap, d_counts n ints.  Every image's lists are those of a single call, bit
+ * for bit; one launch of each of the three kernels serves the batch, so the GPU is filled instead of waiting
+ * on a 0.47 MB image's latency.  Harris and MinEigen.  Asynchronous. */
+int vohip_detect_corners_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                                   double min_quality, int filter_size, int border, int method, float *d_xy,
+                                   float *d_metric, int cap, int *d_counts);
 
 /* Stands in for genKeypoints.m:1-33 with method 'FAST' (dispatch table genKeypoints.m:19; main_eval.m:172-173
  * passes {'MinContrast', 0.11}): detectFASTFeatures(image, 'MinContrast', c, 'MinQuality', q) followed by

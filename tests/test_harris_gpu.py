@@ -102,3 +102,60 @@ def test_fast_edge_cases(vo, ctx, oracle):
         _, kf = vo.genKeypoints(g["img"], "FAST", ["MinContrast", 0.11], ctx=ctx)
         np.testing.assert_array_equal(kf.Location, abf + 1.0)
         np.testing.assert_array_equal(kf.Metric, mf)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_batched_detection_and_pyramids_equal_single_calls(vo, ctx, method):
+    """vohip_detect_corners_batch_dev / vohip_pyramid_batch_dev over a stored sequence (image after image in
+    device memory): every image's corner list, count and pyramid levels are those of the single-image calls,
+    bit for bit."""
+    import ctypes as C
+    import torch
+    lib = vo._lib.load()
+    scene = vo.synth.CorridorScene(seed=11, width=640, height=232)
+    poses = vo.synth.corridor_trajectory(5, step=0.7)
+    frames = np.stack([scene.render(T) for T in poses])
+    n, rows, cols = frames.shape
+    dev = torch.device("cuda", 0)
+    d_imgs = torch.from_numpy(frames).to(dev)
+    cap = 4096
+    d_xy = torch.zeros((n, 2, cap), dtype=torch.float32, device=dev)
+    d_metric = torch.zeros((n, cap), dtype=torch.float32, device=dev)
+    d_counts = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = C.c_void_p(lib.vohip_stream(ctx.handle))
+    torch.cuda.synchronize()
+    for _ in range(2):   # (a second batch on the same scratch)
+        ctx.check(lib.vohip_detect_corners_batch_dev(ctx.handle, d_imgs.data_ptr(), n, rows, cols, 0, 2e-4, 5, 16, method,
+                                                     d_xy.data_ptr(), d_metric.data_ptr(), cap, d_counts.data_ptr()))
+    ctx.synchronize()
+    counts = d_counts.cpu().numpy()
+    assert counts.min() > 200
+    s_xy = torch.zeros((2, cap), dtype=torch.float32, device=dev)
+    s_metric = torch.zeros(cap, dtype=torch.float32, device=dev)
+    s_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    for k in range(n):
+        ctx.check(lib.vohip_detect_corners_dev(ctx.handle, d_imgs[k].data_ptr(), rows, cols, 0, 2e-4, 5, 16, method,
+                                               s_xy.data_ptr(), s_metric.data_ptr(), cap, s_count.data_ptr()))
+        ctx.synchronize()
+        c = int(s_count.item())
+        assert c == counts[k]
+        assert torch.equal(s_xy[:, :c], d_xy[k][:, :c]) and torch.equal(s_metric[:c], d_metric[k][:c])
+    # pyramids
+    levels = 5
+    per = lib.vohip_pyramid_floats(rows, cols, 0, levels)
+    d_pyr = torch.zeros((n, per), dtype=torch.float32, device=dev)
+    ctx.check(lib.vohip_pyramid_batch_dev(ctx.handle, d_imgs.data_ptr(), n, rows, cols, 0, levels, d_pyr.data_ptr()))
+    ctx.synchronize()
+    got = d_pyr.cpu().numpy()
+    for k in (0, n - 1):
+        pyr = vo.Pyramid(d_imgs[k], levels, ctx=ctx)
+        off, A, B = 0, cols, rows
+        for l in range(levels):
+            want = pyr.level(l)
+            assert want.shape == (B, A)
+            np.testing.assert_array_equal(got[k, off:off + A * B].reshape(B, A), want)
+            off += (A * B + 63) // 64 * 64
+            A, B = (A + 1) // 2, (B + 1) // 2
+        assert off == per
+        pyr.release()
+    del stream

@@ -165,6 +165,10 @@ SIGNATURES = {
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_pyramid_build": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vohip_pyramid_build_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vohip_pyramid_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "vohip_pyramid_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "vohip_detect_corners_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_pyramid_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_float_p, c_int_p, c_int_p]),
     "vohip_klt_track": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, C.c_int, C.c_int, C.c_int,
                                    C.c_double, c_double_p, c_uint8_p, c_double_p]),

@@ -130,14 +130,29 @@ __device__ __forceinline__ void tile_maxima(const float *sR, float best, unsigne
     }
 }
 
+// Strides of image blockIdx.y of a batch (all zero for a single image): every image has its own records,
+// counts, maximum slots and output lists.
+struct corner_batch {
+    size_t img = 0, recs = 0;       // pixels per image; records per image
+    int tiles = 0;                  // tiles per image (tile_count, totals; cells: tiles * TB)
+    int max_slots = 0;              // maximum slots per image
+    int xy = 0, metric = 0;         // floats per image in xy_out / metric_out
+    int count = 0;                  // ints per image in count
+};
+
 // max_bits[0 / 1]: the maximum of this call / cleared here for the next call (the two alternate).
 __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restrict__ img, int A, int B, int tiles_a,
                                                           int tiles_b, taps5 G, int method, int lo,
                                                           corner_rec *__restrict__ recs,
                                                           int *__restrict__ tile_count,
                                                           unsigned *__restrict__ max_now,
-                                                          unsigned *__restrict__ max_next)
+                                                          unsigned *__restrict__ max_next, corner_batch bt)
 {
+    img += blockIdx.y * bt.img;
+    recs += blockIdx.y * bt.recs;
+    tile_count += blockIdx.y * (size_t)bt.tiles;
+    max_now += blockIdx.y * (size_t)bt.max_slots;
+    max_next += blockIdx.y * (size_t)bt.max_slots;
     __shared__ float sI[IA * IB];
     __shared__ float sP[3][PA * PB];
     __shared__ float sH[3][RA * PB];
@@ -294,8 +309,14 @@ __global__ __launch_bounds__(256) void corner_count_kernel(const corner_rec *__r
                                                            const int *__restrict__ tile_count, int ntiles, int tiles_a,
                                                            int A, float min_quality,
                                                            const unsigned *__restrict__ max_bits,
-                                                           int *__restrict__ cells, int *__restrict__ totals)
+                                                           int *__restrict__ cells, int *__restrict__ totals,
+                                                           corner_batch bt)
 {
+    recs += blockIdx.y * bt.recs;
+    tile_count += blockIdx.y * (size_t)bt.tiles;
+    max_bits += blockIdx.y * (size_t)bt.max_slots;
+    cells += blockIdx.y * (size_t)bt.tiles * TB;
+    totals += blockIdx.y * (size_t)bt.tiles;
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= ntiles) return;
@@ -333,8 +354,16 @@ __global__ __launch_bounds__(256) void corner_emit_kernel(const corner_rec *__re
                                                           int A, float min_quality,
                                                           const unsigned *__restrict__ max_bits, int cap, int swap_xy,
                                                           float *__restrict__ xy_out, float *__restrict__ metric_out,
-                                                          int *__restrict__ count)
+                                                          int *__restrict__ count, corner_batch bt)
 {
+    recs += blockIdx.y * bt.recs;
+    tile_count += blockIdx.y * (size_t)bt.tiles;
+    max_bits += blockIdx.y * (size_t)bt.max_slots;
+    cells += blockIdx.y * (size_t)bt.tiles * TB;
+    totals += blockIdx.y * (size_t)bt.tiles;
+    xy_out += blockIdx.y * (size_t)bt.xy;
+    metric_out += blockIdx.y * (size_t)bt.metric;
+    count += blockIdx.y * (size_t)bt.count;
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= ntiles) return;
@@ -460,13 +489,72 @@ int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, 
                            max2 + (slot ^ 1u));
     else
         hipLaunchKernelGGL(corner_tile_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, st, d_img, A, B, tiles_a,
-                           tiles_b, G, method, lo, recs, tile_count, max2 + slot, max2 + (slot ^ 1u));
+                           tiles_b, G, method, lo, recs, tile_count, max2 + slot, max2 + (slot ^ 1u), corner_batch());
     hipLaunchKernelGGL(corner_count_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, (const corner_rec *)recs,
                        (const int *)tile_count, ntiles, tiles_a, A, (float)min_quality, (const unsigned *)(max2 + slot),
-                       cells, totals);
+                       cells, totals, corner_batch());
     hipLaunchKernelGGL(corner_emit_kernel, dim3((ntiles + 3) / 4), dim3(256), 0, st, (const corner_rec *)recs,
                        (const int *)tile_count, (const int *)cells, (const int *)totals, ntiles, tiles_a, A,
-                       (float)min_quality, (const unsigned *)(max2 + slot), cap, colmajor ? 1 : 0, d_xy, d_metric, d_count);
+                       (float)min_quality, (const unsigned *)(max2 + slot), cap, colmajor ? 1 : 0, d_xy, d_metric, d_count,
+                       corner_batch());
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+// The same three kernels over n images at once (blockIdx.y = image): every image keeps its own records,
+// counts, maximum and output lists, so the lists are those of n single calls, bit for bit.
+int vohip_detect_corners_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                                       double min_quality, int filter_size, int border, int method, float *d_xy,
+                                       float *d_metric, int cap, int *d_counts)
+{
+    VOHIP_REQUIRE(ctx, d_imgs && d_xy && d_metric && d_counts, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 1 && n <= 65535, "1..65535 images per call");
+    VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
+    VOHIP_REQUIRE(ctx, method == 0 || method == 1, "method: 0 = Harris, 1 = MinEigen");
+    VOHIP_REQUIRE(ctx, filter_size == FS, "only FilterSize 5 (the toolbox default) is built");
+    VOHIP_REQUIRE(ctx, cap >= 1 && cap <= 16384, "cap must be 1..16384");
+    VOHIP_REQUIRE(ctx, border >= 0, "negative border");
+    const int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
+    const int tiles_a = (A + TA - 1) / TA, tiles_b = (B + TB - 1) / TB, ntiles = tiles_a * tiles_b;
+    auto round256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    // scratch of the whole batch: [maxima | tile counts | totals | cells | records | spare maxima], image after image in each
+    const size_t b_max = round256(sizeof(unsigned) * (size_t)n), b_cnt = round256(sizeof(int) * (size_t)n * ntiles),
+                 b_cells = round256(sizeof(int) * (size_t)n * ntiles * TB),
+                 b_recs = sizeof(corner_rec) * (size_t)n * ntiles * TILE_CAP;
+    vohip_buf &buf = ctx->bufs[B_HARRIS_BATCH];
+    VOHIP_TRY(vohip_reserve(ctx, buf, 2 * b_max + 2 * b_cnt + b_cells + b_recs));
+    char *p = (char *)buf.ptr;
+    unsigned *maxima = (unsigned *)p;
+    p += b_max;
+    int *tile_count = (int *)p;
+    p += b_cnt;
+    int *totals = (int *)p;
+    p += b_cnt;
+    int *cells = (int *)p;
+    p += b_cells;
+    corner_rec *recs = (corner_rec *)p;
+    unsigned *spare = (unsigned *)(p + b_recs);   // (n words: the slot an image's first tile clears "for the next call")
+    hipStream_t st = ctx->stream;
+    VOHIP_HIP(ctx, hipMemsetAsync(maxima, 0, b_max, st));
+    corner_batch bt;
+    bt.img = (size_t)A * B;
+    bt.recs = (size_t)ntiles * TILE_CAP;
+    bt.tiles = ntiles;
+    bt.max_slots = 1;
+    bt.xy = 2 * cap;
+    bt.metric = cap;
+    bt.count = 1;
+    taps5 G;
+    gaussian_taps(filter_size, G.w);
+    const int lo = border < 1 ? 1 : border;
+    hipLaunchKernelGGL(corner_tile_kernel, dim3(8 * ((ntiles + 7) / 8), n), dim3(256), 0, st, d_imgs, A, B, tiles_a, tiles_b,
+                       G, method, lo, recs, tile_count, maxima, spare, bt);
+    hipLaunchKernelGGL(corner_count_kernel, dim3((ntiles + 3) / 4, n), dim3(256), 0, st, (const corner_rec *)recs,
+                       (const int *)tile_count, ntiles, tiles_a, A, (float)min_quality, (const unsigned *)maxima, cells, totals,
+                       bt);
+    hipLaunchKernelGGL(corner_emit_kernel, dim3((ntiles + 3) / 4, n), dim3(256), 0, st, (const corner_rec *)recs,
+                       (const int *)tile_count, (const int *)cells, (const int *)totals, ntiles, tiles_a, A,
+                       (float)min_quality, (const unsigned *)maxima, cap, colmajor ? 1 : 0, d_xy, d_metric, d_counts, bt);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
@@ -532,6 +620,15 @@ int vohip_detect_corners_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int
     VOHIP_REQUIRE(ctx, method == 0 || method == 1, "method: 0 = Harris, 1 = MinEigen");
     return detect_dev(ctx, d_img, rows, cols, colmajor, min_quality, filter_size, border, method, 0.0, d_xy, d_metric,
                       cap, d_count);
+}
+
+int vohip_detect_corners_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                                   double min_quality, int filter_size, int border, int method, float *d_xy,
+                                   float *d_metric, int cap, int *d_counts)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    return vohip_detect_corners_batch_enqueue(ctx, d_imgs, n, rows, cols, colmajor, min_quality, filter_size, border, method,
+                                              d_xy, d_metric, cap, d_counts);
 }
 
 int vohip_detect_corners(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double min_quality,

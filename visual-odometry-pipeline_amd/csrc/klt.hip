@@ -52,20 +52,25 @@ __device__ __forceinline__ float tap5(float t0, float t1, float t2, float t3, fl
     return ((t0 + t4) + 4.0f * (t1 + t3) + 6.0f * t2) * 0.0625f;
 }
 
+// (blockIdx.y: image of a batch; the strides are 0 for a single image)
 __global__ __launch_bounds__(256) void u8_to_float_kernel(const uint8_t *__restrict__ src, int n,
-                                                          float *__restrict__ dst)
+                                                          float *__restrict__ dst, size_t src_stride = 0,
+                                                          size_t dst_stride = 0)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = (float)src[i];
+    if (i < n) dst[blockIdx.y * dst_stride + i] = (float)src[blockIdx.y * src_stride + i];
 }
 
 // [1 4 6 4 1]/16 along a then along b, replicated border, even samples kept.
+// (blockIdx.z: image of a batch, `stride` floats apart in src and dst; 0 for a single image)
 __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__ src, int A, int B,
-                                                       float *__restrict__ dst, int A2, int B2)
+                                                       float *__restrict__ dst, int A2, int B2, size_t stride = 0)
 {
     const int a = blockIdx.x * 64 + (threadIdx.x & 63);
     const int b = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (a >= A2 || b >= B2) return;
+    src += blockIdx.z * stride;
+    dst += blockIdx.z * stride;
     const int a0 = max(2 * a - 2, 0), a1 = max(2 * a - 1, 0), a2 = 2 * a, a3 = min(2 * a + 1, A - 1),
               a4 = min(2 * a + 2, A - 1);
     float col[5];
@@ -76,6 +81,45 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__
         col[j] = tap5(row[a0], row[a1], row[a2], row[a3], row[a4]);
     }
     dst[(size_t)b * A2 + a] = tap5(col[0], col[1], col[2], col[3], col[4]);
+}
+
+// Levels 0 and 1 from the uint8 image in one pass: a thread makes one level-1 sample from the 5 x 5 pixels
+// around (2a, 2b) -- converted as they are read, the same taps in the same order as pyr_down_kernel applies to
+// the float level -- and writes the 2 x 2 block of level-0 floats at (2a, 2b), which lies inside that window.
+// The float image is then never read back: level 0 costs its write only.  (blockIdx.z: image of a batch.)
+__global__ __launch_bounds__(256) void pyr_first_kernel(const uint8_t *__restrict__ src, int A, int B,
+                                                        float *__restrict__ lvl0, float *__restrict__ lvl1, int A2, int B2,
+                                                        size_t src_stride, size_t dst_stride)
+{
+    const int a = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int b = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (a >= A2 || b >= B2) return;
+    src += blockIdx.z * src_stride;
+    lvl0 += blockIdx.z * dst_stride;
+    lvl1 += blockIdx.z * dst_stride;
+    const int a0 = max(2 * a - 2, 0), a1 = max(2 * a - 1, 0), a2 = 2 * a, a3 = min(2 * a + 1, A - 1),
+              a4 = min(2 * a + 2, A - 1);
+    float col[5], mid[2][2];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int bb = min(max(2 * b + j - 2, 0), B - 1);
+        const uint8_t *row = src + (size_t)bb * A;
+        const float t0 = (float)row[a0], t1 = (float)row[a1], t2 = (float)row[a2], t3 = (float)row[a3], t4 = (float)row[a4];
+        col[j] = tap5(t0, t1, t2, t3, t4);
+        if (j == 2 || j == 3) {   // rows 2b and 2b + 1 (the latter clamped onto 2b when it does not exist: not stored then)
+            mid[j - 2][0] = t2;
+            mid[j - 2][1] = t3;
+        }
+    }
+    lvl1[(size_t)b * A2 + a] = tap5(col[0], col[1], col[2], col[3], col[4]);
+    const bool right = 2 * a + 1 < A;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (2 * b + r >= B) break;
+        float *o = lvl0 + (size_t)(2 * b + r) * A + 2 * a;
+        o[0] = mid[r][0];
+        if (right) o[1] = mid[r][1];
+    }
 }
 
 #pragma clang fp contract(fast)
@@ -489,10 +533,15 @@ int vohip_pyramid_build_dev(vohip_ctx *ctx, int slot, const uint8_t *d_img, int 
     VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_PYR0 + slot], total * sizeof(float)));
     float *base = (float *)ctx->bufs[B_PYR0 + slot].ptr;
     const int n0 = p.A[0] * p.B[0];
-    hipLaunchKernelGGL(u8_to_float_kernel, dim3((n0 + 255) / 256), dim3(256), 0, ctx->stream, d_img, n0, base);
-    for (int l = 1; l < levels; ++l)
+    if (levels == 1)
+        hipLaunchKernelGGL(u8_to_float_kernel, dim3((n0 + 255) / 256), dim3(256), 0, ctx->stream, d_img, n0, base, (size_t)0,
+                           (size_t)0);
+    else   // levels 0 and 1 in one pass over the image
+        hipLaunchKernelGGL(pyr_first_kernel, dim3((p.A[1] + 63) / 64, (p.B[1] + 3) / 4), dim3(256), 0, ctx->stream, d_img,
+                           p.A[0], p.B[0], base, base + p.offset[1], p.A[1], p.B[1], (size_t)0, (size_t)0);
+    for (int l = 2; l < levels; ++l)
         hipLaunchKernelGGL(pyr_down_kernel, dim3((p.A[l] + 63) / 64, (p.B[l] + 3) / 4), dim3(256), 0, ctx->stream,
-                           base + p.offset[l - 1], p.A[l - 1], p.B[l - 1], base + p.offset[l], p.A[l], p.B[l]);
+                           base + p.offset[l - 1], p.A[l - 1], p.B[l - 1], base + p.offset[l], p.A[l], p.B[l], (size_t)0);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
@@ -504,6 +553,52 @@ int vohip_pyramid_build(vohip_ctx *ctx, int slot, const uint8_t *img, int rows, 
     void *d_img;
     VOHIP_TRY(vohip_upload(ctx, B_IMG_STAGE, img, (size_t)rows * cols, &d_img));
     return vohip_pyramid_build_dev(ctx, slot, (const uint8_t *)d_img, rows, cols, colmajor, levels);
+}
+
+// Level l of a pyramid starts `offset[l]` floats into it (levels back to back, 64-float aligned).
+static size_t pyramid_layout(int rows, int cols, int colmajor, int levels, int *As, int *Bs, size_t *offset)
+{
+    size_t total = 0;
+    int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
+    for (int l = 0; l < levels; ++l) {
+        if (As) As[l] = A;
+        if (Bs) Bs[l] = B;
+        if (offset) offset[l] = total;
+        total += ((size_t)A * B + 63) / 64 * 64;
+        A = (A + 1) / 2;
+        B = (B + 1) / 2;
+    }
+    return total;
+}
+
+size_t vohip_pyramid_floats(int rows, int cols, int colmajor, int levels)
+{
+    if (rows < 1 || cols < 1 || levels < 1 || levels > MAX_LEVELS) return 0;
+    return pyramid_layout(rows, cols, colmajor, levels, nullptr, nullptr, nullptr);
+}
+
+int vohip_pyramid_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor, int levels,
+                            float *d_pyramids)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, d_imgs && d_pyramids && rows >= 1 && cols >= 1, "bad image");
+    VOHIP_REQUIRE(ctx, levels >= 1 && levels <= MAX_LEVELS, "levels must be 1..8");
+    VOHIP_REQUIRE(ctx, n >= 1 && n <= 65535, "1..65535 images per call");
+    int A[MAX_LEVELS], B[MAX_LEVELS];
+    size_t off[MAX_LEVELS];
+    const size_t total = pyramid_layout(rows, cols, colmajor, levels, A, B, off);
+    const int n0 = A[0] * B[0];
+    if (levels == 1)
+        hipLaunchKernelGGL(u8_to_float_kernel, dim3((n0 + 255) / 256, n), dim3(256), 0, ctx->stream, d_imgs, n0, d_pyramids,
+                           (size_t)n0, total);
+    else
+        hipLaunchKernelGGL(pyr_first_kernel, dim3((A[1] + 63) / 64, (B[1] + 3) / 4, n), dim3(256), 0, ctx->stream, d_imgs,
+                           A[0], B[0], d_pyramids, d_pyramids + off[1], A[1], B[1], (size_t)n0, total);
+    for (int l = 2; l < levels; ++l)
+        hipLaunchKernelGGL(pyr_down_kernel, dim3((A[l] + 63) / 64, (B[l] + 3) / 4, n), dim3(256), 0, ctx->stream,
+                           (const float *)(d_pyramids + off[l - 1]), A[l - 1], B[l - 1], d_pyramids + off[l], A[l], B[l], total);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
 }
 
 int vohip_pyramid_level(vohip_ctx *ctx, int slot, int level, float *out, int *A, int *B)
