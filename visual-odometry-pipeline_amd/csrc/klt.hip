@@ -83,42 +83,46 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__
     dst[(size_t)b * A2 + a] = tap5(col[0], col[1], col[2], col[3], col[4]);
 }
 
-// Levels 0 and 1 from the uint8 image in one pass: a thread makes one level-1 sample from the 5 x 5 pixels
-// around (2a, 2b) -- converted as they are read, the same taps in the same order as pyr_down_kernel applies to
-// the float level -- and writes the 2 x 2 block of level-0 floats at (2a, 2b), which lies inside that window.
-// The float image is then never read back: level 0 costs its write only.  (blockIdx.z: image of a batch.)
+// Levels 0 and 1 from the uint8 image in one pass: a level-1 sample comes from the 5 x 5 pixels around
+// (2a, 2b) -- converted as they are read, the same taps in the same order as pyr_down_kernel applies to the
+// float level -- and the 2 x 2 block of level-0 floats at (2a, 2b) lies inside that window, so the float
+// image is written here and never read back: level 0 costs its write only.  A thread makes PF_ROWS
+// vertically adjacent samples: their windows share three of five image rows, so it reads 2 PF_ROWS + 3 rows
+// of five pixels instead of 5 PF_ROWS (the byte loads, not the memory behind them, bound this kernel).
+// (blockIdx.z: image of a batch.)
+constexpr int PF_ROWS = 4;
 __global__ __launch_bounds__(256) void pyr_first_kernel(const uint8_t *__restrict__ src, int A, int B,
                                                         float *__restrict__ lvl0, float *__restrict__ lvl1, int A2, int B2,
                                                         size_t src_stride, size_t dst_stride)
 {
-    const int a = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int b = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (a >= A2 || b >= B2) return;
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    const int b_first = blockIdx.y * PF_ROWS;
+    if (a >= A2) return;
     src += blockIdx.z * src_stride;
     lvl0 += blockIdx.z * dst_stride;
     lvl1 += blockIdx.z * dst_stride;
     const int a0 = max(2 * a - 2, 0), a1 = max(2 * a - 1, 0), a2 = 2 * a, a3 = min(2 * a + 1, A - 1),
               a4 = min(2 * a + 2, A - 1);
-    float col[5], mid[2][2];
+    const bool right = 2 * a + 1 < A;
+    // image rows 2 b_first - 2 .. 2 b_first + 2 PF_ROWS: the horizontal pass of each, once
+    float h[2 * PF_ROWS + 3];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int bb = min(max(2 * b + j - 2, 0), B - 1);
+    for (int j = 0; j < 2 * PF_ROWS + 3; ++j) {
+        const int y = 2 * b_first + j - 2;
+        const int bb = min(max(y, 0), B - 1);
         const uint8_t *row = src + (size_t)bb * A;
         const float t0 = (float)row[a0], t1 = (float)row[a1], t2 = (float)row[a2], t3 = (float)row[a3], t4 = (float)row[a4];
-        col[j] = tap5(t0, t1, t2, t3, t4);
-        if (j == 2 || j == 3) {   // rows 2b and 2b + 1 (the latter clamped onto 2b when it does not exist: not stored then)
-            mid[j - 2][0] = t2;
-            mid[j - 2][1] = t3;
+        h[j] = tap5(t0, t1, t2, t3, t4);
+        if (j >= 2 && j < 2 * PF_ROWS + 2 && y < B) {   // (y >= 0 here) an image row of this thread's blocks: its two pixels
+            float *o = lvl0 + (size_t)y * A + 2 * a;
+            o[0] = t2;
+            if (right) o[1] = t3;
         }
     }
-    lvl1[(size_t)b * A2 + a] = tap5(col[0], col[1], col[2], col[3], col[4]);
-    const bool right = 2 * a + 1 < A;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if (2 * b + r >= B) break;
-        float *o = lvl0 + (size_t)(2 * b + r) * A + 2 * a;
-        o[0] = mid[r][0];
-        if (right) o[1] = mid[r][1];
+    for (int r = 0; r < PF_ROWS; ++r) {
+        const int b = b_first + r;
+        if (b < B2) lvl1[(size_t)b * A2 + a] = tap5(h[2 * r], h[2 * r + 1], h[2 * r + 2], h[2 * r + 3], h[2 * r + 4]);
     }
 }
 
@@ -537,7 +541,7 @@ int vohip_pyramid_build_dev(vohip_ctx *ctx, int slot, const uint8_t *d_img, int 
         hipLaunchKernelGGL(u8_to_float_kernel, dim3((n0 + 255) / 256), dim3(256), 0, ctx->stream, d_img, n0, base, (size_t)0,
                            (size_t)0);
     else   // levels 0 and 1 in one pass over the image
-        hipLaunchKernelGGL(pyr_first_kernel, dim3((p.A[1] + 63) / 64, (p.B[1] + 3) / 4), dim3(256), 0, ctx->stream, d_img,
+        hipLaunchKernelGGL(pyr_first_kernel, dim3((p.A[1] + 255) / 256, (p.B[1] + PF_ROWS - 1) / PF_ROWS), dim3(256), 0, ctx->stream, d_img,
                            p.A[0], p.B[0], base, base + p.offset[1], p.A[1], p.B[1], (size_t)0, (size_t)0);
     for (int l = 2; l < levels; ++l)
         hipLaunchKernelGGL(pyr_down_kernel, dim3((p.A[l] + 63) / 64, (p.B[l] + 3) / 4), dim3(256), 0, ctx->stream,
@@ -592,7 +596,7 @@ int vohip_pyramid_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int ro
         hipLaunchKernelGGL(u8_to_float_kernel, dim3((n0 + 255) / 256, n), dim3(256), 0, ctx->stream, d_imgs, n0, d_pyramids,
                            (size_t)n0, total);
     else
-        hipLaunchKernelGGL(pyr_first_kernel, dim3((A[1] + 63) / 64, (B[1] + 3) / 4, n), dim3(256), 0, ctx->stream, d_imgs,
+        hipLaunchKernelGGL(pyr_first_kernel, dim3((A[1] + 255) / 256, (B[1] + PF_ROWS - 1) / PF_ROWS, n), dim3(256), 0, ctx->stream, d_imgs,
                            A[0], B[0], d_pyramids, d_pyramids + off[1], A[1], B[1], (size_t)n0, total);
     for (int l = 2; l < levels; ++l)
         hipLaunchKernelGGL(pyr_down_kernel, dim3((A[l] + 63) / 64, (B[l] + 3) / 4, n), dim3(256), 0, ctx->stream,
