@@ -61,26 +61,35 @@ __global__ __launch_bounds__(256) void u8_to_float_kernel(const uint8_t *__restr
     if (i < n) dst[blockIdx.y * dst_stride + i] = (float)src[blockIdx.y * src_stride + i];
 }
 
-// [1 4 6 4 1]/16 along a then along b, replicated border, even samples kept.
+// [1 4 6 4 1]/16 along a then along b, replicated border, even samples kept.  A thread makes PD_ROWS
+// vertically adjacent samples: their windows share three of five source rows (2 PD_ROWS + 3 horizontal
+// passes instead of 5 PD_ROWS; each sample's arithmetic is what a thread of its own would do).  One sample
+// per thread for a single image (its small levels are a matter of latency: 12.4 us per pyramid against 18.0
+// with four), four for a batch (throughput: 0.52 -> 0.47 ms per 256 pyramids).
 // (blockIdx.z: image of a batch, `stride` floats apart in src and dst; 0 for a single image)
+template <int PD_ROWS>
 __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__ src, int A, int B,
-                                                       float *__restrict__ dst, int A2, int B2, size_t stride = 0)
+                                                       float *__restrict__ dst, int A2, int B2, size_t stride)
 {
     const int a = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int b = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (a >= A2 || b >= B2) return;
+    const int b_first = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PD_ROWS;
+    if (a >= A2 || b_first >= B2) return;
     src += blockIdx.z * stride;
     dst += blockIdx.z * stride;
     const int a0 = max(2 * a - 2, 0), a1 = max(2 * a - 1, 0), a2 = 2 * a, a3 = min(2 * a + 1, A - 1),
               a4 = min(2 * a + 2, A - 1);
-    float col[5];
+    float h[2 * PD_ROWS + 3];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int bb = min(max(2 * b + j - 2, 0), B - 1);
+    for (int j = 0; j < 2 * PD_ROWS + 3; ++j) {
+        const int bb = min(max(2 * b_first + j - 2, 0), B - 1);
         const float *row = src + (size_t)bb * A;
-        col[j] = tap5(row[a0], row[a1], row[a2], row[a3], row[a4]);
+        h[j] = tap5(row[a0], row[a1], row[a2], row[a3], row[a4]);
     }
-    dst[(size_t)b * A2 + a] = tap5(col[0], col[1], col[2], col[3], col[4]);
+#pragma unroll
+    for (int r = 0; r < PD_ROWS; ++r) {
+        const int b = b_first + r;
+        if (b < B2) dst[(size_t)b * A2 + a] = tap5(h[2 * r], h[2 * r + 1], h[2 * r + 2], h[2 * r + 3], h[2 * r + 4]);
+    }
 }
 
 // Levels 0 and 1 from the uint8 image in one pass: a level-1 sample comes from the 5 x 5 pixels around
@@ -544,7 +553,7 @@ int vohip_pyramid_build_dev(vohip_ctx *ctx, int slot, const uint8_t *d_img, int 
         hipLaunchKernelGGL(pyr_first_kernel, dim3((p.A[1] + 255) / 256, (p.B[1] + PF_ROWS - 1) / PF_ROWS), dim3(256), 0, ctx->stream, d_img,
                            p.A[0], p.B[0], base, base + p.offset[1], p.A[1], p.B[1], (size_t)0, (size_t)0);
     for (int l = 2; l < levels; ++l)
-        hipLaunchKernelGGL(pyr_down_kernel, dim3((p.A[l] + 63) / 64, (p.B[l] + 3) / 4), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(pyr_down_kernel<1>, dim3((p.A[l] + 63) / 64, (p.B[l] + 3) / 4), dim3(256), 0, ctx->stream,
                            base + p.offset[l - 1], p.A[l - 1], p.B[l - 1], base + p.offset[l], p.A[l], p.B[l], (size_t)0);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
@@ -599,7 +608,7 @@ int vohip_pyramid_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int ro
         hipLaunchKernelGGL(pyr_first_kernel, dim3((A[1] + 255) / 256, (B[1] + PF_ROWS - 1) / PF_ROWS, n), dim3(256), 0, ctx->stream, d_imgs,
                            A[0], B[0], d_pyramids, d_pyramids + off[1], A[1], B[1], (size_t)n0, total);
     for (int l = 2; l < levels; ++l)
-        hipLaunchKernelGGL(pyr_down_kernel, dim3((A[l] + 63) / 64, (B[l] + 3) / 4, n), dim3(256), 0, ctx->stream,
+        hipLaunchKernelGGL(pyr_down_kernel<4>, dim3((A[l] + 63) / 64, (B[l] + 15) / 16, n), dim3(256), 0, ctx->stream,
                            (const float *)(d_pyramids + off[l - 1]), A[l - 1], B[l - 1], d_pyramids + off[l], A[l], B[l], total);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
