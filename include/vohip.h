@@ -291,6 +291,15 @@ int vohip_frame_step_ahead(vohip_frame *f, const uint8_t *image, int image_on_de
 int vohip_frame_begin(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
                       int next_on_device, const double *u3, int h, const double *u8);
 int vohip_frame_finish(vohip_frame *f, vohip_frame_pose *pose, vohip_frame_counts *counts);
+/* For a stored sequence (the loop of main_demo.m:352-375 reads its images from a directory): the n images
+ * (pointers to host memory, or to device memory when the flag is set) are copied to the device and the
+ * pyramids and corner lists of ALL of them are made by one batched launch sequence each (image = a grid
+ * dimension; the FAST variant's corners are still detected frame by frame).  A later vohip_frame_begin /
+ * _step / _step_ahead whose `image` or `next_image` is one of these pointers then transfers nothing, builds no
+ * pyramid and detects no corners for it; the results are those of the unprepared calls, bit for bit.  The
+ * prepared data (about 2.7 MB per KITTI-shape image) lives until the next vohip_frame_prepare (n = 0 frees
+ * it) or vohip_frame_destroy; the images themselves are not read again.  No counterpart in the reference. */
+int vohip_frame_prepare(vohip_frame *f, const uint8_t *const *images, int n, int on_device);
 int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates);
 /* Copies of S.P (2xn), S.X(1:3,:) (3xn), S.X(4,:), S.C, S.F (2xm), S.T (12xm); any pointer may be NULL. */
 int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc, double *T12);

@@ -73,6 +73,39 @@ def test_device_loop_with_few_landmarks_and_lost_tracks(vo, ctx, oracle, sequenc
     dev.close()
 
 
+@pytest.mark.parametrize("feat,on_device,ahead", [("Harris", False, True), ("Harris", True, True), ("Harris", False, False),
+                                                  ("MinEigen", True, True), ("FAST", False, True)])
+def test_prepared_sequence_changes_nothing(vo, ctx, oracle, sequence, feat, on_device, ahead):
+    """vohip_frame_prepare: the stored sequence's images on the GPU once, all pyramids and corner lists from
+    batched launches (FAST: the pyramids only).  Poses, counts and the final state are those of the loop that
+    transfers, builds and detects frame by frame, bit for bit; so is a frame that was not prepared."""
+    import torch
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    hp.feature_extract = feat
+    hp.feature_extract_options = {"Harris": ["MinQuality", 2e-4], "MinEigen": ["MinQuality", 2e-3],
+                                  "FAST": ["MinContrast", 0.11]}[feat]
+    imgs = [torch.from_numpy(f).cuda() for f in frames] if on_device else frames
+    runs = []
+    for prepared in (False, True):
+        dev = vo.VOPipelineDevice(K, imgs[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(5), ctx=ctx)
+        if prepared:
+            dev.prepare(imgs[1:-1])            # (the last frame is left to the unprepared path)
+        Ts = []
+        for i in range(1, len(imgs)):
+            nxt = imgs[i + 1] if ahead and i + 1 < len(imgs) else None
+            Ts.append(dev.process_frame(imgs[i], next_image=nxt))
+        runs.append((np.array(Ts), list(dev.num_X), list(dev.num_C), list(dev.num_new), dev.S,
+                     dev.last_counts.n_detected, dev.rng.bit_generator.state))
+        dev.close()
+    a, b = runs
+    np.testing.assert_array_equal(a[0], b[0])
+    assert a[1:4] == b[1:4] and a[5] == b[5] and a[6] == b[6]
+    for key in ("P", "X", "C", "F", "T"):
+        np.testing.assert_array_equal(getattr(a[4], key), getattr(b[4], key), err_msg=key)
+
+
 def test_device_loop_matches_stage_by_stage_loop(vo, ctx, oracle, sequence):
     scene, poses, frames = sequence
     X0, xy = _start(vo, oracle, sequence)

@@ -96,6 +96,7 @@ SIGNATURES = {
     "vohip_frame_finish": (C.c_int, [C.c_void_p, C.POINTER(FramePose), C.POINTER(FrameCounts)]),
     "vohip_frame_step_ahead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_double_p, C.c_int,
                                           c_double_p, C.POINTER(FramePose), C.POINTER(FrameCounts)]),
+    "vohip_frame_prepare": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "vohip_frame_sizes": (C.c_int, [C.c_void_p, c_int_p, c_int_p]),
     "vohip_frame_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]),

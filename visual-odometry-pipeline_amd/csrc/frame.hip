@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <unordered_map>
 
 namespace {
 
@@ -652,6 +653,32 @@ __global__ __launch_bounds__(256) void detection_rows_kernel(const float *__rest
     U_live[base + i] = on ? 1 : 0;
 }
 
+// The same for an image whose corners were detected ahead with the whole stored sequence: its list and
+// count are copied to where the frame's other kernels read them, and become rows of the table.
+__global__ __launch_bounds__(256) void prepared_rows_kernel(const float *__restrict__ src_xy,
+                                                            const float *__restrict__ src_metric,
+                                                            const int *__restrict__ src_count, int capK,
+                                                            float *__restrict__ corner_xy,
+                                                            float *__restrict__ corner_metric, int *__restrict__ n_det,
+                                                            int base, int ld, double *__restrict__ U_xy,
+                                                            uint8_t *__restrict__ U_live)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= capK) return;
+    const int n = *src_count;
+    if (i == 0) *n_det = n;
+    const bool on = i < n;
+    if (on) {
+        const float x = src_xy[i], y = src_xy[capK + i];
+        corner_xy[i] = x;
+        corner_xy[capK + i] = y;
+        corner_metric[i] = src_metric[i];
+        U_xy[base + i] = (double)x;
+        U_xy[ld + base + i] = (double)y;
+    }
+    U_live[base + i] = on ? 1 : 0;
+}
+
 // main_demo.m:342-344: the landmarks a sequence starts with, as rows of the table.
 __global__ __launch_bounds__(256) void init_rows_kernel(const double *__restrict__ L_rc, int n, int ld,
                                                         double *__restrict__ U_xy, uint8_t *__restrict__ U_live,
@@ -688,6 +715,16 @@ struct vohip_frame {
     void *pinned = nullptr;      // host mirror of the counters and doubles
     double *ba_stage = nullptr;  // pinned host copies of S.P, S.X(1:3,:), S.X(4,:) for the bundle adjustment (6 x capL doubles)
     bool ba_mirrored = false;    // ... written by the last kernel of the frame just finished (is_BA)
+    // A stored sequence prepared ahead (vohip_frame_prepare): the images on the device, their pyramids and
+    // corner lists, all made by batched launches; a call recognises a prepared image by the caller's pointer.
+    void *prep_block = nullptr;
+    int prep_n = 0;
+    uint8_t *prep_imgs = nullptr;
+    float *prep_pyr = nullptr, *prep_xy = nullptr, *prep_metric = nullptr;
+    int *prep_counts = nullptr;
+    size_t prep_pyr_floats = 0;
+    std::unordered_map<const void *, int> prep_index;
+    bool next_pyramid_stands = false;   // the following image's pyramid was prepared: no event to wait for
     uint8_t *img[2] = {nullptr, nullptr};   // image staging (host images), by frame parity
     double *L_rc, *L_X, *L_id, *C_rc, *F_rc, *T12;
     double *mv_rc, *Xv, *idv, *kp_uv;
@@ -869,11 +906,21 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
 // table of that parity, and the event the tail waits for -- recorded behind the NEXT filter on this stream --
 // covers it.  `par`: parity of the frame the image belongs to; `ready`: event after which the image is on
 // the device, or NULL.
-int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t ready)
+int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t ready, int prepared = -1)
 {
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
     hipStream_t s = f->side;
+    if (prepared >= 0) {   // detected ahead with the whole sequence: one kernel hands the list over
+        hipLaunchKernelGGL(prepared_rows_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s,
+                           (const float *)(f->prep_xy + 2 * (size_t)f->capK * prepared),
+                           (const float *)(f->prep_metric + (size_t)f->capK * prepared), (const int *)(f->prep_counts + prepared),
+                           f->capK, f->corner_xy[par], f->corner_metric[par], f->cnt + N_DET + par, f->capL + f->capC, f->capU,
+                           f->U_xy[par], f->U_live[par]);
+        VOHIP_HIP(ctx, hipGetLastError());
+        if (f->trace) (void)hipEventRecord(f->tr_det[par], s);
+        return VOHIP_OK;
+    }
     if (ready) VOHIP_HIP(ctx, hipStreamWaitEvent(s, ready, 0));   // (NULL: the image was on the device all along)
     VOHIP_TRY(vohip_detect_corners_enqueue(ctx, s, f->corner_scratch, &f->det_calls, d_img, f->rows, f->cols,
                                            f->colmajor, p.min_quality, p.filter_size, p.border, p.detector,
@@ -980,7 +1027,8 @@ int enqueue_trackers(vohip_frame *f, int par, int slot_from, int slot_to, int nL
         VOHIP_HIP(ctx, hipEventRecord(f->ev_adv[par], ctx->stream));
         stream_swap sw(ctx, f->side);
         VOHIP_HIP(ctx, hipStreamWaitEvent(f->side, start, 0));
-        if (counts_on_device) VOHIP_HIP(ctx, hipStreamWaitEvent(f->side, f->ev_img, 0));   // the following image's pyramid
+        if (counts_on_device && !f->next_pyramid_stands)
+            VOHIP_HIP(ctx, hipStreamWaitEvent(f->side, f->ev_img, 0));   // the following image's pyramid
         VOHIP_TRY(vohip_klt_enqueue_sets(ctx, slot_from, slot_to, sets + 1, 1, p.klt_block, p.klt_max_iter,
                                          p.klt_max_bidir_error));
         VOHIP_HIP(ctx, hipEventRecord(f->ev_advC[par], f->side));
@@ -1020,7 +1068,7 @@ int enqueue_trackers_ahead(vohip_frame *f)
 {
     vohip_ctx *ctx = f->ctx;
     hipStream_t s = ctx->stream;
-    VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_img, 0));   // the following image's pyramid
+    if (!f->next_pyramid_stands) VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_img, 0));   // the following image's pyramid
     // the landmarks this launch tracks are the ones the frame appends, which come from its candidates (the
     // kept ones have their own, earlier launch); candidates grow by the detections that are kept
     const long long nLb = (long long)f->n_C, nCb = (long long)f->n_C + f->capK;
@@ -1255,6 +1303,7 @@ int vohip_frame_destroy(vohip_frame *f)
     if (f->block) (void)hipFree(f->block);
     if (f->pinned) (void)hipHostFree(f->pinned);
     if (f->ba_stage) (void)hipHostFree(f->ba_stage);
+    if (f->prep_block) (void)hipFree(f->prep_block);
     delete f;
     return VOHIP_OK;
 }
@@ -1387,17 +1436,34 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     // read them there (a few KB each; a copy command would cost the host more than the reads cost the GPU)
     std::memcpy(pin_u3(f), u3, sizeof(double) * 3 * (size_t)h);
     if (f->have_map) std::memcpy(pin_u8(f), u8, sizeof(double) * 8 * (size_t)p.fm_trials);
-    const uint8_t *d_img = image_on_device ? image : f->img[par];
-    const uint8_t *d_next = next_image ? (next_on_device ? next_image : f->img[par ^ 1]) : nullptr;
+    // images of a sequence prepared ahead are on the device already, with their pyramids and corner lists
+    const size_t img_bytes = (size_t)f->rows * f->cols;
+    auto prepared_of = [&](const uint8_t *img) {
+        if (!img || f->prep_index.empty()) return -1;
+        const auto it = f->prep_index.find(img);
+        return it == f->prep_index.end() ? -1 : it->second;
+    };
+    const int prep_cur = prepared_of(image), prep_next = prepared_of(next_image);
+    if (prep_cur >= 0) image_on_device = 1;
+    if (prep_next >= 0) next_on_device = 1;
+    const uint8_t *d_img = prep_cur >= 0 ? f->prep_imgs + img_bytes * prep_cur : (image_on_device ? image : f->img[par]);
+    const uint8_t *d_next = next_image ? (prep_next >= 0 ? f->prep_imgs + img_bytes * prep_next
+                                                         : (next_on_device ? next_image : f->img[par ^ 1]))
+                                       : nullptr;
     if (!f->ahead) {
         // nothing was done ahead: this image, its pyramid, the trackers from the previous image
         if (!image_on_device) VOHIP_TRY(enqueue_image_transfer(f, image, f->img[par], s));
         VOHIP_HIP(ctx, hipEventRecord(f->ev_pyr, s));
-        VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
+        if (prep_cur >= 0)
+            VOHIP_TRY(vohip_pyramid_attach(ctx, f->slot_cur, f->prep_pyr + f->prep_pyr_floats * prep_cur, f->rows, f->cols,
+                                           f->colmajor, p.klt_levels));
+        else
+            VOHIP_TRY(vohip_pyramid_build_dev(ctx, f->slot_cur, d_img, f->rows, f->cols, f->colmajor, p.klt_levels));
         VOHIP_HIP(ctx, hipEventRecord(f->ev_feed, s));
         VOHIP_TRY(enqueue_trackers(f, par, f->slot_prev, f->slot_cur, f->n_L, f->have_map ? f->n_C : 0, false, f->ev_feed));
     }   // (else the previous call enqueued all of that, the trackers behind its own last kernel)
-    if (!f->ahead) VOHIP_TRY(enqueue_detection(f, d_img, par, image_on_device ? nullptr : f->ev_pyr));
+    if (!f->ahead)
+        VOHIP_TRY(enqueue_detection(f, d_img, par, image_on_device ? nullptr : f->ev_pyr, f->prep_xy ? prep_cur : -1));
     const int h0 = h < 256 ? h : 256;   // the first triples come out of the selection kernel itself
     static const bool fused_off = std::getenv("VOHIP_FRAME_UNFUSED") != nullptr;   // (A/B measurements)
     if (f->ahead) VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_advA[par], 0));   // the kept landmarks' own tracker
@@ -1412,7 +1478,11 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     VOHIP_TRY(enqueue_localize(f, u3, h, h0, fused));
     if (f->trace) (void)hipEventRecord(f->tr[2], s);   // pose refined
     VOHIP_TRY(enqueue_side_filter(f, u8));
-    if (next_image) {
+    f->next_pyramid_stands = next_image && prep_next >= 0;
+    if (f->next_pyramid_stands) {   // built with the whole sequence: the third slot just shows it
+        VOHIP_TRY(vohip_pyramid_attach(ctx, f->slot_next, f->prep_pyr + f->prep_pyr_floats * prep_next, f->rows, f->cols,
+                                       f->colmajor, p.klt_levels));
+    } else if (next_image) {
         // streams of their own, beside the trackers (which leave most of the GPU idle): the next image,
         // its pyramid (third slot) and its corners, so that the next call starts with its trackers
         stream_swap sw(ctx, f->trk);
@@ -1427,7 +1497,8 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     VOHIP_TRY(enqueue_tail(f));
     if (next_image) VOHIP_TRY(enqueue_trackers_ahead(f));
     // (last: nothing waits for the following image's corners before the next call's final kernels)
-    if (next_image) VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, next_on_device ? nullptr : f->ev_next));
+    if (next_image)
+        VOHIP_TRY(enqueue_detection(f, d_next, par ^ 1, next_on_device ? nullptr : f->ev_next, f->prep_xy ? prep_next : -1));
     f->h_cur = h;
     f->stage = 2;
     f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
@@ -1536,6 +1607,67 @@ int vohip_frame_bundle_adjust(vohip_frame *f, vohip_window *w, const double T_W_
     for (int k = 0; k < *n_poses; ++k)
         if (offsets[k] == 0) return vohip_frame_apply_ba(f, X, (int)n, poses + 16 * (size_t)k);
     return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "the optimised window holds no pose for the current frame");
+}
+
+int vohip_frame_prepare(vohip_frame *f, const uint8_t *const *images, int n, int on_device)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, n >= 0 && n <= 65535 && (n == 0 || images), "bad argument");
+    VOHIP_REQUIRE(ctx, f->stage == 0, "a sequence is prepared between frames");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    VOHIP_HIP(ctx, hipStreamSynchronize(f->side));
+    VOHIP_HIP(ctx, hipStreamSynchronize(f->trk));
+    f->prep_index.clear();
+    if (f->prep_block) (void)hipFree(f->prep_block);
+    f->prep_block = nullptr;
+    f->prep_n = 0;
+    f->prep_xy = nullptr;
+    if (n == 0) return VOHIP_OK;
+    const vohip_frame_params &p = f->prm;
+    const size_t img_bytes = (size_t)f->rows * f->cols;
+    const size_t pyr_floats = vohip_pyramid_floats(f->rows, f->cols, f->colmajor, p.klt_levels);
+    const bool corners = p.detector != 2 && f->capK <= 16384;   // (the FAST variant is detected frame by frame)
+    auto round256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t b_img = round256(img_bytes * n), b_pyr = round256(sizeof(float) * pyr_floats * n),
+                 b_xy = corners ? round256(sizeof(float) * 2 * (size_t)f->capK * n) : 0,
+                 b_metric = corners ? round256(sizeof(float) * (size_t)f->capK * n) : 0,
+                 b_cnt = corners ? round256(sizeof(int) * (size_t)n) : 0;
+    VOHIP_HIP(ctx, hipMalloc(&f->prep_block, b_img + b_pyr + b_xy + b_metric + b_cnt));
+    char *q = (char *)f->prep_block;
+    f->prep_imgs = (uint8_t *)q;
+    q += b_img;
+    f->prep_pyr = (float *)q;
+    q += b_pyr;
+    float *xy = (float *)q;
+    q += b_xy;
+    f->prep_metric = (float *)q;
+    q += b_metric;
+    f->prep_counts = (int *)q;
+    f->prep_pyr_floats = pyr_floats;
+    for (int k = 0; k < n; ++k) {
+        VOHIP_REQUIRE(ctx, images[k], "NULL image");
+        VOHIP_HIP(ctx, hipMemcpyAsync(f->prep_imgs + img_bytes * k, images[k], img_bytes,
+                                      on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    }
+    VOHIP_TRY(vohip_pyramid_batch_dev(ctx, f->prep_imgs, n, f->rows, f->cols, f->colmajor, p.klt_levels, f->prep_pyr));
+    if (corners) {
+        const int chunk = 64;   // (bounds the detector's scratch: records of 64 images at a time)
+        for (int c = 0; c < n; c += chunk) {
+            const int m = n - c < chunk ? n - c : chunk;
+            VOHIP_TRY(vohip_detect_corners_batch_enqueue(ctx, f->prep_imgs + img_bytes * c, m, f->rows, f->cols, f->colmajor,
+                                                         p.min_quality, p.filter_size, p.border, p.detector,
+                                                         xy + 2 * (size_t)f->capK * c, f->prep_metric + (size_t)f->capK * c, f->capK,
+                                                         f->prep_counts + c));
+        }
+    }
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    if (corners) f->prep_xy = xy;
+    f->prep_n = n;
+    for (int k = 0; k < n; ++k) f->prep_index[images[k]] = k;
+    return VOHIP_OK;
 }
 
 }  // extern "C"

@@ -510,12 +510,42 @@ int vohip_pyramid_desc(vohip_ctx *ctx, int slot, pyr_desc &d)
     const vohip_pyramid &p = ctx->pyr[slot];
     VOHIP_REQUIRE(ctx, p.levels > 0, "pyramid slot is empty");
     d.levels = p.levels;
-    const float *base = (const float *)ctx->bufs[B_PYR0 + slot].ptr;
+    const float *base = ctx->pyr_ext[slot] ? ctx->pyr_ext[slot] : (const float *)ctx->bufs[B_PYR0 + slot].ptr;
     for (int l = 0; l < MAX_LEVELS; ++l) {
         d.lvl[l] = l < p.levels ? base + p.offset[l] : nullptr;
         d.A[l] = l < p.levels ? p.A[l] : 0;
         d.B[l] = l < p.levels ? p.B[l] : 0;
     }
+    return VOHIP_OK;
+}
+
+// Level l of a pyramid starts `offset[l]` floats into it (levels back to back, 64-float aligned).
+static size_t pyramid_layout(int rows, int cols, int colmajor, int levels, int *As, int *Bs, size_t *offset)
+{
+    size_t total = 0;
+    int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
+    for (int l = 0; l < levels; ++l) {
+        if (As) As[l] = A;
+        if (Bs) Bs[l] = B;
+        if (offset) offset[l] = total;
+        total += ((size_t)A * B + 63) / 64 * 64;
+        A = (A + 1) / 2;
+        B = (B + 1) / 2;
+    }
+    return total;
+}
+
+int vohip_pyramid_attach(vohip_ctx *ctx, int slot, const float *d_pyr, int rows, int cols, int colmajor, int levels)
+{
+    VOHIP_REQUIRE(ctx, slot >= 0 && slot < VOHIP_PYR_SLOTS, "pyramid slot out of range");
+    VOHIP_REQUIRE(ctx, d_pyr && rows >= 1 && cols >= 1 && levels >= 1 && levels <= MAX_LEVELS, "bad pyramid");
+    vohip_pyramid &p = ctx->pyr[slot];
+    p.rows = rows;
+    p.cols = cols;
+    p.colmajor = colmajor ? 1 : 0;
+    p.levels = levels;
+    pyramid_layout(rows, cols, colmajor, levels, p.A, p.B, p.offset);
+    ctx->pyr_ext[slot] = d_pyr;
     return VOHIP_OK;
 }
 
@@ -544,6 +574,7 @@ int vohip_pyramid_build_dev(vohip_ctx *ctx, int slot, const uint8_t *d_img, int 
         B = (B + 1) / 2;
     }
     VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_PYR0 + slot], total * sizeof(float)));
+    ctx->pyr_ext[slot] = nullptr;
     float *base = (float *)ctx->bufs[B_PYR0 + slot].ptr;
     const int n0 = p.A[0] * p.B[0];
     if (levels == 1)
@@ -566,22 +597,6 @@ int vohip_pyramid_build(vohip_ctx *ctx, int slot, const uint8_t *img, int rows, 
     void *d_img;
     VOHIP_TRY(vohip_upload(ctx, B_IMG_STAGE, img, (size_t)rows * cols, &d_img));
     return vohip_pyramid_build_dev(ctx, slot, (const uint8_t *)d_img, rows, cols, colmajor, levels);
-}
-
-// Level l of a pyramid starts `offset[l]` floats into it (levels back to back, 64-float aligned).
-static size_t pyramid_layout(int rows, int cols, int colmajor, int levels, int *As, int *Bs, size_t *offset)
-{
-    size_t total = 0;
-    int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
-    for (int l = 0; l < levels; ++l) {
-        if (As) As[l] = A;
-        if (Bs) Bs[l] = B;
-        if (offset) offset[l] = total;
-        total += ((size_t)A * B + 63) / 64 * 64;
-        A = (A + 1) / 2;
-        B = (B + 1) / 2;
-    }
-    return total;
 }
 
 size_t vohip_pyramid_floats(int rows, int cols, int colmajor, int levels)

@@ -58,6 +58,7 @@ struct vohip_ctx {
     char err[512] = {0};
     vohip_buf bufs[VOHIP_NBUF];
     vohip_pyramid pyr[VOHIP_PYR_SLOTS];
+    const float *pyr_ext[VOHIP_PYR_SLOTS] = {nullptr};   // a slot that shows a pyramid in the caller's memory (vohip_pyramid_attach)
     int ransac_h = 0;  // hypotheses held by B_RANSAC_RT / B_RANSAC_M
     int opt_ransac_variant = -1;  // scoring-kernel geometry, see vohip_set_option
     int opt_klt_stats = 0;        // count tracker work (two atomics per track), see vohip_klt_stats
@@ -172,6 +173,8 @@ size_t vohip_corner_scratch_bytes(int rows, int cols);
 int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, unsigned *calls, const uint8_t *d_img,
                                  int rows, int cols, int colmajor, double min_quality, int filter_size, int border,
                                  int method, double min_contrast, float *d_xy, float *d_metric, int cap, int *d_count);
+// Slot `slot` shows the pyramid at d_pyr (layout of vohip_pyramid_batch_dev) until the slot is built again; nothing is copied.
+int vohip_pyramid_attach(vohip_ctx *ctx, int slot, const float *d_pyr, int rows, int cols, int colmajor, int levels);
 int vohip_detect_corners_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
                                        double min_quality, int filter_size, int border, int method, float *d_xy,
                                        float *d_metric, int cap, int *d_counts);

@@ -132,14 +132,17 @@ def load_results(path):
 
 
 def run_sequence(images, K, hyper_paras, ground_truth=None, bootstrap_frames=(0, 2), dataset="synthetic",
-                 save_dir=None, rng=None, ctx=None, window_size=3, keyframe_d=2, now=None, device_loop=True):
+                 save_dir=None, rng=None, ctx=None, window_size=3, keyframe_d=2, now=None, device_loop=True,
+                 prepare=True):
     """One full run as main_demo.m:249-476 does it: bootstrap on images[b1..b2], continuous
     operation on the remaining images, timing, evaluation against ground_truth (N-by-2 (x, z) table,
     optional) and, when save_dir is given, the '<experiment>_res.mat' file.
     Returns a dict with the saved variables plus 'S' (the final state) and 'path'.
     device_loop: the loop with its state resident on the GPU (one library call per frame, the following
     image of the stored sequence handed over ahead); False: the stage-by-stage loop, one call per
-    reference function."""
+    reference function.
+    prepare (device loop): the images of the loop go to the GPU in one go, with all their pyramids and corner
+    lists from batched launches (VOPipelineDevice.prepare); the results do not depend on it."""
     from .bootstrap import bootstrap
     from .frame_pipeline import VOPipelineDevice
     from .pipeline import VOPipeline
@@ -163,6 +166,8 @@ def run_sequence(images, K, hyper_paras, ground_truth=None, bootstrap_frames=(0,
         pipe = VOPipeline(K, img_seqs[-1], p_W_landmarks, keypoints, T_init_WC, hyper_paras=hyper_paras,
                           window_size=window_size, keyframe_d=keyframe_d, rng=rng, ctx=ctx)
     try:   # (a run that fails gives its pyramid slots and device state back all the same)
+        if device_loop and prepare and len(frame_range) > 0:
+            pipe.prepare([images[i] for i in frame_range])
         for i in frame_range:
             if device_loop:
                 pipe.process_frame(images[i], next_image=images[i + 1] if i + 1 < len(images) else None)

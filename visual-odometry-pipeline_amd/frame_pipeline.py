@@ -122,6 +122,24 @@ class VOPipelineDevice:
             img = np.asfortranarray(img) if self._colmajor else np.ascontiguousarray(img)
         return C.c_void_p(img.ctypes.data), 0, img
 
+    def prepare(self, images):
+        """For a stored sequence: all of its images go to the GPU once, and their pyramids and corner lists are
+        made by batched launches (vohip_frame_prepare).  Frames later passed to process_frame / begin_frame as
+        the same objects then cost no transfer, no pyramid and no detection of their own; results do not change.
+        Pass an empty list to release the prepared data."""
+        ptrs, keep, on_dev = [], [], None
+        for im in images:
+            ptr, dev, k = self._image_ptr(im)
+            if on_dev is None:
+                on_dev = dev
+            if dev != on_dev:
+                raise ValueError("host and device images cannot be mixed in one prepared sequence")
+            ptrs.append(ptr.value)
+            keep.append(k)
+        arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
+        self.ctx.check(_lib.load().vohip_frame_prepare(self._h, arr, len(ptrs), int(on_dev or 0)))
+        self._prepared = keep   # (the pointers are the library's keys: the arrays must stay alive and in place)
+
     def process_frame(self, image, next_image=None):
         """One frame of the loop (main_demo.m:377-427).  next_image: the frame after this one, when the
         caller already holds it (a stored sequence): its transfer, pyramid and corner detection then run
