@@ -20,7 +20,8 @@
 //                        pose step.
 //   ba_update_kernel     one thread per landmark: back-substitution, trial state, cost of the
 //                        trial state over the landmark's observations -> partial costs.
-//   ba_decide_kernel     one workgroup: accept / reject, lambda update, stopping tests, commit.
+//   (ba_decide)          the workgroup of ba_update_kernel that finishes last: accept / reject, lambda update,
+//                        stopping tests, commit.
 // At the reference's sizes (F = 5 poses, 10^2..10^3 landmarks) the reduced camera system is 30x30:
 // far too small for a matrix-core contraction, so everything is fp64 VALU.
 //
@@ -532,22 +533,83 @@ void launch_ba_solve(hipStream_t s, int F, int nblocks, const double *S_part, co
     static_assert(FMAX == 8, "one case per window size");
 }
 
-// Back-substitution, trial state and its cost.  One thread per landmark.
+// The decision of a trial, by ONE thread (the last workgroup of ba_update_kernel to finish, or its first one
+// when the solve failed).  An accepted step is not copied anywhere: the two state buffers change roles.
+// `mirror`: the host's pinned copy of the status (the host follows the run by polling it instead of
+// synchronising: the count of decided trials is stored last, with system scope).
+__device__ void ba_decide(int nblocks, const double *partial, ba_status *st, int *fail_flag, int max_iter, double ftol,
+                          double xtol, ba_status *mirror)
+{
+    int accept = 0;
+    st->trials++;
+    bool finished = false;
+    if (st->solve_failed) {
+        st->lambda *= 10.0;
+        if (++st->rejects > 10) finished = true;
+    } else {
+        double c = 0.0, dn = 0.0, xn = 0.0;
+        for (int b = 0; b < nblocks; ++b) {
+            c += partial[3 * b];
+            dn += partial[3 * b + 1];
+            xn += partial[3 * b + 2];
+        }
+        st->cost_trial = c;
+        st->step_norm2 = dn;
+        st->x_norm2 = xn;
+        if (c < st->cost) {
+            const double dec = st->cost - c, cost_old = st->cost;
+            accept = 1;
+            st->cost = c;
+            st->lambda = st->lambda * 0.1 > 1e-12 ? st->lambda * 0.1 : 1e-12;
+            st->iter++;
+            st->rejects = 0;
+            if (dec < ftol * (1.0 + cost_old)) finished = true;
+            if (sqrt(dn) < xtol * (1.0 + sqrt(xn))) finished = true;
+            if (st->iter >= max_iter) finished = true;
+        } else {
+            st->lambda *= 10.0;
+            if (++st->rejects > 10) finished = true;
+        }
+    }
+    st->accepted_last = accept;
+    if (accept) st->cur ^= 1;
+    st->done = finished ? 1 : 0;
+    *fail_flag = 0;
+    if (mirror) {
+        ba_status c = *st;
+        const int decided = c.trials;
+        c.trials = decided - 1;   // (what the host saw last)
+        *mirror = c;
+        __threadfence_system();
+        __hip_atomic_store(&mirror->trials, decided, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Back-substitution, trial state and its cost, one thread per landmark; then the decision of the trial by the
+// workgroup that finishes last (every workgroup publishes its three partial sums, then takes a ticket; the
+// sums are added in workgroup order, so the result does not depend on which workgroup that is).
+// The status is read at the top by every workgroup and rewritten only after the last ticket is taken.
 __global__ __launch_bounds__(256) void ba_update_kernel(ba_problem P, double *__restrict__ X0, double *__restrict__ X1,
                                                         const double *__restrict__ dp,
                                                         const double *__restrict__ E_in,
                                                         const double *__restrict__ gl_in,
-                                                        const double *__restrict__ W_in,
-                                                        const ba_status *__restrict__ st,
-                                                        double *__restrict__ partial /* 3 per block */)
+                                                        const double *__restrict__ W_in, ba_status *st,
+                                                        double *partial /* 3 per block */, unsigned *tickets,
+                                                        int *fail_flag, int max_iter, double ftol, double xtol,
+                                                        ba_status *mirror)
 {
     __shared__ frame_lin sF[FMAX];
     __shared__ double sdp[6 * FMAX];
     __shared__ double sRed[3][256];
     const int F = P.F, np = 6 * F, tid = threadIdx.x;
-    if (st->done || st->solve_failed) return;
-    const double *__restrict__ state = st->cur ? X1 : X0;   // the trial state goes to the other buffer
-    double *__restrict__ trial = st->cur ? X0 : X1;
+    const int done = st->done, solve_failed = st->solve_failed, cur_buf = st->cur;
+    if (done) return;
+    if (solve_failed) {   // no trial state: the rejection is decided at once
+        if (blockIdx.x == 0 && tid == 0) ba_decide(0, partial, st, fail_flag, max_iter, ftol, xtol, mirror);
+        return;
+    }
+    const double *__restrict__ state = cur_buf ? X1 : X0;   // the trial state goes to the other buffer
+    double *__restrict__ trial = cur_buf ? X0 : X1;
     if (tid < np) sdp[tid] = dp[tid];
     __syncthreads();
     if (tid < F) {
@@ -604,61 +666,13 @@ __global__ __launch_bounds__(256) void ba_update_kernel(ba_problem P, double *__
             for (int q = 0; q < 3; ++q) sRed[q][tid] += sRed[q][tid + s];
         __syncthreads();
     }
-    if (tid == 0)
+    if (tid == 0) {
         for (int q = 0; q < 3; ++q) partial[3 * blockIdx.x + q] = sRed[q][0];
-}
-
-// One thread.  An accepted step is not copied anywhere: the two state buffers change roles.
-// `mirror`: the host's pinned copy of the status (the host follows the run by polling it instead of
-// synchronising: the count of decided trials is stored last, with system scope).
-__global__ __launch_bounds__(64) void ba_decide_kernel(int nblocks, const double *__restrict__ partial,
-                                                       ba_status *__restrict__ st, int *__restrict__ fail_flag,
-                                                       int max_iter, double ftol, double xtol, ba_status *mirror)
-{
-    if (threadIdx.x != 0 || st->done) return;
-    int accept = 0;
-    {
-        st->trials++;
-        bool finished = false;
-        if (st->solve_failed) {
-            st->lambda *= 10.0;
-            if (++st->rejects > 10) finished = true;
-        } else {
-            double c = 0.0, dn = 0.0, xn = 0.0;
-            for (int b = 0; b < nblocks; ++b) {
-                c += partial[3 * b];
-                dn += partial[3 * b + 1];
-                xn += partial[3 * b + 2];
-            }
-            st->cost_trial = c;
-            st->step_norm2 = dn;
-            st->x_norm2 = xn;
-            if (c < st->cost) {
-                const double dec = st->cost - c, cost_old = st->cost;
-                accept = 1;
-                st->cost = c;
-                st->lambda = st->lambda * 0.1 > 1e-12 ? st->lambda * 0.1 : 1e-12;
-                st->iter++;
-                st->rejects = 0;
-                if (dec < ftol * (1.0 + cost_old)) finished = true;
-                if (sqrt(dn) < xtol * (1.0 + sqrt(xn))) finished = true;
-                if (st->iter >= max_iter) finished = true;
-            } else {
-                st->lambda *= 10.0;
-                if (++st->rejects > 10) finished = true;
-            }
-        }
-        st->accepted_last = accept;
-        if (accept) st->cur ^= 1;
-        st->done = finished ? 1 : 0;
-        *fail_flag = 0;
-        if (mirror) {
-            ba_status c = *st;
-            const int decided = c.trials;
-            c.trials = decided - 1;   // (what the host saw last)
-            *mirror = c;
-            __threadfence_system();
-            __hip_atomic_store(&mirror->trials, decided, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence();   // the sums are visible to the whole GPU before the ticket is
+        if (atomicAdd(tickets, 1u) == gridDim.x - 1) {
+            __threadfence();
+            *tickets = 0u;
+            ba_decide((int)gridDim.x, partial, st, fail_flag, max_iter, ftol, xtol, mirror);
         }
     }
 }
@@ -1046,9 +1060,8 @@ int vohip_ba_run(vohip_ctx *ctx, double *state, int state_len, const double *obs
         }
         hipLaunchKernelGGL(ba_update_kernel, dim3(nb_upd), dim3(256), 0, s, P, (double *)d_state, (double *)d_trial,
                            (const double *)d_dp, (const double *)d_E, (const double *)d_gl, (const double *)d_W,
-                           (const ba_status *)d_st, (double *)d_part);
-        hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, s, nb_upd, (const double *)d_part, (ba_status *)d_st,
-                           (int *)d_fail, max_iter, ftol, xtol, (ba_status *)h_st);
+                           (ba_status *)d_st, (double *)d_part, (unsigned *)((char *)d_st + 384), (int *)d_fail, max_iter,
+                           ftol, xtol, (ba_status *)h_st);
         VOHIP_HIP(ctx, hipGetLastError());
     }
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
