@@ -10,8 +10,10 @@
 //   every edge; sub-pixel offset per axis from the parabola through 3 responses (+-0.5 max).
 // Kernels (the response map never goes to memory):
 //   corner_tile_kernel   one fused tile kernel: uint8 tile + 4 px halo (1 gradient + 2 Gaussian + 1
-//                        non-maximum suppression) -> LDS, gradient products, separable Gaussian and the
-//                        response of the tile and a 1 px ring around it all in LDS; every strict 3x3
+//                        non-maximum suppression) -> LDS (all loads of a thread in flight together), the
+//                        row pass of the Gaussian over gradient products made on the way, the column pass
+//                        and the response of the tile and a 1 px ring around it (two outputs per thread,
+//                        packed fp32), 24 KB of LDS per workgroup; every strict 3x3
 //                        maximum of the tile inside the border margin becomes a 16-byte record (pixel
 //                        index, response, sub-pixel position) in the tile's own list, in pixel order
 //                        (ballot compaction, no atomics); tile maximum -> one atomicMax per workgroup.
@@ -42,6 +44,8 @@ constexpr int RA = TA + 2, RB = TB + 2;                        // response tile:
 constexpr int PA = RA + 2 * HALF, PB = RB + 2 * HALF;          // gradient-product tile
 constexpr int IA = PA + 2, IB = PB + 2;                        // staged image tile
 constexpr int TILE_CAP = TA * TB / 4;                          // strict 3x3 maxima cannot touch: at most one per 2x2
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct taps5 {
     float w[FS];
@@ -78,7 +82,9 @@ __device__ __forceinline__ void tile_maxima(const float *sR, float best, unsigne
     for (int m = 32; m >= 1; m >>= 1) kb = max(kb, (unsigned)__shfl_xor((int)kb, m, 64));
     if (lane == 0) atomicMax(sMaxp, kb);
     __syncthreads();
-    if (tid == 0) atomicMax(max_now, *sMaxp);
+    // (a maximum only grows: a tile whose own maximum does not exceed the value it reads has nothing to add, and
+    // most tiles do not -- the atomics of the tiles of an image all go to one address and would queue there)
+    if (tid == 0 && *sMaxp > __hip_atomic_load(max_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_now, *sMaxp);
     // strict 3x3 maxima of the tile, in pixel order: pixel q = 256 k + tid of the tile is (row q / 64,
     // column q % 64), so wavefront `wave` of round k holds one tile row and the order is (k, wave, lane)
     bool is_max[4];
@@ -153,10 +159,12 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restr
     tile_count += blockIdx.y * (size_t)bt.tiles;
     max_now += blockIdx.y * (size_t)bt.max_slots;
     max_next += blockIdx.y * (size_t)bt.max_slots;
-    __shared__ float sI[IA * IB];
-    __shared__ float sP[3][PA * PB];
-    __shared__ float sH[3][RA * PB];
-    __shared__ float sR[RA * RB];
+    // the staged image is dead when the responses are written: the two share their memory (24 KB of LDS per
+    // workgroup in all, six workgroups per compute unit)
+    constexpr int N_IR = IA * IB > RA * RB ? IA * IB : RA * RB;
+    __shared__ __align__(8) float sIR[N_IR];
+    __shared__ __align__(8) float sH[3][RA * PB];
+    float *const sI = sIR, *const sR = sIR;
     __shared__ unsigned sMax;
     __shared__ int sCnt[16];
     const int tid = threadIdx.x;
@@ -172,60 +180,86 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restr
         if (tile == 0) *max_next = 0u;
     }
     const float s255 = 1.0f / 255.0f;
-    for (int q = tid; q < IA * IB; q += 256) {
+    // every load of the thread is issued before the first one is waited for (one round trip to memory for the
+    // tile instead of one per round)
+    constexpr int ROUNDS = (IA * IB + 255) / 256;
+    uint8_t px[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int q = min(tid + 256 * k, IA * IB - 1);
         const int rb = q / IA, ra = q - rb * IA;
         const int a = min(max(a0 - HALF - 2 + ra, 0), A - 1);
         const int b = min(max(b0 - HALF - 2 + rb, 0), B - 1);
-        sI[q] = (float)img[(size_t)b * A + a] * s255;
+        px[k] = img[(size_t)b * A + a];
+    }
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int q = tid + 256 * k;
+        if (q < IA * IB) sI[q] = (float)px[k] * s255;
     }
     __syncthreads();
-    for (int q = tid; q < PA * PB; q += 256) {
-        const int rb = q / PA, ra = q - rb * PA;
-        const float *c = sI + (rb + 1) * IA + (ra + 1);
-        const float gx = c[1] - c[-1];
-        const float gy = c[IA] - c[-IA];
-        sP[0][q] = gx * gx;
-        sP[1][q] = gy * gy;
-        sP[2][q] = gx * gy;
-    }
-    __syncthreads();
-    for (int q = tid; q < RA * PB; q += 256) {
-        const int rb = q / RA, ra = q - rb * RA;
+    // Row pass of the 5-tap filter over the three gradient products, which are made on the way from the staged
+    // image (central differences; no pass and no memory of their own).  Both filter passes make two outputs
+    // per thread with packed fp32 instructions (two IEEE products or sums per instruction, every output's own
+    // operations in the same order as one at a time): the row pass for a vertical pair of rows, the column pass
+    // for a horizontal pair of columns.
+    static_assert(PB % 2 == 0 && RA % 2 == 0, "pairs of rows / columns");
+    for (int q = tid; q < RA * (PB / 2); q += 256) {
+        const int k = q / RA, ra = q - k * RA;
+        // product (rb, ra + i) is centred on staged pixel (rb + 1, ra + i + 1); rows rb = 2k and 2k + 1
+        const float *rowM = sI + (2 * k) * IA + ra, *row0 = rowM + IA, *row1 = row0 + IA, *rowP = row1 + IA;
+        float c0[FS + 2], c1[FS + 2];
+#pragma unroll
+        for (int i = 0; i < FS + 2; ++i) {
+            c0[i] = row0[i];
+            c1[i] = row1[i];
+        }
+        v2f s[3];
+#pragma unroll
+        for (int i = 0; i < FS; ++i) {
+            const v2f gx = (v2f){c0[i + 2], c1[i + 2]} - (v2f){c0[i], c1[i]};
+            const v2f gy = (v2f){c1[i + 1], rowP[i + 1]} - (v2f){rowM[i + 1], c0[i + 1]};
+            const v2f pr[3] = {gx * gx, gy * gy, gx * gy};
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) s[ch] = i == 0 ? G.w[0] * pr[ch] : s[ch] + G.w[i] * pr[ch];
+        }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const float *p = sP[ch] + rb * PA + ra;
-            float s = G.w[0] * p[0];
-#pragma unroll
-            for (int i = 1; i < FS; ++i) s = s + G.w[i] * p[i];
-            sH[ch][q] = s;
+            sH[ch][(2 * k) * RA + ra] = s[ch].x;
+            sH[ch][(2 * k + 1) * RA + ra] = s[ch].y;
         }
     }
     __syncthreads();
     float best = -INFINITY;
-    for (int q = tid; q < RA * RB; q += 256) {
-        const int rb = q / RA, ra = q - rb * RA;
-        float v[3];
+    for (int q = tid; q < (RA / 2) * RB; q += 256) {
+        const int rb = q / (RA / 2), ra = 2 * (q - rb * (RA / 2));
+        v2f v[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const float *p = sH[ch] + rb * RA + ra;
-            float s = G.w[0] * p[0];
+            const v2f *p = reinterpret_cast<const v2f *>(sH[ch] + rb * RA + ra);
+            v2f s = G.w[0] * p[0];
 #pragma unroll
-            for (int i = 1; i < FS; ++i) s = s + G.w[i] * p[i * RA];
+            for (int i = 1; i < FS; ++i) s = s + G.w[i] * p[i * (RA / 2)];
             v[ch] = s;
         }
-        float r;
+        v2f r;
         if (method == 0) {
-            const float det = v[0] * v[1] - v[2] * v[2];
-            const float tr = v[0] + v[1];
+            const v2f det = v[0] * v[1] - v[2] * v[2];
+            const v2f tr = v[0] + v[1];
             r = det - 0.04f * (tr * tr);
         } else {
-            const float d = v[0] - v[1];
-            r = ((v[0] + v[1]) - sqrtf(d * d + 4.0f * (v[2] * v[2]))) * 0.5f;
+            const v2f d = v[0] - v[1];
+            const v2f e = d * d + 4.0f * (v[2] * v[2]);
+            r = ((v[0] + v[1]) - (v2f){sqrtf(e.x), sqrtf(e.y)}) * 0.5f;
         }
-        sR[q] = r;
+        *reinterpret_cast<v2f *>(sR + rb * RA + ra) = r;
         // the image maximum is taken over the pixels of the tile itself (every pixel belongs to one tile)
-        const int a = a0 - 1 + ra, b = b0 - 1 + rb;
-        if (ra >= 1 && ra <= TA && rb >= 1 && rb <= TB && a < A && b < B) best = fmaxf(best, r);
+        const int b = b0 - 1 + rb;
+        if (rb >= 1 && rb <= TB && b < B) {
+            const int a = a0 - 1 + ra;
+            if (ra >= 1 && ra <= TA && a < A) best = fmaxf(best, r.x);
+            if (ra + 1 <= TA && a + 1 < A) best = fmaxf(best, r.y);
+        }
     }
     tile_maxima<true>(sR, best, &sMax, sCnt, A, B, a0, b0, lo, tile, recs, tile_count, max_now);
 }
@@ -253,11 +287,21 @@ __global__ __launch_bounds__(256) void fast_tile_kernel(const uint8_t *__restric
         sMax = 0u;
         if (tile == 0) *max_next = 0u;
     }
-    for (int q = tid; q < FA * FB; q += 256) {
+    // (every load of the thread issued before the first one is waited for)
+    constexpr int ROUNDS = (FA * FB + 255) / 256;
+    uint8_t px[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int q = min(tid + 256 * k, FA * FB - 1);
         const int rb = q / FA, ra = q - rb * FA;
         const int a = min(max(a0 - 4 + ra, 0), A - 1);
         const int b = min(max(b0 - 4 + rb, 0), B - 1);
-        sI[q] = (int)img[(size_t)b * A + a];
+        px[k] = img[(size_t)b * A + a];
+    }
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int q = tid + 256 * k;
+        if (q < FA * FB) sI[q] = (int)px[k];
     }
     __syncthreads();
     // circle of radius 3, clockwise from the top: offsets (da, db)
