@@ -91,6 +91,7 @@ __global__ __launch_bounds__(128) void triangulate_refine_kernel(const double *_
 constexpr int FILT_THREADS = 1024;
 constexpr int FILT_DET = 16;      // detections per workgroup (one per wavefront)
 constexpr int FILT_CHUNK = 4096;  // existing points staged at a time (32 KB)
+static_assert(FILT_CHUNK % FILT_THREADS == 0, "whole rounds of the workgroup per chunk");
 
 __global__ __launch_bounds__(FILT_THREADS) void candidate_filter_kernel(const float *__restrict__ new_xy, int ld, int n_new,
                                                                         const double *__restrict__ C_rc, int nC,
@@ -130,10 +131,21 @@ __global__ __launch_bounds__(FILT_THREADS) void candidate_filter_kernel(const fl
     for (int base = 0; base < total; base += FILT_CHUNK) {
         const int cnt = min(FILT_CHUNK, total - base);
         __syncthreads();
-        for (int k = tid; k < cnt; k += FILT_THREADS) {
-            const int g = base + k;
+        // (a chunk is FILT_CHUNK / FILT_THREADS points per thread: all their loads are issued before the first
+        // one is waited for)
+        constexpr int PER_THREAD = FILT_CHUNK / FILT_THREADS;
+        double pr[PER_THREAD], pc[PER_THREAD];
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            const int g = base + min(tid + FILT_THREADS * u, cnt - 1);
             const double *src = g < nC ? C_rc + 2 * (size_t)g : P_rc + 2 * (size_t)(g - nC);
-            sP[k] = make_float2((float)src[1], (float)src[0]);
+            pr[u] = src[0];
+            pc[u] = src[1];
+        }
+#pragma unroll
+        for (int u = 0; u < PER_THREAD; ++u) {
+            const int k = tid + FILT_THREADS * u;
+            if (k < cnt) sP[k] = make_float2((float)pc[u], (float)pr[u]);
         }
         __syncthreads();
 #pragma unroll
@@ -175,14 +187,16 @@ __global__ __launch_bounds__(128) void candidate_triangulate_kernel(const double
 {
     // four lanes per candidate (the triangulation is shared by the quad; the rest is cheap and repeated)
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    if (n_dev) n = *n_dev;  // count and pose kept on the device (the frame pipeline)
-    if (i >= n) return;
+    if (i >= n) return;   // (n: the rows the arrays hold)
+    // the candidate's row is fetched together with the count kept on the device (the frame pipeline), not
+    // after it: one round trip to memory instead of two
     if (T_dev)
         for (int q = 0; q < 16; ++q) prm.T_W_C[q] = T_dev[q];
     double Tf[12];
     for (int k = 0; k < 12; ++k) Tf[k] = T_first[12 * (size_t)i + k];
     const double cur[2] = {cur_rc[2 * (size_t)i], cur_rc[2 * (size_t)i + 1]};
     const double fst[2] = {first_rc[2 * (size_t)i], first_rc[2 * (size_t)i + 1]};
+    if (n_dev && i >= *n_dev) return;
     double X[3], ang;
     const int st = candidate_point<true>(cur, fst, Tf, prm.T_W_C, prm.K, prm.angle_threshold_deg, prm.min_depth,
                                          prm.max_depth, prm.is_BA, X, ang);
