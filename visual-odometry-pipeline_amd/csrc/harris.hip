@@ -105,35 +105,46 @@ __device__ __forceinline__ void tile_maxima(const float *sR, float best, unsigne
         if (lane == 0) sCnt[4 * k + wave] = __popcll(bal[k]);
     }
     __syncthreads();
-    corner_rec *out = recs + (size_t)tile * TILE_CAP;
-    int total = 0;
+    // Exclusive prefix of the 16 (round, wavefront) counts, by every wavefront for itself; the maxima's tile
+    // pixels then go to a list in pixel order and ONE thread per maximum makes its record: the sub-pixel
+    // arithmetic runs once per maximum, not once per wavefront and round that holds a maximum.
+    static_assert(TILE_CAP <= 256 && TA == 64 && TB == 16, "one thread per record; 4 rounds of 4 tile rows");
+    __shared__ unsigned short sList[TILE_CAP];
+    const int mine = lane < 16 ? sCnt[lane] : 0;
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    const int exc = inc - mine;
+    const int total = __shfl(inc, 15, 64);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        int before = 0;
-        for (int w = 0; w < 4 * k + wave; ++w) before += sCnt[w];
-        if (is_max[k]) {
-            const int rb = 4 * k + wave, ra = lane;
-            const int a = a0 + ra, b = b0 + rb;
-            const float *cc = sR + (rb + 1) * RA + (ra + 1);
-            const float r = cc[0];
-            const float da = cc[1] - cc[-1], dda = (cc[1] - 2.0f * r) + cc[-1];
-            const float db = cc[RA] - cc[-RA], ddb = (cc[RA] - 2.0f * r) + cc[-RA];
-            float oa = dda < 0.0f ? -0.5f * da / dda : 0.0f;
-            float ob = ddb < 0.0f ? -0.5f * db / ddb : 0.0f;
-            oa = SUBPIXEL ? fminf(fmaxf(oa, -0.5f), 0.5f) : 0.0f;
-            ob = SUBPIXEL ? fminf(fmaxf(ob, -0.5f), 0.5f) : 0.0f;
-            corner_rec rec;
-            rec.key = b * A + a;
-            rec.r = r;
-            rec.pa = (float)a + oa;
-            rec.pb = (float)b + ob;
-            out[before + __popcll(bal[k] & ((1ull << lane) - 1ull))] = rec;
-        }
+        const int before = __shfl(exc, 4 * k + wave, 64);
+        if (is_max[k])
+            sList[before + __popcll(bal[k] & ((1ull << lane) - 1ull))] = (unsigned short)((4 * k + wave) * 64 + lane);
     }
-    if (tid == 0) {
-        for (int w = 0; w < 16; ++w) total += sCnt[w];
-        tile_count[tile] = total;
+    __syncthreads();
+    if (tid < total) {
+        const int q = sList[tid], rb = q >> 6, ra = q & 63;
+        const int a = a0 + ra, b = b0 + rb;
+        const float *cc = sR + (rb + 1) * RA + (ra + 1);
+        const float r = cc[0];
+        const float da = cc[1] - cc[-1], dda = (cc[1] - 2.0f * r) + cc[-1];
+        const float db = cc[RA] - cc[-RA], ddb = (cc[RA] - 2.0f * r) + cc[-RA];
+        float oa = dda < 0.0f ? -0.5f * da / dda : 0.0f;
+        float ob = ddb < 0.0f ? -0.5f * db / ddb : 0.0f;
+        oa = SUBPIXEL ? fminf(fmaxf(oa, -0.5f), 0.5f) : 0.0f;
+        ob = SUBPIXEL ? fminf(fmaxf(ob, -0.5f), 0.5f) : 0.0f;
+        corner_rec rec;
+        rec.key = b * A + a;
+        rec.r = r;
+        rec.pa = (float)a + oa;
+        rec.pb = (float)b + ob;
+        recs[(size_t)tile * TILE_CAP + tid] = rec;
     }
+    if (tid == 0) tile_count[tile] = total;
 }
 
 // Strides of image blockIdx.y of a batch (all zero for a single image): every image has its own records,
