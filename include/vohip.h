@@ -43,8 +43,10 @@ typedef enum vohip_status {
                                        sample triples; outputs hold the best model so far */
     VOHIP_TOO_FEW_POINTS = 5,
     VOHIP_ERR_NO_DEVICE = 6,
-    VOHIP_CAPACITY_EXCEEDED = 7     /* an output list was longer than the caller's capacity; the
+    VOHIP_CAPACITY_EXCEEDED = 7,    /* an output list was longer than the caller's capacity; the
                                        first `cap` entries are valid but their choice is arbitrary */
+    VOHIP_SEQUENCE_IDLE = 8         /* vohip_group_finish: this sequence of the group took no part in the frame
+                                       (not reset, ended earlier, or stopped by an error of its own) */
 } vohip_status;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -257,6 +259,9 @@ int vohip_frame_reset(vohip_frame *f, const uint8_t *image, int image_on_device,
                       const double *P_rc, int n, const double T_W_C[16]);
 /* One frame: u3 = 3 x h uniforms for the P3P hypotheses, u8 = 8 x fm_trials uniforms for the
  * fundamental-matrix trials (may be NULL while there are no candidates yet).  One synchronisation.
+ * An image passed as device memory must be complete when the call is made: the corner detection reads it
+ * on a stream of the loop's own, which does not wait for work the caller still has in flight on the
+ * context's stream.
  * VOHIP_SAMPLES_EXHAUSTED: the adaptive rule wants more than h hypotheses (pose->num_iterations tells
  * how many); call vohip_frame_retry with a longer u3 whose first h triples are the ones already
  * passed.  VOHIP_NO_MODEL: no hypothesis reached 30 inliers (the reference stops there too).
@@ -303,6 +308,49 @@ int vohip_frame_prepare(vohip_frame *f, const uint8_t *const *images, int n, int
 int vohip_frame_sizes(vohip_frame *f, int *n_landmarks, int *n_candidates);
 /* Copies of S.P (2xn), S.X(1:3,:) (3xn), S.X(4,:), S.C, S.F (2xm), S.T (12xm); any pointer may be NULL. */
 int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc, double *T12);
+
+/* ---- a group of loops advanced in lockstep -------------------------------------------------------
+ * main_eval.m:22-23 runs independent sequences (feature variant x repetition, each the loop body
+ * main_demo.m:377-424 over its own images with its own random draws) one after the other.  A group holds
+ * n_sequences such loops of one image shape, camera matrix and parameter set, and advances all of them by
+ * one frame per call: every kernel of the frame is launched once, with the sequence as a grid dimension, so
+ * the launches, their latencies and the host's enqueue work are shared by the sequences and the tracker
+ * launch fills the GPU.  Each sequence's state, counts, ids and poses are those of its own vohip_frame_*
+ * loop, bit for bit (a sequence reads nothing of another).
+ *
+ * The sequences are stored ones: vohip_group_prepare copies sequence `seq`'s n images (n <= max_frames;
+ * image 0 is the one the loop is reset on, main_demo.m:342-344, images 1.. are the loop's frames) to the
+ * device and makes all their pyramids and corner lists by batched launches, as vohip_frame_prepare does
+ * (detector < 0: the group's detector and thresholds; else 0 Harris / 1 MinEigen with min_quality: the
+ * feature variants of main_eval.m:165-174 may share a group, the loop only reads the corner lists).
+ * vohip_group_reset gives sequence `seq` its initial state (as vohip_frame_reset; the image is prepared
+ * image 0).  The first reset after a frame was processed starts a new run of the group: sequences that
+ * are not reset again stay idle in it.
+ *
+ * vohip_group_begin enqueues frame k = 1, 2, ... for every sequence that was reset, has not failed and holds
+ * an image k; u3 = n_sequences x (3 x h) uniforms, u8 = n_sequences x (8 x fm_trials) (blocks of idle
+ * sequences are not read).  vohip_group_finish waits for the frame and fills poses[n_sequences],
+ * counts[n_sequences] and status[n_sequences] (the status vohip_frame_step would return for that sequence, or
+ * VOHIP_SEQUENCE_IDLE; the call's own return value only reports failures of the runtime).  A sequence whose
+ * status is VOHIP_SAMPLES_EXHAUSTED must be answered with vohip_group_retry (more hypotheses for that
+ * sequence alone, as vohip_frame_retry) before the next vohip_group_begin; one that failed otherwise stays
+ * idle for the rest of the run.  No bundle adjustment in a group (is_BA must be 0).
+ * Memory: max_frames x (pyramid + image + corner lists, about 3.2 MB at 1241 x 376) per sequence. */
+typedef struct vohip_group vohip_group;
+int vohip_group_create(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor,
+                       const vohip_frame_params *params, int n_sequences, int max_frames, vohip_group **out);
+int vohip_group_destroy(vohip_group *g);
+int vohip_group_prepare(vohip_group *g, int seq, const uint8_t *const *images, int n, int on_device, int detector,
+                        double min_quality, double min_contrast);
+int vohip_group_reset(vohip_group *g, int seq, const double *X, const double *ids, const double *P_rc, int n,
+                      const double T_W_C[16]);
+int vohip_group_begin(vohip_group *g, const double *u3, int h, const double *u8);
+int vohip_group_finish(vohip_group *g, vohip_frame_pose *poses, vohip_frame_counts *counts, int *status);
+int vohip_group_retry(vohip_group *g, int seq, const double *u3, int h, vohip_frame_pose *pose,
+                      vohip_frame_counts *counts);
+int vohip_group_sizes(vohip_group *g, int seq, int *n_landmarks, int *n_candidates, int *frames_done);
+int vohip_group_state(vohip_group *g, int seq, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc,
+                      double *T12);
 
 /* The device-side half of VO_bundle_adjust.m:53-70 for a loop whose state lives on the GPU.  The
  * keyframe bookkeeping and the runBA call stay with the caller (which reads S.P, S.X with

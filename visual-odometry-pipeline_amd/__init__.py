@@ -11,7 +11,7 @@ from .bootstrap import (bootstrap, compProjMat, matching_init, pose_estimation_i
 from .evaluation import (alignError, alignEstimateToGroundTruth, experiment_name, load_results, main_eval,
                          quantitative_eval, run_sequence, save_results)
 from .fmatrix import draw_octets, estimateFundamentalMatrix, octets_from_uniforms
-from .frame_pipeline import VOPipelineDevice
+from .frame_pipeline import VOGroupDevice, VOPipelineDevice
 from .keypoints import cornerPoints, genKeypoints
 from .klt import PointTracker, Pyramid
 from .pipeline import (VO_bundle_adjust, VOPipeline, default_hyper_paras, init_state, update_candidate,

@@ -20,10 +20,12 @@ VOHIP_SAMPLES_EXHAUSTED = 4
 VOHIP_TOO_FEW_POINTS = 5
 VOHIP_ERR_NO_DEVICE = 6
 VOHIP_CAPACITY_EXCEEDED = 7
+VOHIP_SEQUENCE_IDLE = 8
 
 STATUS_NAMES = {
     0: "VOHIP_OK", 1: "VOHIP_ERR_INVALID_ARGUMENT", 2: "VOHIP_ERR_HIP", 3: "VOHIP_NO_MODEL",
     4: "VOHIP_SAMPLES_EXHAUSTED", 5: "VOHIP_TOO_FEW_POINTS", 6: "VOHIP_ERR_NO_DEVICE", 7: "VOHIP_CAPACITY_EXCEEDED",
+    8: "VOHIP_SEQUENCE_IDLE",
 }
 
 c_double_p = C.POINTER(C.c_double)
@@ -101,6 +103,19 @@ SIGNATURES = {
     "vohip_frame_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]),
     "vohip_frame_apply_ba": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
+    "vohip_group_create": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams), C.c_int,
+                                     C.c_int, C.POINTER(C.c_void_p)]),
+    "vohip_group_destroy": (C.c_int, [C.c_void_p]),
+    "vohip_group_prepare": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_double,
+                                      C.c_double]),
+    "vohip_group_reset": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p]),
+    "vohip_group_begin": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
+    "vohip_group_finish": (C.c_int, [C.c_void_p, C.POINTER(FramePose), C.POINTER(FrameCounts), c_int_p]),
+    "vohip_group_retry": (C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_int, C.POINTER(FramePose),
+                                    C.POINTER(FrameCounts)]),
+    "vohip_group_sizes": (C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p]),
+    "vohip_group_state": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                    c_double_p]),
     "vohip_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "vohip_destroy": (C.c_int, [C.c_void_p]),
     "vohip_last_error": (C.c_char_p, [C.c_void_p]),

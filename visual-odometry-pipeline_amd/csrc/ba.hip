@@ -31,6 +31,7 @@
 #include "vohip_internal.h"
 #include "se3_device.h"
 #include "wave_reduce.h"
+#include "seq_index.h"
 
 #include <chrono>
 #include <cstdlib>
@@ -695,8 +696,14 @@ __global__ __launch_bounds__(PR_THREADS) void pose_refine_kernel(pr_params P, co
                                                                  const double *__restrict__ X,
                                                                  double *__restrict__ T_io /*16*/,
                                                                  double *__restrict__ stats /*3*/,
-                                                                 const int *__restrict__ offsets)
+                                                                 const int *__restrict__ offsets, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_STATE(kp_uv);
+    VOHIP_SEQ_STATE(X);
+    VOHIP_SEQ_STATE(T_io);
+    VOHIP_SEQ_STATE_OPT(stats);
     if (offsets) {
         const int b = blockIdx.x, first = offsets[b];
         P.n = offsets[b + 1] - first;
@@ -1102,16 +1109,19 @@ int vohip_pose_refine_dev(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, co
 // n, or *d_n when given (the frame pipeline keeps the count on the device).
 int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, const double *d_X, int n,
                               const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
-                              double *d_stats)
+                              double *d_stats, const vohip_seqs *seqs)
 {
+    const vohip_seqs SQ = seqs ? *seqs : vohip_seqs();
+    const int ny = vohip_seq_count(SQ);
+    if (ny < 1) return VOHIP_OK;
     pr_params P;
     std::memcpy(P.K, K, sizeof(P.K));
     P.n = n;
     P.max_iter = max_iter;
     P.ftol = ftol;
     P.xtol = xtol;
-    hipLaunchKernelGGL(pose_refine_kernel, dim3(1), dim3(PR_THREADS), 0, ctx->stream, P, d_n, d_kp_uv, d_X, d_T,
-                       d_stats, (const int *)nullptr);
+    hipLaunchKernelGGL(pose_refine_kernel, dim3(1, ny), dim3(PR_THREADS), 0, ctx->stream, P, d_n, d_kp_uv, d_X, d_T,
+                       d_stats, (const int *)nullptr, SQ);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
@@ -1178,7 +1188,7 @@ int vohip_pose_refine_batch(vohip_ctx *ctx, int k, double *T, const double *kp_u
                 st = vohip_fail(ctx, VOHIP_ERR_HIP, "hipMemsetAsync failed");
             hipLaunchKernelGGL(pose_refine_kernel, dim3(k), dim3(PR_THREADS), 0, ctx->stream, P, (const int *)nullptr,
                                (const double *)d_kp, (const double *)d_X, (double *)d_T, (double *)d_stats,
-                               (const int *)d_off);
+                               (const int *)d_off, vohip_seqs());
             if (st == VOHIP_OK && hipGetLastError() != hipSuccess) st = vohip_fail(ctx, VOHIP_ERR_HIP, "launch failed");
         }
         if (st == VOHIP_OK) st = vohip_download(ctx, T, d_T, sizeof(double) * 16 * (size_t)k);

@@ -13,6 +13,7 @@
 // group of 8 lanes per trial), fm_count_kernel (one wavefront per trial, ballot/popcount), fm_mask_kernel.
 #include "vohip_internal.h"
 #include "sampson_test.h"
+#include "seq_index.h"
 
 #include <cmath>
 
@@ -30,8 +31,13 @@ __device__ __forceinline__ double wsum(double v)
 __global__ __launch_bounds__(256) void fm_normalise_kernel(const double *__restrict__ p1,
                                                            const double *__restrict__ p2, int n,
                                                            const int *__restrict__ n_dev,
-                                                           double *__restrict__ nrm)
+                                                           double *__restrict__ nrm, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(p1);
+    VOHIP_SEQ_STATE(p2);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_STATE(nrm);
     __shared__ double sW[4][4];
     if (n_dev) n = *n_dev;  // point count kept on the device (the frame pipeline)
     __shared__ double sMean[4];
@@ -213,8 +219,16 @@ __device__ void rank2(double F[3][3])
 __global__ __launch_bounds__(64) void fm_solve_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
                                                       int n, const int *__restrict__ n_dev,
                                                       const int32_t *__restrict__ samples, int trials,
-                                                      const double *__restrict__ nrm, double *__restrict__ F_out)
+                                                      const double *__restrict__ nrm, double *__restrict__ F_out,
+                                                      vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(p1);
+    VOHIP_SEQ_STATE(p2);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_STATE(samples);
+    VOHIP_SEQ_STATE(nrm);
+    VOHIP_SEQ_STATE(F_out);
     __shared__ double sA[8][72];
     __shared__ int sP[8][9];
     const int g = threadIdx.x & 7, slot = threadIdx.x >> 3;
@@ -270,8 +284,14 @@ using vohip_dev::sampson_inlier;   // sampson_test.h
 __global__ __launch_bounds__(256) void fm_count_kernel(const double *__restrict__ p1, const double *__restrict__ p2,
                                                        int n, const int *__restrict__ n_dev,
                                                        const double *__restrict__ Fs, int trials, double thr,
-                                                       int32_t *__restrict__ counts)
+                                                       int32_t *__restrict__ counts, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(p1);
+    VOHIP_SEQ_STATE(p2);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_STATE(Fs);
+    VOHIP_SEQ_STATE(counts);
     if (n_dev) n = *n_dev;
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,14 +338,17 @@ double trial_budget(int inliers, int n, int num_trials, double confidence)
 // trial), the point count may live on the device.  d_nrm 6 doubles, d_F 9 x trials, d_counts trials.
 int vohip_fm_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int *d_n,
                      const int32_t *d_samples, int num_trials, double threshold, double *d_nrm, double *d_F,
-                     int32_t *d_counts)
+                     int32_t *d_counts, const vohip_seqs *seqs)
 {
     hipStream_t s = ctx->stream;
-    hipLaunchKernelGGL(fm_normalise_kernel, dim3(1), dim3(256), 0, s, d_p1, d_p2, n, d_n, d_nrm);
-    hipLaunchKernelGGL(fm_solve_kernel, dim3((num_trials + 7) / 8), dim3(64), 0, s, d_p1, d_p2, n, d_n, d_samples,
-                       num_trials, (const double *)d_nrm, d_F);
-    hipLaunchKernelGGL(fm_count_kernel, dim3((num_trials + 3) / 4), dim3(256), 0, s, d_p1, d_p2, n, d_n,
-                       (const double *)d_F, num_trials, threshold, d_counts);
+    const vohip_seqs SQ = seqs ? *seqs : vohip_seqs();
+    const int ny = vohip_seq_count(SQ);
+    if (ny < 1) return VOHIP_OK;
+    hipLaunchKernelGGL(fm_normalise_kernel, dim3(1, ny), dim3(256), 0, s, d_p1, d_p2, n, d_n, d_nrm, SQ);
+    hipLaunchKernelGGL(fm_solve_kernel, dim3((num_trials + 7) / 8, ny), dim3(64), 0, s, d_p1, d_p2, n, d_n, d_samples,
+                       num_trials, (const double *)d_nrm, d_F, SQ);
+    hipLaunchKernelGGL(fm_count_kernel, dim3((num_trials + 3) / 4, ny), dim3(256), 0, s, d_p1, d_p2, n, d_n,
+                       (const double *)d_F, num_trials, threshold, d_counts, SQ);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }

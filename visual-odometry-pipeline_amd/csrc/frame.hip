@@ -27,6 +27,7 @@
 #include "vohip_internal.h"
 #include "inlier_test.h"
 #include "ordered_select.h"
+#include "seq_index.h"
 #include "sampson_test.h"
 
 #include <chrono>
@@ -34,6 +35,7 @@
 #include <cstdlib>
 #include <new>
 #include <unordered_map>
+#include <vector>
 
 namespace {
 
@@ -109,9 +111,25 @@ __global__ __launch_bounds__(256) void select_tracked_kernel(const double *__res
                                                              double *__restrict__ idv, int32_t *__restrict__ rowv,
                                                              int *__restrict__ cnt, double *__restrict__ dv,
                                                              const double *__restrict__ u3, int h0,
-                                                             int32_t *__restrict__ samples)
+                                                             int32_t *__restrict__ samples,
+                                                             const int *__restrict__ n_dev, vohip_seqs SQ)
 {
     __shared__ int sh[12];
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(out_xy);
+    VOHIP_SEQ_STATE(valid);
+    VOHIP_SEQ_STATE(L_X);
+    VOHIP_SEQ_STATE(L_id);
+    VOHIP_SEQ_STATE(mv_rc);
+    VOHIP_SEQ_STATE(Xv);
+    VOHIP_SEQ_STATE(idv);
+    VOHIP_SEQ_STATE(rowv);
+    VOHIP_SEQ_STATE(cnt);
+    VOHIP_SEQ_STATE(dv);
+    VOHIP_SEQ_STATE(samples);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_PIN(u3);
+    if (n_dev) n = min(n, *n_dev);   // (a group of loops: the count of each is known on the device only)
     int total;
     // the ids handed out in the previous frame are final now
     if (blockIdx.x == 0 && threadIdx.x == 0) dv[D_IDX] = dv[D_IDX_NEXT];
@@ -135,8 +153,13 @@ __global__ __launch_bounds__(256) void select_tracked_kernel(const double *__res
 
 // uniform draws -> index triples (3 distinct indices in [0, n)), for hypotheses [first, first + h)
 __global__ __launch_bounds__(256) void triples_kernel(const double *__restrict__ u, int first, int h,
-                                                      const int *__restrict__ cnt, int32_t *__restrict__ samples)
+                                                      const int *__restrict__ cnt, int32_t *__restrict__ samples,
+                                                      vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(cnt);
+    VOHIP_SEQ_STATE(samples);
+    VOHIP_SEQ_PIN(u);
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= h) return;
     triple_from_uniforms(u + 3 * (size_t)(first + k), cnt[N_V], samples + 3 * (size_t)(first + k));
@@ -268,10 +291,27 @@ __global__ __launch_bounds__(256) void select_inliers_kernel(const int32_t *__re
                                                              double *__restrict__ dv,
                                                              int *__restrict__ cnt, double *__restrict__ L_rc,
                                                              double *__restrict__ L_X, double *__restrict__ L_id,
-                                                             int32_t *__restrict__ srcL, double *__restrict__ kp_uv)
+                                                             int32_t *__restrict__ srcL, double *__restrict__ kp_uv,
+                                                             vohip_seqs SQ)
 {
     __shared__ int sh[12];
     __shared__ int s_winner;
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(counts4);
+    VOHIP_SEQ_STATE(Rt_all);
+    VOHIP_SEQ_STATE(M_all);
+    VOHIP_SEQ_STATE(mv_rc);
+    VOHIP_SEQ_STATE(Xv);
+    VOHIP_SEQ_STATE(idv);
+    VOHIP_SEQ_STATE(rowv);
+    VOHIP_SEQ_STATE(dv);
+    VOHIP_SEQ_STATE(cnt);
+    VOHIP_SEQ_STATE(L_rc);
+    VOHIP_SEQ_STATE(L_X);
+    VOHIP_SEQ_STATE(L_id);
+    VOHIP_SEQ_STATE(srcL);
+    VOHIP_SEQ_STATE(kp_uv);
+
     const int n = cnt[N_V];
     // the stopping rule of the localisation, replayed by the first wavefront of every workgroup (the
     // scored hypotheses are few: cheaper than a kernel of its own); workgroup 0 publishes the outcome
@@ -340,9 +380,26 @@ __global__ __launch_bounds__(256) void select_cand_tracked_kernel(const double *
                                                                   double *__restrict__ F_t, double *__restrict__ T_t,
                                                                   int row_base, int32_t *__restrict__ row_t,
                                                                   int *__restrict__ cnt, const double *__restrict__ u8,
-                                                                  int trials, int32_t *__restrict__ samples8)
+                                                                  int trials, int32_t *__restrict__ samples8,
+                                                                  const int *__restrict__ n_dev, vohip_seqs SQ)
 {
     __shared__ int sh[12];
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(out_xy);
+    VOHIP_SEQ_STATE(valid);
+    VOHIP_SEQ_STATE(C_rc);
+    VOHIP_SEQ_STATE(F_rc);
+    VOHIP_SEQ_STATE(T12);
+    VOHIP_SEQ_STATE(p1_rc);
+    VOHIP_SEQ_STATE(m_rc);
+    VOHIP_SEQ_STATE(F_t);
+    VOHIP_SEQ_STATE(T_t);
+    VOHIP_SEQ_STATE(row_t);
+    VOHIP_SEQ_STATE(cnt);
+    VOHIP_SEQ_STATE(samples8);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_PIN(u8);
+    if (n_dev) n = min(n, *n_dev);   // (a group of loops: the count of each is known on the device only)
     int total;
     const int r = ordered_rank(valid, n, is_set(), total, sh);
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -380,9 +437,16 @@ constexpr int FM_DECIDE = 512;
 
 __global__ __launch_bounds__(FM_DECIDE) void fm_decide_kernel(const int32_t *__restrict__ counts, int num_trials,
                                                               double confidence, const double *__restrict__ F_all,
-                                                              int *__restrict__ cnt, double *__restrict__ dv)
+                                                              int *__restrict__ cnt, double *__restrict__ dv,
+                                                              vohip_seqs SQ)
 {
     constexpr int NW = FM_DECIDE / 64;
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(counts);
+    VOHIP_SEQ_STATE(F_all);
+    VOHIP_SEQ_STATE(cnt);
+    VOHIP_SEQ_STATE(dv);
+
     __shared__ int w_max[NW], w_stop[NW], w_hit[NW], s_mlast;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = cnt[N_CV];
@@ -440,9 +504,21 @@ __global__ __launch_bounds__(256) void select_f_inliers_kernel(const double *__r
                                                                const int32_t *__restrict__ row_t,
                                                                int *__restrict__ cnt, double *__restrict__ m2_rc,
                                                                double *__restrict__ F2, double *__restrict__ T2,
-                                                               int32_t *__restrict__ row2)
+                                                               int32_t *__restrict__ row2, vohip_seqs SQ)
 {
     __shared__ int sh[12];
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(p1_rc);
+    VOHIP_SEQ_STATE(m_rc);
+    VOHIP_SEQ_STATE(F_t);
+    VOHIP_SEQ_STATE(T_t);
+    VOHIP_SEQ_STATE(F9);
+    VOHIP_SEQ_STATE(row_t);
+    VOHIP_SEQ_STATE(cnt);
+    VOHIP_SEQ_STATE(m2_rc);
+    VOHIP_SEQ_STATE(F2);
+    VOHIP_SEQ_STATE(T2);
+    VOHIP_SEQ_STATE(row2);
     const int n = cnt[F_BEST_T] >= 0 ? cnt[N_CV] : 0;
     double F[9];
     for (int q = 0; q < 9; ++q) F[q] = F9[q];
@@ -476,9 +552,28 @@ __global__ __launch_bounds__(256) void split_candidates_kernel(const uint8_t *__
                                                                double *__restrict__ L_rc, double *__restrict__ L_X,
                                                                double *__restrict__ L_id, int32_t *__restrict__ srcL,
                                                                double *__restrict__ C_rc, double *__restrict__ F_rc,
-                                                               double *__restrict__ T12, int32_t *__restrict__ srcC)
+                                                               double *__restrict__ T12, int32_t *__restrict__ srcC,
+                                                               vohip_seqs SQ)
 {
     __shared__ int sh[12];
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(status);
+    VOHIP_SEQ_STATE(m2_rc);
+    VOHIP_SEQ_STATE(F2);
+    VOHIP_SEQ_STATE(T2);
+    VOHIP_SEQ_STATE(Xnew);
+    VOHIP_SEQ_STATE(row2);
+    VOHIP_SEQ_STATE(cnt);
+    VOHIP_SEQ_STATE(n_det);
+    VOHIP_SEQ_STATE(dv);
+    VOHIP_SEQ_STATE(L_rc);
+    VOHIP_SEQ_STATE(L_X);
+    VOHIP_SEQ_STATE(L_id);
+    VOHIP_SEQ_STATE(srcL);
+    VOHIP_SEQ_STATE(C_rc);
+    VOHIP_SEQ_STATE(F_rc);
+    VOHIP_SEQ_STATE(T12);
+    VOHIP_SEQ_STATE(srcC);
     const int n = cnt[N_CI];
     const int nL = cnt[N_IN];
     const double idx0 = dv[D_IDX];
@@ -526,8 +621,12 @@ __global__ __launch_bounds__(256) void split_candidates_kernel(const uint8_t *__
 
 // The same three counts for a frame without candidates (update_landmarks does not run).
 __global__ void filter_counts_kernel(int *__restrict__ cnt, const int *__restrict__ n_det, int capK, int have_map,
-                                     double *__restrict__ dv)
+                                     double *__restrict__ dv, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(cnt);
+    VOHIP_SEQ_STATE(n_det);
+    VOHIP_SEQ_STATE(dv);
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     cnt[FILT0] = min(*n_det, capK);
     cnt[FILT1] = cnt[N_C_MID];
@@ -547,9 +646,23 @@ __global__ __launch_bounds__(256) void append_candidates_kernel(const float *__r
                                                                 const double *__restrict__ L_rc,
                                                                 const double *__restrict__ L_X,
                                                                 const double *__restrict__ L_id, int capL,
-                                                                double *__restrict__ mirror_L)
+                                                                double *__restrict__ mirror_L, vohip_seqs SQ)
 {
     __shared__ int sh[12];
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(corner_xy);
+    VOHIP_SEQ_STATE(keep);
+    VOHIP_SEQ_STATE(cnt);
+    VOHIP_SEQ_STATE(dv);
+    VOHIP_SEQ_STATE(C_rc);
+    VOHIP_SEQ_STATE(F_rc);
+    VOHIP_SEQ_STATE(T12);
+    VOHIP_SEQ_STATE(srcC);
+    VOHIP_SEQ_STATE(L_rc);
+    VOHIP_SEQ_STATE(L_X);
+    VOHIP_SEQ_STATE(L_id);
+    VOHIP_SEQ_PIN(mirror_dv);
+    VOHIP_SEQ_PIN(mirror_cnt);
     const int n = cnt[FILT0];
     const int nC = cnt[N_C_MID];
     int total;
@@ -661,8 +774,17 @@ __global__ __launch_bounds__(256) void prepared_rows_kernel(const float *__restr
                                                             float *__restrict__ corner_xy,
                                                             float *__restrict__ corner_metric, int *__restrict__ n_det,
                                                             int base, int ld, double *__restrict__ U_xy,
-                                                            uint8_t *__restrict__ U_live)
+                                                            uint8_t *__restrict__ U_live, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(corner_xy);
+    VOHIP_SEQ_STATE(corner_metric);
+    VOHIP_SEQ_STATE(n_det);
+    VOHIP_SEQ_STATE(U_xy);
+    VOHIP_SEQ_STATE(U_live);
+    VOHIP_SEQ_PREP(src_xy);
+    VOHIP_SEQ_PREP(src_metric);
+    VOHIP_SEQ_PREP(src_count);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= capK) return;
     const int n = *src_count;
@@ -718,6 +840,7 @@ struct vohip_frame {
     // A stored sequence prepared ahead (vohip_frame_prepare): the images on the device, their pyramids and
     // corner lists, all made by batched launches; a call recognises a prepared image by the caller's pointer.
     void *prep_block = nullptr;
+    size_t prep_bytes = 0;
     int prep_n = 0;
     uint8_t *prep_imgs = nullptr;
     float *prep_pyr = nullptr, *prep_xy = nullptr, *prep_metric = nullptr;
@@ -756,6 +879,24 @@ struct vohip_frame {
     double enqueue_us = 0.0;     // host time the enqueue of the current frame took
     bool have_map = false;       // the frame started with candidates (update_landmarks runs)
     std::chrono::steady_clock::time_point t_entry;   // host-side timing of the current call
+    // A group of loops advanced in lockstep (vohip_group_*): nseq state blocks, pinned blocks and prepared
+    // sequences of one layout each, a constant number of bytes apart; the members above then describe
+    // sequence 0 (pointers) or the whole group (n_L, n_C: the largest count, which sizes the grids).
+    bool is_group = false;
+    int nseq = 1;
+    vohip_seqs Q, Qn;        // the sequences the launches of the current frame serve / those of the look-ahead
+    size_t pin_bytes = 0;    // of one sequence's pinned block
+    struct seq_state {
+        int n_L = 0, n_C = 0, evaluated = 0, n_frames = 0;
+        int stage = 0;       // 0 = in step, 1 = waits for vohip_group_retry, STAGE_FAILED
+        bool reset = false;  // takes part in the run that is under way
+    };
+    std::vector<seq_state> seqs;
+    int g_max_frames = 0;
+    int g_frame = 0;         // index (within the prepared sequences) of the frame processed last
+    bool g_inflight = false; // vohip_group_begin without its vohip_group_finish
+    int g_h = 0;
+    double *prep_xy_all = nullptr;   // (group) corner lists of the prepared frames, sequence 0
 };
 
 namespace {
@@ -833,10 +974,43 @@ struct stream_swap {
 // pinned host block: [dv mirror | cnt mirror | staging of the P3P uniforms | staging of the trial uniforms]
 constexpr size_t PIN_CNT = sizeof(double) * N_DOUBLES;
 constexpr size_t PIN_U3 = PIN_CNT + sizeof(int) * N_COUNTERS;
-inline double *pin_dv(vohip_frame *f) { return (double *)f->pinned; }
-inline int *pin_cnt(vohip_frame *f) { return (int *)((char *)f->pinned + PIN_CNT); }
-inline double *pin_u3(vohip_frame *f) { return (double *)((char *)f->pinned + PIN_U3); }
-inline double *pin_u8(vohip_frame *f) { return pin_u3(f) + 3 * (size_t)f->hmax; }
+inline double *pin_dv(vohip_frame *f, int seq = 0) { return (double *)((char *)f->pinned + f->pin_bytes * seq); }
+inline int *pin_cnt(vohip_frame *f, int seq = 0) { return (int *)((char *)f->pinned + f->pin_bytes * seq + PIN_CNT); }
+inline double *pin_u3(vohip_frame *f, int seq = 0) { return (double *)((char *)f->pinned + f->pin_bytes * seq + PIN_U3); }
+inline double *pin_u8(vohip_frame *f, int seq = 0) { return pin_u3(f, seq) + 3 * (size_t)f->hmax; }
+// the same array of another sequence of the group
+template <class T>
+inline T *seq_host(vohip_frame *f, T *p, int seq)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(p) + f->Q.stride_state * (size_t)seq);
+}
+inline int ny_of(const vohip_seqs &q) { return vohip_seq_count(q); }
+
+// A pyramid slot of this loop may show a pyramid inside the prepared block (vohip_pyramid_attach).  Before
+// that block is released, such a pyramid is copied into the slot's own buffer, so that the trackers of the
+// following frames still find it; with copy = false the slot is just emptied (the loop ends).
+int detach_prepared_slots(vohip_frame *f, bool copy)
+{
+    vohip_ctx *ctx = f->ctx;
+    if (!f->prep_block) return VOHIP_OK;
+    const char *lo = (const char *)f->prep_block, *hi = lo + f->prep_bytes;
+    const int slots[3] = {f->slot_prev, f->slot_cur, f->slot_next};
+    for (int q = 0; q < 3; ++q) {
+        const int slot = slots[q];
+        const char *ext = (const char *)ctx->pyr_ext[slot];
+        if (!ext || ext < lo || ext >= hi) continue;
+        if (copy) {
+            const size_t bytes = sizeof(float) * f->prep_pyr_floats;
+            VOHIP_TRY(vohip_reserve(ctx, ctx->bufs[B_PYR0 + slot], bytes));
+            VOHIP_HIP(ctx, hipMemcpyAsync(ctx->bufs[B_PYR0 + slot].ptr, ext, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        } else {
+            ctx->pyr[slot].levels = 0;
+        }
+        ctx->pyr_ext[slot] = nullptr;
+    }
+    return VOHIP_OK;
+}
 
 int fetch_summary(vohip_frame *f)
 {
@@ -883,15 +1057,17 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
     VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_adv[f->par], 0));
     if (f->trace) (void)hipEventRecord(f->tr[3], s);
     if (f->have_map) {
-        hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->U_xy[f->par] + f->capL,
+        const int ny = ny_of(f->Q);
+        hipLaunchKernelGGL(select_cand_tracked_kernel, dim3(blocks256(f->n_C), ny), dim3(256), 0, s, f->U_xy[f->par] + f->capL,
                            f->capU, f->U_live[f->par] + f->capL, f->C_rc, f->F_rc, f->T12, f->n_C, f->p1_rc, f->m_rc, f->F_t,
-                           f->T_t, f->capL, f->row_t, f->cnt, pin_u8(f), T, f->samples8);
+                           f->T_t, f->capL, f->row_t, f->cnt, pin_u8(f), T, f->samples8,
+                           f->is_group ? (const int *)(f->cnt + N_C_END) : (const int *)nullptr, f->Q);
         VOHIP_TRY(vohip_fm_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->samples8, T, p.fm_threshold,
-                                   f->dv + D_NRM, f->fm_F, f->fm_counts));
-        hipLaunchKernelGGL(fm_decide_kernel, dim3(1), dim3(FM_DECIDE), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
-                           f->dv);
-        hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->p1_rc, f->m_rc, f->F_t,
-                           f->T_t, f->dv + D_F, p.fm_threshold, f->row_t, f->cnt, f->m2_rc, f->F2, f->T2, f->row2);
+                                   f->dv + D_NRM, f->fm_F, f->fm_counts, &f->Q));
+        hipLaunchKernelGGL(fm_decide_kernel, dim3(1, ny), dim3(FM_DECIDE), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
+                           f->dv, f->Q);
+        hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C), ny), dim3(256), 0, s, f->p1_rc, f->m_rc, f->F_t,
+                           f->T_t, f->dv + D_F, p.fm_threshold, f->row_t, f->cnt, f->m2_rc, f->F2, f->T2, f->row2, f->Q);
         VOHIP_HIP(ctx, hipGetLastError());
     }
     VOHIP_HIP(ctx, hipEventRecord(f->ev_side, s));
@@ -906,17 +1082,19 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
 // table of that parity, and the event the tail waits for -- recorded behind the NEXT filter on this stream --
 // covers it.  `par`: parity of the frame the image belongs to; `ready`: event after which the image is on
 // the device, or NULL.
-int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t ready, int prepared = -1)
+int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t ready, int prepared = -1,
+                      const vohip_seqs *seqs = nullptr)
 {
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
     hipStream_t s = f->side;
+    const vohip_seqs &SQ = seqs ? *seqs : f->Q;
     if (prepared >= 0) {   // detected ahead with the whole sequence: one kernel hands the list over
-        hipLaunchKernelGGL(prepared_rows_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s,
+        hipLaunchKernelGGL(prepared_rows_kernel, dim3(blocks256(f->capK), ny_of(SQ)), dim3(256), 0, s,
                            (const float *)(f->prep_xy + 2 * (size_t)f->capK * prepared),
                            (const float *)(f->prep_metric + (size_t)f->capK * prepared), (const int *)(f->prep_counts + prepared),
                            f->capK, f->corner_xy[par], f->corner_metric[par], f->cnt + N_DET + par, f->capL + f->capC, f->capU,
-                           f->U_xy[par], f->U_live[par]);
+                           f->U_xy[par], f->U_live[par], SQ);
         VOHIP_HIP(ctx, hipGetLastError());
         if (f->trace) (void)hipEventRecord(f->tr_det[par], s);
         return VOHIP_OK;
@@ -944,27 +1122,29 @@ int enqueue_localize(vohip_frame *f, const double *u3, int h, int ready, bool wi
     const vohip_frame_params &p = f->prm;
     const int first = f->evaluated, more = h - first;
     // (the kernels read the draws from the pinned staging block itself: a few KB, no copy command)
-    if (ready == 0)
+    // (u3 == NULL: the caller has put them there itself)
+    if (ready == 0 && u3)
         std::memcpy(pin_u3(f) + 3 * (size_t)first, u3 + 3 * (size_t)first, sizeof(double) * 3 * (size_t)more);
+    const int ny = ny_of(f->Q);
     if (more > ready)
-        hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more - ready)), dim3(256), 0, s, pin_u3(f), first + ready,
-                           more - ready, f->cnt, f->samples3);
+        hipLaunchKernelGGL(triples_kernel, dim3(blocks256(more - ready), ny), dim3(256), 0, s, pin_u3(f), first + ready,
+                           more - ready, f->cnt, f->samples3, f->Q);
     // with_selection: the selection of the valid tracks has not been launched; it rides with the solve kernel
     const vohip_select_tracked sel = {f->U_xy[f->par], f->capU, f->U_live[f->par], f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv,
                                       f->idv, f->rowv, f->cnt + N_V, f->dv + D_IDX, f->dv + D_IDX_NEXT, pin_u3(f), ready,
-                                      f->samples3};
+                                      f->samples3, f->is_group ? f->cnt + N_L_END : nullptr};
     VOHIP_TRY(vohip_ransac_enqueue(ctx, f->mv_rc, f->Xv, f->n_L, f->cnt + N_V, f->K, f->samples3, first, more,
-                                   f->counts4, f->Rt_all, f->M_all, with_selection ? &sel : nullptr));
+                                   f->counts4, f->Rt_all, f->M_all, with_selection ? &sel : nullptr, &f->Q));
     f->evaluated = h;
-    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->counts4, h,
+    hipLaunchKernelGGL(select_inliers_kernel, dim3(blocks256(f->n_L), ny), dim3(256), 0, s, f->counts4, h,
                        (const double *)f->Rt_all, (const double *)f->M_all, f->mv_rc,
                        f->Xv, f->idv, f->rowv,
-                       f->dv, f->cnt, f->L_rc, f->L_X, f->L_id, f->srcL, f->kp_uv);
+                       f->dv, f->cnt, f->L_rc, f->L_X, f->L_id, f->srcL, f->kp_uv, f->Q);
     VOHIP_HIP(ctx, hipGetLastError());
     VOHIP_HIP(ctx, hipEventRecord(f->ev_inl, s));   // S.P of the inliers is final: their tracker may start
     if (p.refine_pose)   // main_demo.m:398-400
         VOHIP_TRY(vohip_pose_refine_enqueue(ctx, f->dv + D_T, f->kp_uv, f->L_X, f->n_L, f->cnt + N_IN, f->K,
-                                            p.refine_max_iter, 1e-6, 1e-6, f->dv + D_STATS));   // lsqnonlin's default tolerances (T_refinement.m:4)
+                                            p.refine_max_iter, 1e-6, 1e-6, f->dv + D_STATS, &f->Q));   // lsqnonlin's default tolerances (T_refinement.m:4)
     return VOHIP_OK;
 }
 
@@ -976,22 +1156,23 @@ int enqueue_tail(vohip_frame *f)
     const vohip_frame_params &p = f->prm;
     VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_side, 0));   // (the epipolar filter, and this image's corners before it on that stream)
     const int *n_det = f->cnt + N_DET + f->par;
+    const int ny = ny_of(f->Q);
     if (f->have_map) {
         VOHIP_TRY(vohip_candidate_triangulate_enqueue(ctx, f->m2_rc, f->F2, f->T2, f->n_C, f->cnt + N_CI, f->dv + D_T,
                                                       f->K, p.angle_threshold_deg, p.min_depth, p.max_depth,
-                                                      p.is_BA ? 1 : 0, f->status, f->Xnew));
-        hipLaunchKernelGGL(split_candidates_kernel, dim3(blocks256(f->n_C)), dim3(256), 0, s, f->status, f->m2_rc, f->F2,
+                                                      p.is_BA ? 1 : 0, f->status, f->Xnew, &f->Q));
+        hipLaunchKernelGGL(split_candidates_kernel, dim3(blocks256(f->n_C), ny), dim3(256), 0, s, f->status, f->m2_rc, f->F2,
                            f->T2, f->Xnew, f->row2, f->cnt, n_det, f->dv, f->capL, f->capK, f->L_rc, f->L_X, f->L_id,
-                           f->srcL, f->C_rc, f->F_rc, f->T12, f->srcC);
+                           f->srcL, f->C_rc, f->F_rc, f->T12, f->srcC, f->Q);
     } else {
-        hipLaunchKernelGGL(filter_counts_kernel, dim3(1), dim3(64), 0, s, f->cnt, n_det, f->capK, 0, f->dv);
+        hipLaunchKernelGGL(filter_counts_kernel, dim3(1, ny), dim3(64), 0, s, f->cnt, n_det, f->capK, 0, f->dv, f->Q);
     }
     VOHIP_TRY(vohip_candidate_filter_enqueue(ctx, f->corner_xy[f->par], f->capK, f->capK, f->C_rc, f->L_rc,
-                                             f->cnt + FILT0, p.r_discard_redundant, f->keep));
-    hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s, f->corner_xy[f->par], f->capK,
+                                             f->cnt + FILT0, p.r_discard_redundant, f->keep, &f->Q));
+    hipLaunchKernelGGL(append_candidates_kernel, dim3(blocks256(f->capK), ny), dim3(256), 0, s, f->corner_xy[f->par], f->capK,
                        f->keep, f->cnt, f->dv, f->capC, f->capL + f->capC, f->C_rc, f->F_rc, f->T12, f->srcC, pin_dv(f),
                        pin_cnt(f), (const double *)f->L_rc, (const double *)f->L_X, (const double *)f->L_id, f->capL,
-                       f->ba_stage);
+                       f->ba_stage, f->Q);
     f->ba_mirrored = f->ba_stage != nullptr;
     VOHIP_HIP(ctx, hipGetLastError());
     if (f->trace) (void)hipEventRecord(f->tr[6], s);   // tail done (before the event the host waits for: it is read right after)
@@ -1006,19 +1187,20 @@ int enqueue_tail(vohip_frame *f)
 // grid and the counts are the ones the frame before left in device memory (that frame may still be
 // running: this is how the trackers of the following frame are enqueued behind a frame's last kernel).
 int enqueue_trackers(vohip_frame *f, int par, int slot_from, int slot_to, int nL, int nC, bool counts_on_device,
-                     hipEvent_t start)
+                     hipEvent_t start, const vohip_seqs *seqs = nullptr, bool kept_apart = true)
 {
     vohip_ctx *ctx = f->ctx;
     const vohip_frame_params &p = f->prm;
+    const vohip_seqs *SQ = seqs ? seqs : &f->Q;
     const int *dL = counts_on_device ? f->cnt + N_L_END : nullptr, *dC = counts_on_device ? f->cnt + N_C_END : nullptr;
     // ahead of the frame, the landmarks the previous frame kept as inliers have a tracker of their own
     // (enqueue_tracker_kept); this launch then starts at the landmarks that frame appended
-    const int *dFirst = counts_on_device ? f->cnt + N_IN : nullptr;
+    const int *dFirst = counts_on_device && kept_apart ? f->cnt + N_IN : nullptr;
     const vohip_klt_set sets[2] = {
         {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcL, nullptr, dL, f->capU, nL, 0, 0, dFirst},
         {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcC, nullptr, dC, f->capU, nC, 0, f->capL, nullptr}};
     if (f->trace) (void)hipEventRecord(f->tr_trk[par][0], ctx->stream);
-    if ((counts_on_device ? f->n_C : f->n_L + f->n_C) >= SPLIT_TRACKERS_FROM) {
+    if (!f->is_group && (counts_on_device ? f->n_C : f->n_L + f->n_C) >= SPLIT_TRACKERS_FROM) {
         // landmarks on the context's stream, candidates on the second stream (where the epipolar filter
         // follows them in stream order); `start`: what the candidate launch waits for on the context's stream
         VOHIP_TRY(vohip_klt_enqueue_sets(ctx, slot_from, slot_to, sets, 1, p.klt_block, p.klt_max_iter,
@@ -1036,7 +1218,7 @@ int enqueue_trackers(vohip_frame *f, int par, int slot_from, int slot_to, int nL
         return VOHIP_OK;
     }
     f->split_used[par] = false;
-    VOHIP_TRY(vohip_klt_enqueue_sets(ctx, slot_from, slot_to, sets, 2, p.klt_block, p.klt_max_iter, p.klt_max_bidir_error));
+    VOHIP_TRY(vohip_klt_enqueue_sets(ctx, slot_from, slot_to, sets, 2, p.klt_block, p.klt_max_iter, p.klt_max_bidir_error, SQ));
     if (f->trace) (void)hipEventRecord(f->tr_trk[par][1], ctx->stream);
     VOHIP_HIP(ctx, hipEventRecord(f->ev_adv[par], ctx->stream));   // the other streams start from here
     return VOHIP_OK;
@@ -1056,7 +1238,7 @@ int enqueue_tracker_kept(vohip_frame *f)
     const vohip_klt_set set = {f->U_xy[par ^ 1], f->U_xy[par], f->U_live[par], nullptr, f->srcL, nullptr, f->cnt + N_IN,
                                f->capU, f->n_L, 0, 0, nullptr};
     VOHIP_TRY(vohip_klt_enqueue_sets(ctx, f->slot_cur, f->slot_next, &set, 1, p.klt_block, p.klt_max_iter,
-                                     p.klt_max_bidir_error));
+                                     p.klt_max_bidir_error, &f->Qn));
     VOHIP_HIP(ctx, hipEventRecord(f->ev_advA[par], f->trk));
     return VOHIP_OK;
 }
@@ -1073,7 +1255,7 @@ int enqueue_trackers_ahead(vohip_frame *f)
     // kept ones have their own, earlier launch); candidates grow by the detections that are kept
     const long long nLb = (long long)f->n_C, nCb = (long long)f->n_C + f->capK;
     VOHIP_TRY(enqueue_trackers(f, f->par ^ 1, f->slot_cur, f->slot_next, (int)(nLb < f->capL ? nLb : f->capL),
-                               (int)(nCb < f->capC ? nCb : f->capC), true, f->ev_tail));
+                               (int)(nCb < f->capC ? nCb : f->capC), true, f->ev_tail, &f->Qn));
     return VOHIP_OK;
 }
 
@@ -1161,6 +1343,8 @@ int complete_frame(vohip_frame *f, int h, vohip_frame_pose *pose, vohip_frame_co
 
 int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, const uint8_t *next_image,
                   int next_on_device, const double *u3, int h, const double *u8);
+int create_loops(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor, const vohip_frame_params *params,
+                 int nseq, vohip_frame **out);
 
 }  // namespace
 
@@ -1201,6 +1385,17 @@ void vohip_frame_default_params(vohip_frame_params *p)
 int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor,
                        const vohip_frame_params *params, vohip_frame **out)
 {
+    return create_loops(ctx, K, rows, cols, colmajor, params, 1, out);
+}
+
+}  // extern "C"
+
+namespace {
+
+// One loop, or the `nseq` loops of a group: state blocks and pinned blocks of one layout, back to back.
+int create_loops(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor, const vohip_frame_params *params,
+                 int nseq, vohip_frame **out)
+{
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, K && params && out, "NULL argument");
     VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
@@ -1230,12 +1425,15 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     f->slot_prev = p.slot_a;
     f->slot_cur = p.slot_b;
     f->slot_next = p.slot_c;
-    const size_t bytes = layout(f, nullptr);
-    hipError_t e = hipMalloc(&f->block, bytes);
-    if (e == hipSuccess) e = hipMemsetAsync(f->block, 0, bytes, ctx->stream);
-    if (e == hipSuccess)
-        e = hipHostMalloc(&f->pinned, PIN_U3 + sizeof(double) * (3 * (size_t)f->hmax + 8 * (size_t)p.fm_trials),
-                          hipHostMallocDefault);
+    f->nseq = nseq;
+    f->seqs.resize(nseq);
+    const size_t bytes = layout(f, nullptr);   // (a multiple of 256)
+    f->pin_bytes = (PIN_U3 + sizeof(double) * (3 * (size_t)f->hmax + 8 * (size_t)p.fm_trials) + 255) / 256 * 256;
+    f->Q.stride_state = f->Qn.stride_state = bytes;
+    f->Q.stride_pin = f->Qn.stride_pin = f->pin_bytes;
+    hipError_t e = hipMalloc(&f->block, bytes * nseq);
+    if (e == hipSuccess) e = hipMemsetAsync(f->block, 0, bytes * nseq, ctx->stream);
+    if (e == hipSuccess) e = hipHostMalloc(&f->pinned, f->pin_bytes * nseq, hipHostMallocDefault);
     if (e == hipSuccess && p.is_BA)   // the host's copy of S.P and S.X, written by every frame's last kernel
         e = hipHostMalloc((void **)&f->ba_stage, sizeof(double) * 6 * (size_t)f->capL, hipHostMallocDefault);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&f->trk, hipStreamNonBlocking);
@@ -1267,6 +1465,10 @@ int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
     *out = f;
     return VOHIP_OK;
 }
+
+}  // namespace
+
+extern "C" {
 
 int vohip_frame_destroy(vohip_frame *f)
 {
@@ -1303,6 +1505,7 @@ int vohip_frame_destroy(vohip_frame *f)
     if (f->block) (void)hipFree(f->block);
     if (f->pinned) (void)hipHostFree(f->pinned);
     if (f->ba_stage) (void)hipHostFree(f->ba_stage);
+    if (f->ctx) (void)detach_prepared_slots(f, false);   // (no slot of the context may keep pointing into the block)
     if (f->prep_block) (void)hipFree(f->prep_block);
     delete f;
     return VOHIP_OK;
@@ -1472,7 +1675,8 @@ int begin_enqueue(vohip_frame *f, const uint8_t *image, int image_on_device, con
     const bool fused = h <= h0 && f->n_L <= 8192 && !fused_off;
     if (!fused) {
         hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L)), dim3(256), 0, s, f->U_xy[par], f->capU, f->U_live[par],
-                           f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->rowv, f->cnt, f->dv, pin_u3(f), h0, f->samples3);
+                           f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->rowv, f->cnt, f->dv, pin_u3(f), h0, f->samples3,
+                           (const int *)nullptr, f->Q);
         VOHIP_HIP(ctx, hipGetLastError());
     }
     VOHIP_TRY(enqueue_localize(f, u3, h, h0, fused));
@@ -1518,6 +1722,8 @@ int vohip_frame_retry(vohip_frame *f, const double *u3, int h, vohip_frame_pose 
     VOHIP_REQUIRE(ctx, h > f->evaluated && h <= f->hmax, "hypothesis count must grow and stay within max_hypotheses");
     f->t_entry = std::chrono::steady_clock::now();
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    // (the first attempt's tracker of the kept landmarks may still read the lists the selection rewrites)
+    if (f->ahead_launched) VOHIP_HIP(ctx, hipStreamWaitEvent(ctx->stream, f->ev_advA[f->par ^ 1], 0));
     int st = enqueue_localize(f, u3, h, 0);
     // (the trackers enqueued ahead started from the lists of the first attempt: once more, from the final ones)
     if (st == VOHIP_OK && f->ahead_launched) st = enqueue_tracker_kept(f);
@@ -1621,8 +1827,10 @@ int vohip_frame_prepare(vohip_frame *f, const uint8_t *const *images, int n, int
     VOHIP_HIP(ctx, hipStreamSynchronize(f->side));
     VOHIP_HIP(ctx, hipStreamSynchronize(f->trk));
     f->prep_index.clear();
+    VOHIP_TRY(detach_prepared_slots(f, true));   // (a frame in progress keeps the pyramids it still tracks from)
     if (f->prep_block) (void)hipFree(f->prep_block);
     f->prep_block = nullptr;
+    f->prep_bytes = 0;
     f->prep_n = 0;
     f->prep_xy = nullptr;
     if (n == 0) return VOHIP_OK;
@@ -1636,6 +1844,7 @@ int vohip_frame_prepare(vohip_frame *f, const uint8_t *const *images, int n, int
                  b_metric = corners ? round256(sizeof(float) * (size_t)f->capK * n) : 0,
                  b_cnt = corners ? round256(sizeof(int) * (size_t)n) : 0;
     VOHIP_HIP(ctx, hipMalloc(&f->prep_block, b_img + b_pyr + b_xy + b_metric + b_cnt));
+    f->prep_bytes = b_img + b_pyr + b_xy + b_metric + b_cnt;
     char *q = (char *)f->prep_block;
     f->prep_imgs = (uint8_t *)q;
     q += b_img;
@@ -1667,6 +1876,465 @@ int vohip_frame_prepare(vohip_frame *f, const uint8_t *const *images, int n, int
     if (corners) f->prep_xy = xy;
     f->prep_n = n;
     for (int k = 0; k < n; ++k) f->prep_index[images[k]] = k;
+    return VOHIP_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// A group of loops advanced in lockstep: one launch sequence per frame serves every sequence of the
+// group (main_eval.m:22-23 runs independent sequences one after the other; here S of them share the
+// launches, their latencies and the host's enqueue work, and the tracker launch fills the GPU).
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// host-side view of one sequence's state block
+template <class T>
+inline T *of_seq(vohip_frame *f, T *p, int seq)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(p) + f->Q.stride_state * (size_t)seq);
+}
+template <class T>
+inline T *prep_of_seq(vohip_frame *f, T *p, int seq)
+{
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(p) + f->Q.stride_prep * (size_t)seq);
+}
+
+int group_check(vohip_frame *f, int seq)
+{
+    if (!f) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(f->ctx, f->is_group, "not a group of loops");
+    VOHIP_REQUIRE(f->ctx, seq >= 0 && seq < f->nseq, "sequence index out of range");
+    return VOHIP_OK;
+}
+
+// The frame with prepared index k, for the sequences of f->Q (look-ahead for those of f->Qn): the launch
+// sequence of begin_enqueue for a prepared, stored sequence.
+int group_enqueue(vohip_frame *f, int k, int h)
+{
+    vohip_ctx *ctx = f->ctx;
+    f->t_entry = std::chrono::steady_clock::now();
+    hipStream_t s = ctx->stream;
+    const vohip_frame_params &p = f->prm;
+    const int par = f->par;
+    f->evaluated = 0;
+    f->ahead_launched = f->Qn.mask != 0;
+    auto pyramid = [&](int index) { return f->prep_pyr + f->prep_pyr_floats * (size_t)index; };
+    VOHIP_TRY(vohip_pyramid_attach(ctx, f->slot_cur, pyramid(k), f->rows, f->cols, f->colmajor, p.klt_levels));
+    if (!f->ahead) {
+        // the first frame of a run: its trackers from the image the loops were reset on (index k - 1), counts
+        // from device memory (every sequence has its own), and the hand-over of its corner lists
+        VOHIP_TRY(vohip_pyramid_attach(ctx, f->slot_prev, pyramid(k - 1), f->rows, f->cols, f->colmajor, p.klt_levels));
+        VOHIP_HIP(ctx, hipEventRecord(f->ev_feed, s));
+        VOHIP_TRY(enqueue_trackers(f, par, f->slot_prev, f->slot_cur, f->n_L, f->have_map ? f->n_C : 0, true, f->ev_feed,
+                                   &f->Q, false));
+        VOHIP_TRY(enqueue_detection(f, nullptr, par, nullptr, k, &f->Q));
+    } else {
+        VOHIP_HIP(ctx, hipStreamWaitEvent(s, f->ev_advA[par], 0));   // the kept landmarks' own tracker
+    }
+    const int h0 = h < 256 ? h : 256;
+    const bool fused = h <= h0 && f->n_L <= 8192;
+    if (!fused) {
+        hipLaunchKernelGGL(select_tracked_kernel, dim3(blocks256(f->n_L), ny_of(f->Q)), dim3(256), 0, s, f->U_xy[par], f->capU,
+                           f->U_live[par], f->L_X, f->L_id, f->n_L, f->mv_rc, f->Xv, f->idv, f->rowv, f->cnt, f->dv, pin_u3(f),
+                           h0, f->samples3, (const int *)(f->cnt + N_L_END), f->Q);
+        VOHIP_HIP(ctx, hipGetLastError());
+    }
+    VOHIP_TRY(enqueue_localize(f, nullptr, h, h0, fused));
+    VOHIP_TRY(enqueue_side_filter(f, nullptr));
+    f->next_pyramid_stands = true;
+    if (f->Qn.mask) {
+        VOHIP_TRY(vohip_pyramid_attach(ctx, f->slot_next, pyramid(k + 1), f->rows, f->cols, f->colmajor, p.klt_levels));
+        VOHIP_TRY(enqueue_tracker_kept(f));
+    }
+    VOHIP_TRY(enqueue_tail(f));
+    if (f->Qn.mask) {
+        VOHIP_TRY(enqueue_trackers_ahead(f));
+        VOHIP_TRY(enqueue_detection(f, nullptr, par ^ 1, nullptr, k + 1, &f->Qn));
+    }
+    f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
+    return VOHIP_OK;
+}
+
+// What sequence `seq` reports for the frame just run (its summary is in its pinned block).  Returns the
+// sequence's status.
+int group_collect(vohip_frame *f, int seq, int h, vohip_frame_pose *pose, vohip_frame_counts *out, double wait_us)
+{
+    vohip_ctx *ctx = f->ctx;
+    vohip_frame::seq_state &q = f->seqs[seq];
+    const int *hc = pin_cnt(f, seq);
+    const double *hd = pin_dv(f, seq);
+    std::memset(pose, 0, sizeof(*pose));
+    std::memset(out, 0, sizeof(*out));
+    pose->n_tracked = hc[N_V];
+    pose->n_iter = hc[R_ITER];
+    pose->found = hc[R_FOUND];
+    pose->exhausted = hc[R_EXHAUSTED];
+    pose->n_inliers = hc[N_IN];
+    pose->max_num_inliers = hc[R_MAX_INL];
+    pose->evaluated = h;
+    pose->num_iterations = hd[D_NUM_ITER];
+    std::memcpy(pose->T_W_C, hd + D_T, sizeof(double) * 16);
+    std::memcpy(pose->Rt, hd + D_RT, sizeof(double) * 12);
+    std::memcpy(pose->refine_stats, hd + D_STATS, sizeof(double) * 3);
+    q.evaluated = h;
+    if (hc[N_V] >= 3 && hc[R_EXHAUSTED] && h < f->hmax) {
+        q.stage = 1;   // vohip_group_retry goes on from here
+        return vohip_fail(ctx, VOHIP_SAMPLES_EXHAUSTED, "sequence %d: the adaptive bound (%.0f) exceeds the %d hypotheses supplied",
+                          seq, hd[D_NUM_ITER], h);
+    }
+    const int par = f->par;
+    out->n_landmarks = hc[N_L_END];
+    out->n_candidates = hc[N_C_END];
+    out->num_new = hc[NUM_NEW];
+    out->n_detected = hc[N_DET + par];
+    out->n_kept = hc[N_KEPT];
+    out->n_candidates_tracked = f->have_map ? hc[N_CV] : 0;
+    out->n_candidates_inliers = f->have_map ? hc[N_CI] : 0;
+    out->fm_trials_run = f->have_map ? hc[F_TRIALS] : 0;
+    out->overflow = hc[OVERFLOW];
+    out->host_enqueue_us = f->enqueue_us;
+    out->host_wait_us = wait_us;
+    q.n_L = hc[N_L_END];
+    q.n_C = hc[N_C_END];
+    q.stage = 0;
+    // (the same ends of a run as complete_frame's)
+    const bool lost = hc[N_V] < 3 || !hc[R_FOUND] || (f->have_map && hc[N_CV] < 8);
+    const bool over = hc[N_DET + par] > f->capK || hc[OVERFLOW] != 0;
+    if (lost || over) q.stage = STAGE_FAILED;
+    if (hc[N_V] < 3) return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "sequence %d: only %d landmarks were tracked", seq, hc[N_V]);
+    if (!hc[R_FOUND])
+        return vohip_fail(ctx, VOHIP_NO_MODEL, "sequence %d: no hypothesis reached 30 inliers in %d iterations", seq, hc[R_ITER]);
+    if (f->have_map && hc[N_CV] < 8)
+        return vohip_fail(ctx, VOHIP_TOO_FEW_POINTS, "sequence %d: the 8-point algorithm needs 8 candidate tracks, got %d", seq,
+                          hc[N_CV]);
+    if (hc[N_DET + par] > f->capK)
+        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "sequence %d: %d corners found, capacity %d", seq, hc[N_DET + par], f->capK);
+    if (hc[OVERFLOW])
+        return vohip_fail(ctx, VOHIP_CAPACITY_EXCEEDED, "sequence %d: landmark or candidate capacity exceeded (flags %d)", seq,
+                          hc[OVERFLOW]);
+    return VOHIP_OK;
+}
+
+}  // namespace
+
+struct vohip_group {
+    vohip_frame *f = nullptr;
+};
+
+extern "C" {
+
+int vohip_group_create(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor,
+                       const vohip_frame_params *params, int n_sequences, int max_frames, vohip_group **out)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, out && params, "NULL argument");
+    VOHIP_REQUIRE(ctx, n_sequences >= 1 && n_sequences <= VOHIP_MAX_SEQ, "1..64 sequences per group");
+    VOHIP_REQUIRE(ctx, max_frames >= 2 && max_frames <= 65535, "a sequence holds 2..65535 images");
+    VOHIP_REQUIRE(ctx, !params->is_BA, "bundle adjustment is not available in a group of loops");
+    VOHIP_REQUIRE(ctx, params->cap_corners <= 16384, "corner capacity of prepared sequences is at most 16384");
+    vohip_frame *f = nullptr;
+    VOHIP_TRY(create_loops(ctx, K, rows, cols, colmajor, params, n_sequences, &f));
+    f->is_group = true;
+    f->g_max_frames = max_frames;
+    // the prepared sequences: per sequence [images | pyramids | corner (x, y) | corner metric | corner counts]
+    const vohip_frame_params &p = f->prm;
+    const size_t img_bytes = (size_t)rows * cols;
+    const size_t pyr_floats = vohip_pyramid_floats(rows, cols, f->colmajor, p.klt_levels);
+    auto round256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t b_img = round256(img_bytes * max_frames), b_pyr = round256(sizeof(float) * pyr_floats * max_frames),
+                 b_xy = round256(sizeof(float) * 2 * (size_t)f->capK * max_frames),
+                 b_metric = round256(sizeof(float) * (size_t)f->capK * max_frames), b_cnt = round256(sizeof(int) * (size_t)max_frames);
+    const size_t stride = b_img + b_pyr + b_xy + b_metric + b_cnt;
+    const hipError_t e = hipMalloc(&f->prep_block, stride * n_sequences);
+    if (e != hipSuccess) {
+        vohip_frame_destroy(f);
+        return vohip_fail(ctx, VOHIP_ERR_HIP, "%.1f MB for %d prepared sequences of %d frames: %s", stride * n_sequences / 1048576.0,
+                          n_sequences, max_frames, hipGetErrorString(e));
+    }
+    f->prep_bytes = stride * n_sequences;
+    char *q = (char *)f->prep_block;
+    f->prep_imgs = (uint8_t *)q;
+    q += b_img;
+    f->prep_pyr = (float *)q;
+    q += b_pyr;
+    f->prep_xy = (float *)q;
+    q += b_xy;
+    f->prep_metric = (float *)q;
+    q += b_metric;
+    f->prep_counts = (int *)q;
+    f->prep_pyr_floats = pyr_floats;
+    f->prep_n = max_frames;
+    f->Q.stride_prep = f->Qn.stride_prep = stride;
+    vohip_group *g = new (std::nothrow) vohip_group;
+    if (!g) {
+        vohip_frame_destroy(f);
+        return vohip_fail(ctx, VOHIP_ERR_HIP, "out of host memory");
+    }
+    g->f = f;
+    *out = g;
+    return VOHIP_OK;
+}
+
+int vohip_group_destroy(vohip_group *g)
+{
+    if (!g) return VOHIP_OK;
+    const int st = vohip_frame_destroy(g->f);
+    delete g;
+    return st;
+}
+
+int vohip_group_prepare(vohip_group *g, int seq, const uint8_t *const *images, int n, int on_device, int detector,
+                        double min_quality, double min_contrast)
+{
+    vohip_frame *f = g ? g->f : nullptr;
+    VOHIP_TRY(group_check(f, seq));
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, images && n >= 2 && n <= f->g_max_frames, "a sequence holds 2..max_frames images");
+    VOHIP_REQUIRE(ctx, !f->g_inflight, "a frame is in flight (vohip_group_finish)");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const vohip_frame_params &p = f->prm;
+    if (detector < 0) {
+        detector = p.detector;
+        min_quality = p.min_quality;
+        min_contrast = p.min_contrast;
+    }
+    VOHIP_REQUIRE(ctx, detector == 0 || detector == 1, "prepared sequences: Harris or MinEigen corners");
+    const size_t img_bytes = (size_t)f->rows * f->cols;
+    uint8_t *imgs = prep_of_seq(f, f->prep_imgs, seq);
+    for (int k = 0; k < n; ++k) {
+        VOHIP_REQUIRE(ctx, images[k], "NULL image");
+        VOHIP_HIP(ctx, hipMemcpyAsync(imgs + img_bytes * k, images[k], img_bytes,
+                                      on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    }
+    VOHIP_TRY(vohip_pyramid_batch_dev(ctx, imgs, n, f->rows, f->cols, f->colmajor, p.klt_levels, prep_of_seq(f, f->prep_pyr, seq)));
+    float *xy = prep_of_seq(f, f->prep_xy, seq), *metric = prep_of_seq(f, f->prep_metric, seq);
+    int *counts = prep_of_seq(f, f->prep_counts, seq);
+    const int chunk = 64;   // (bounds the detector's scratch: records of 64 images at a time)
+    for (int c = 0; c < n; c += chunk) {
+        const int m = n - c < chunk ? n - c : chunk;
+        VOHIP_TRY(vohip_detect_corners_batch_enqueue(ctx, imgs + img_bytes * c, m, f->rows, f->cols, f->colmajor, min_quality,
+                                                     p.filter_size, p.border, detector, xy + 2 * (size_t)f->capK * c,
+                                                     metric + (size_t)f->capK * c, f->capK, counts + c));
+    }
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    f->seqs[seq].n_frames = n;
+    f->seqs[seq].reset = false;
+    return VOHIP_OK;
+}
+
+int vohip_group_reset(vohip_group *g, int seq, const double *X, const double *ids, const double *P_rc, int n,
+                      const double T_W_C[16])
+{
+    vohip_frame *f = g ? g->f : nullptr;
+    VOHIP_TRY(group_check(f, seq));
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, X && P_rc && T_W_C, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 1 && n <= f->capL, "landmark count outside the capacity");
+    VOHIP_REQUIRE(ctx, f->seqs[seq].n_frames >= 2, "the sequence has not been prepared (vohip_group_prepare)");
+    VOHIP_REQUIRE(ctx, !f->g_inflight, "a frame is in flight (vohip_group_finish)");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    VOHIP_HIP(ctx, hipStreamSynchronize(f->side));
+    VOHIP_HIP(ctx, hipStreamSynchronize(f->trk));
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    if (f->g_frame > 0 || f->ahead) {
+        // a new run of the group starts: only sequences reset from here on take part in it
+        for (auto &q : f->seqs) q.reset = false;
+        f->g_frame = 0;
+    }
+    f->ahead = f->ahead_launched = false;
+    f->split_used[0] = f->split_used[1] = false;
+    f->par = 1;   // the image the loops are reset on counts as an even frame
+    f->stage = 0;
+    int *cnt = of_seq(f, f->cnt, seq);
+    double *dv = of_seq(f, f->dv, seq);
+    VOHIP_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(int) * N_COUNTERS, s));
+    VOHIP_HIP(ctx, hipMemsetAsync(dv, 0, sizeof(double) * N_DOUBLES, s));
+    std::vector<double> stage(17 + (size_t)n);
+    std::memcpy(stage.data(), T_W_C, sizeof(double) * 16);
+    double next_id = (double)(n + 1);
+    for (int i = 0; i < n; ++i) stage[17 + i] = ids ? ids[i] : (double)(i + 1);   // 1..n (main_demo.m:275)
+    if (ids) {
+        double mx = 0.0;
+        for (int i = 0; i < n; ++i) mx = ids[i] > mx ? ids[i] : mx;
+        next_id = mx + 1.0;
+    }
+    stage[16] = next_id;
+    VOHIP_HIP(ctx, hipMemcpyAsync(of_seq(f, f->L_rc, seq), P_rc, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(of_seq(f, f->L_X, seq), X, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(of_seq(f, f->L_id, seq), stage.data() + 17, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(dv + D_T, stage.data(), sizeof(double) * 16, hipMemcpyHostToDevice, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(dv + D_IDX, stage.data() + 16, sizeof(double), hipMemcpyHostToDevice, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(dv + D_IDX_NEXT, stage.data() + 16, sizeof(double), hipMemcpyHostToDevice, s));
+    const int n_host = n;
+    VOHIP_HIP(ctx, hipMemcpyAsync(cnt + N_L_END, &n_host, sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(init_rows_kernel, dim3(blocks256(n)), dim3(256), 0, s, (const double *)of_seq(f, f->L_rc, seq), n, f->capU,
+                       of_seq(f, f->U_xy[0], seq), of_seq(f, f->U_live[0], seq), of_seq(f, f->srcL, seq));
+    VOHIP_HIP(ctx, hipGetLastError());
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));   // (the staging vector is released on return)
+    vohip_frame::seq_state &q = f->seqs[seq];
+    q.n_L = n;
+    q.n_C = 0;
+    q.evaluated = 0;
+    q.stage = 0;
+    q.reset = true;
+    return VOHIP_OK;
+}
+
+int vohip_group_begin(vohip_group *g, const double *u3, int h, const double *u8)
+{
+    vohip_frame *f = g ? g->f : nullptr;
+    VOHIP_TRY(group_check(f, 0));
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, u3, "NULL argument");
+    VOHIP_REQUIRE(ctx, !f->g_inflight, "a frame is in flight (vohip_group_finish)");
+    VOHIP_REQUIRE(ctx, f->stage != STAGE_FAILED, "an earlier call failed half-way: vohip_group_reset starts over");
+    VOHIP_REQUIRE(ctx, h >= 1 && h <= f->hmax, "hypothesis count outside 1..max_hypotheses");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    const int k = f->g_frame + 1;
+    vohip_seqs Q = f->Q, Qn = f->Qn;
+    Q.mask = Qn.mask = 0;
+    int nL = 0, nC = 0;
+    bool some_map = false, all_map = true;
+    for (int s = 0; s < f->nseq; ++s) {
+        const vohip_frame::seq_state &q = f->seqs[s];
+        VOHIP_REQUIRE(ctx, q.stage != 1, "a sequence waits for vohip_group_retry");
+        if (!q.reset || q.stage != 0 || k >= q.n_frames) continue;
+        Q.mask |= 1ull << s;
+        if (k + 1 < q.n_frames) Qn.mask |= 1ull << s;
+        nL = q.n_L > nL ? q.n_L : nL;
+        nC = q.n_C > nC ? q.n_C : nC;
+        some_map = some_map || q.n_C > 0;
+        all_map = all_map && q.n_C > 0;
+    }
+    VOHIP_REQUIRE(ctx, Q.mask != 0, "no sequence of the group has a frame left");
+    // update_landmarks runs when a loop holds candidates (main_demo.m:406): in step, either every sequence does
+    // (every frame but a run's first) or none
+    VOHIP_REQUIRE(ctx, some_map == all_map, "the sequences of a group must all hold candidates, or none of them");
+    VOHIP_REQUIRE(ctx, !some_map || u8, "candidates exist: the fundamental-matrix draws are needed");
+    if (f->g_frame > 0) {   // the frame before is complete: its pyramid is the next "previous" (main_demo.m:417-424)
+        f->par ^= 1;
+        f->ahead = true;
+    }
+    f->Q = Q;
+    f->Qn = Qn;
+    f->n_L = nL;
+    f->n_C = nC;
+    f->have_map = some_map;
+    // the draws of both RANSAC stages: each sequence reads its own from its pinned block
+    for (int s = 0; s < f->nseq; ++s) {
+        if (!(Q.mask >> s & 1)) continue;
+        std::memcpy(pin_u3(f, s), u3 + 3 * (size_t)h * s, sizeof(double) * 3 * (size_t)h);
+        if (some_map) std::memcpy(pin_u8(f, s), u8 + 8 * (size_t)f->prm.fm_trials * s, sizeof(double) * 8 * (size_t)f->prm.fm_trials);
+    }
+    const int st = group_enqueue(f, k, h);
+    if (st != VOHIP_OK) {
+        f->stage = STAGE_FAILED;
+        return st;
+    }
+    f->g_h = h;
+    f->g_inflight = true;
+    return VOHIP_OK;
+}
+
+int vohip_group_finish(vohip_group *g, vohip_frame_pose *poses, vohip_frame_counts *counts, int *status)
+{
+    vohip_frame *f = g ? g->f : nullptr;
+    VOHIP_TRY(group_check(f, 0));
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, poses && counts && status, "NULL argument");
+    VOHIP_REQUIRE(ctx, f->g_inflight, "no frame is enqueued (vohip_group_begin)");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    const auto t_wait = std::chrono::steady_clock::now();
+    if (const int st = fetch_summary(f)) {
+        f->stage = STAGE_FAILED;
+        return st;
+    }
+    const double wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_wait).count();
+    f->g_inflight = false;
+    f->g_frame += 1;
+    for (int s = 0; s < f->nseq; ++s) {
+        if (f->Q.mask >> s & 1) {
+            status[s] = group_collect(f, s, f->g_h, poses + s, counts + s, wait_us);
+        } else {
+            std::memset(poses + s, 0, sizeof(*poses));
+            std::memset(counts + s, 0, sizeof(*counts));
+            status[s] = VOHIP_SEQUENCE_IDLE;
+        }
+    }
+    return VOHIP_OK;
+}
+
+int vohip_group_retry(vohip_group *g, int seq, const double *u3, int h, vohip_frame_pose *pose, vohip_frame_counts *counts)
+{
+    vohip_frame *f = g ? g->f : nullptr;
+    VOHIP_TRY(group_check(f, seq));
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, u3 && pose && counts, "NULL argument");
+    vohip_frame::seq_state &q = f->seqs[seq];
+    VOHIP_REQUIRE(ctx, !f->g_inflight && q.stage == 1, "the sequence is not waiting for more hypotheses");
+    VOHIP_REQUIRE(ctx, h > q.evaluated && h <= f->hmax, "hypothesis count must grow and stay within max_hypotheses");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    f->t_entry = std::chrono::steady_clock::now();
+    // the launches of the frame once more from the hypotheses onwards, for this sequence alone
+    const vohip_seqs Q = f->Q, Qn = f->Qn;
+    f->Q.mask = 1ull << seq;
+    f->Qn.mask = Qn.mask & (1ull << seq);
+    f->evaluated = q.evaluated;
+    std::memcpy(pin_u3(f, seq) + 3 * (size_t)q.evaluated, u3 + 3 * (size_t)q.evaluated,
+                sizeof(double) * 3 * (size_t)(h - q.evaluated));
+    int st = VOHIP_OK;
+    // (the first attempt's tracker of the kept landmarks may still read the lists the selection rewrites)
+    if (f->Qn.mask && hipStreamWaitEvent(ctx->stream, f->ev_advA[f->par ^ 1], 0) != hipSuccess)
+        st = vohip_fail(ctx, VOHIP_ERR_HIP, "hipStreamWaitEvent failed");
+    if (st == VOHIP_OK) st = enqueue_localize(f, nullptr, h, 0);
+    if (st == VOHIP_OK && f->Qn.mask) st = enqueue_tracker_kept(f);
+    if (st == VOHIP_OK) st = enqueue_tail(f);
+    if (st == VOHIP_OK && f->Qn.mask) st = enqueue_trackers_ahead(f);
+    f->Q = Q;
+    f->Qn = Qn;
+    if (st != VOHIP_OK) {
+        f->stage = STAGE_FAILED;
+        return st;
+    }
+    f->enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - f->t_entry).count();
+    const auto t_wait = std::chrono::steady_clock::now();
+    if (const int e = fetch_summary(f)) {
+        f->stage = STAGE_FAILED;
+        return e;
+    }
+    const double wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_wait).count();
+    return group_collect(f, seq, h, pose, counts, wait_us);
+}
+
+int vohip_group_sizes(vohip_group *g, int seq, int *n_landmarks, int *n_candidates, int *frames_done)
+{
+    vohip_frame *f = g ? g->f : nullptr;
+    VOHIP_TRY(group_check(f, seq));
+    if (n_landmarks) *n_landmarks = f->seqs[seq].n_L;
+    if (n_candidates) *n_candidates = f->seqs[seq].n_C;
+    if (frames_done) *frames_done = f->g_frame;
+    return VOHIP_OK;
+}
+
+int vohip_group_state(vohip_group *g, int seq, double *P_rc, double *X, double *ids, double *C_rc, double *F_rc, double *T12)
+{
+    vohip_frame *f = g ? g->f : nullptr;
+    VOHIP_TRY(group_check(f, seq));
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, !f->g_inflight && f->seqs[seq].stage != 1, "the state is complete only between frames");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t nL = f->seqs[seq].n_L, nC = f->seqs[seq].n_C;
+    hipStream_t s = f->side;   // (idle between frames; see vohip_frame_state)
+    if (P_rc && nL) VOHIP_HIP(ctx, hipMemcpyAsync(P_rc, of_seq(f, f->L_rc, seq), sizeof(double) * 2 * nL, hipMemcpyDeviceToHost, s));
+    if (X && nL) VOHIP_HIP(ctx, hipMemcpyAsync(X, of_seq(f, f->L_X, seq), sizeof(double) * 3 * nL, hipMemcpyDeviceToHost, s));
+    if (ids && nL) VOHIP_HIP(ctx, hipMemcpyAsync(ids, of_seq(f, f->L_id, seq), sizeof(double) * nL, hipMemcpyDeviceToHost, s));
+    if (C_rc && nC) VOHIP_HIP(ctx, hipMemcpyAsync(C_rc, of_seq(f, f->C_rc, seq), sizeof(double) * 2 * nC, hipMemcpyDeviceToHost, s));
+    if (F_rc && nC) VOHIP_HIP(ctx, hipMemcpyAsync(F_rc, of_seq(f, f->F_rc, seq), sizeof(double) * 2 * nC, hipMemcpyDeviceToHost, s));
+    if (T12 && nC) VOHIP_HIP(ctx, hipMemcpyAsync(T12, of_seq(f, f->T12, seq), sizeof(double) * 12 * nC, hipMemcpyDeviceToHost, s));
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
     return VOHIP_OK;
 }
 

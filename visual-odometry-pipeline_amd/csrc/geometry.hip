@@ -10,6 +10,7 @@
 #include "vohip_internal.h"
 #include "se3_device.h"
 #include "geometry_device.h"
+#include "seq_index.h"
 
 using namespace vohip_dev;
 
@@ -97,8 +98,14 @@ __global__ __launch_bounds__(FILT_THREADS) void candidate_filter_kernel(const fl
                                                                         const double *__restrict__ C_rc, int nC,
                                                                         const double *__restrict__ P_rc, int nP,
                                                                         const int *__restrict__ counts_dev, float r,
-                                                                        uint8_t *__restrict__ keep)
+                                                                        uint8_t *__restrict__ keep, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(new_xy);
+    VOHIP_SEQ_STATE(C_rc);
+    VOHIP_SEQ_STATE(P_rc);
+    VOHIP_SEQ_STATE_OPT(counts_dev);
+    VOHIP_SEQ_STATE(keep);
     __shared__ float2 sP[FILT_CHUNK];   // (col, row) of existing points
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int PER_WAVE = FILT_DET / (FILT_THREADS / 64);
@@ -183,8 +190,17 @@ __global__ __launch_bounds__(128) void candidate_triangulate_kernel(const double
                                                                     const double *__restrict__ T_dev,
                                                                     cand_params prm, uint8_t *__restrict__ status,
                                                                     double *__restrict__ X_out,
-                                                                    double *__restrict__ angles)
+                                                                    double *__restrict__ angles, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(cur_rc);
+    VOHIP_SEQ_STATE(first_rc);
+    VOHIP_SEQ_STATE(T_first);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_STATE_OPT(T_dev);
+    VOHIP_SEQ_STATE(status);
+    VOHIP_SEQ_STATE(X_out);
+    VOHIP_SEQ_STATE_OPT(angles);
     // four lanes per candidate (the triangulation is shared by the quad; the rest is cheap and repeated)
     const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
     if (i >= n) return;   // (n: the rows the arrays hold)
@@ -303,7 +319,7 @@ int vohip_candidate_filter_dev(vohip_ctx *ctx, const float *d_new_xy, int n_new,
     VOHIP_REQUIRE(ctx, (n_new == 0 || d_new_xy) && (nC == 0 || d_C_rc) && (nP == 0 || d_P_rc), "NULL array");
     if (n_new == 0) return VOHIP_OK;
     hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new + FILT_DET - 1) / FILT_DET), dim3(FILT_THREADS), 0, ctx->stream, d_new_xy, n_new,
-                       n_new, d_C_rc, nC, d_P_rc, nP, (const int *)nullptr, (float)r, d_keep);
+                       n_new, d_C_rc, nC, d_P_rc, nP, (const int *)nullptr, (float)r, d_keep, vohip_seqs());
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
@@ -313,11 +329,14 @@ int vohip_candidate_filter_dev(vohip_ctx *ctx, const float *d_new_xy, int n_new,
 // Frame-pipeline form: x and y columns `ld` apart, at most n_new_cap detections, the three counts
 // {n_new, nC, nP} in device memory.
 int vohip_candidate_filter_enqueue(vohip_ctx *ctx, const float *d_new_xy, int ld, int n_new_cap, const double *d_C_rc,
-                                   const double *d_P_rc, const int *d_counts3, double r, uint8_t *d_keep)
+                                   const double *d_P_rc, const int *d_counts3, double r, uint8_t *d_keep,
+                                   const vohip_seqs *seqs)
 {
-    if (n_new_cap <= 0) return VOHIP_OK;
-    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new_cap + FILT_DET - 1) / FILT_DET), dim3(FILT_THREADS), 0, ctx->stream, d_new_xy, ld,
-                       n_new_cap, d_C_rc, 0, d_P_rc, 0, d_counts3, (float)r, d_keep);
+    const vohip_seqs SQ = seqs ? *seqs : vohip_seqs();
+    const int ny = vohip_seq_count(SQ);
+    if (n_new_cap <= 0 || ny < 1) return VOHIP_OK;
+    hipLaunchKernelGGL(candidate_filter_kernel, dim3((n_new_cap + FILT_DET - 1) / FILT_DET, ny), dim3(FILT_THREADS), 0, ctx->stream, d_new_xy, ld,
+                       n_new_cap, d_C_rc, 0, d_P_rc, 0, d_counts3, (float)r, d_keep, SQ);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
@@ -326,9 +345,12 @@ int vohip_candidate_filter_enqueue(vohip_ctx *ctx, const float *d_new_xy, int ld
 int vohip_candidate_triangulate_enqueue(vohip_ctx *ctx, const double *d_cur_rc, const double *d_first_rc,
                                         const double *d_T_first, int n_cap, const int *d_n, const double *d_T_W_C,
                                         const double K[9], double angle_threshold_deg, double min_depth,
-                                        double max_depth, int is_BA, uint8_t *d_status, double *d_X)
+                                        double max_depth, int is_BA, uint8_t *d_status, double *d_X,
+                                        const vohip_seqs *seqs)
 {
-    if (n_cap <= 0) return VOHIP_OK;
+    const vohip_seqs SQ = seqs ? *seqs : vohip_seqs();
+    const int ny = vohip_seq_count(SQ);
+    if (n_cap <= 0 || ny < 1) return VOHIP_OK;
     cand_params prm;
     std::memset(prm.T_W_C, 0, sizeof(prm.T_W_C));
     std::memcpy(prm.K, K, sizeof(prm.K));
@@ -336,8 +358,8 @@ int vohip_candidate_triangulate_enqueue(vohip_ctx *ctx, const double *d_cur_rc, 
     prm.min_depth = min_depth;
     prm.max_depth = max_depth;
     prm.is_BA = is_BA;
-    hipLaunchKernelGGL(candidate_triangulate_kernel, dim3((n_cap + 31) / 32), dim3(128), 0, ctx->stream, d_cur_rc,
-                       d_first_rc, d_T_first, n_cap, d_n, d_T_W_C, prm, d_status, d_X, (double *)nullptr);
+    hipLaunchKernelGGL(candidate_triangulate_kernel, dim3((n_cap + 31) / 32, ny), dim3(128), 0, ctx->stream, d_cur_rc,
+                       d_first_rc, d_T_first, n_cap, d_n, d_T_W_C, prm, d_status, d_X, (double *)nullptr, SQ);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
@@ -380,7 +402,7 @@ int vohip_candidate_triangulate_dev(vohip_ctx *ctx, const double *d_cur_rc, cons
     prm.is_BA = is_BA;
     hipLaunchKernelGGL(candidate_triangulate_kernel, dim3((n + 31) / 32), dim3(128), 0, ctx->stream, d_cur_rc,
                        d_first_rc, d_T_first, n, (const int *)nullptr, (const double *)nullptr, prm, d_status, d_X,
-                       d_angles);
+                       d_angles, vohip_seqs());
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }

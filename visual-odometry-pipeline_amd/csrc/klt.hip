@@ -28,6 +28,7 @@
 //   same formulas).  G is summed in fp64; the right-hand side b is summed per lane in fp32 down the
 //   lane's column and across lanes by a fixed fp32 tree.
 #include "vohip_internal.h"
+#include "seq_index.h"
 #include "wave_reduce.h"
 
 #include <cmath>
@@ -252,8 +253,8 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int A
 
 // Tracks (pa, pb) from pyramid P to pyramid Q.  sI / sJ: this wavefront's LDS.
 template <int W>
-__device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, double min_lmin, double pa, double pb,
-                          double &qa, double &qb, float *sI, float *sJ, int &iters)
+__device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, size_t seq_floats, int max_iter, double min_lmin, double pa,
+                          double pb, double &qa, double &qb, float *sI, float *sJ, int &iters)
 {
     using C = klt_cfg<W>;
     const int lane = threadIdx.x;
@@ -270,8 +271,8 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, int max_iter, do
     const int offJ = wb0 * C::SJ + wa;
     for (int l = P.levels - 1; l >= 0; --l) {
         const int A = P.A[l], B = P.B[l];
-        const float *__restrict__ Pl = P.lvl[l];
-        const float *__restrict__ Ql = Q.lvl[l];
+        const float *__restrict__ Pl = P.lvl[l] + seq_floats;   // (the serving sequence's pyramids, see vohip_seqs)
+        const float *__restrict__ Ql = Q.lvl[l] + seq_floats;
         const double scale = 1.0 / (double)(1 << l);
         const double ca = pa * scale, cb = pb * scale;
         const double fca = floor(ca), fcb = floor(cb);
@@ -444,8 +445,10 @@ struct klt_sets {
 template <int W>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 21 ? KLT_WAVES_21 : 2, W <= 21 ? KLT_WAVES_21 : 2)))
 void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_iter, double max_bidir, double min_lmin,
-                      unsigned long long *__restrict__ stats)
+                      unsigned long long *__restrict__ stats, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    const size_t seq_floats = (size_t)(SQ.stride_prep * (unsigned long long)seq__) / sizeof(float);
     using C = klt_cfg<W>;
     __shared__ float sI[C::SI_ROWS * C::SI + 8];
     __shared__ float sJ[C::SJ * C::SJ];
@@ -471,6 +474,14 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
     const int ld = KLT_PICK(ld), base = KLT_PICK(base), out_base = KLT_PICK(out_base);
     int n = KLT_PICK(n);
 #undef KLT_PICK
+    VOHIP_SEQ_STATE(pts_xy);
+    VOHIP_SEQ_STATE(out_xy);
+    VOHIP_SEQ_STATE(valid);
+    VOHIP_SEQ_STATE_OPT(fb_err);
+    VOHIP_SEQ_STATE_OPT(rows);
+    VOHIP_SEQ_STATE_OPT(live);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_STATE_OPT(first_dev);
     if (first_dev) {   // tracks [*first_dev, *n_dev) of the list; n only sizes the grid
         i += *first_dev;
         n = *n_dev;
@@ -489,7 +500,7 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
     const double pa = swap_xy ? y : x, pb = swap_xy ? x : y;
     double qa, qb, ra, rb;
     int iters = 0;
-    const bool ok_f = track_dir<W>(P, Q, max_iter, min_lmin, pa, pb, qa, qb, sI, sJ, iters);
+    const bool ok_f = track_dir<W>(P, Q, seq_floats, max_iter, min_lmin, pa, pb, qa, qb, sI, sJ, iters);
     const bool inside = qa >= 0.0 && qa <= (double)(P.A[0] - 1) && qb >= 0.0 && qb <= (double)(P.B[0] - 1);
     // A track that is already invalid after the forward pass (untrackable at level 0, or outside the image)
     // is not tracked back: its forward-backward distance is reported as infinite.  (qa, qb are the same in
@@ -497,7 +508,7 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
     bool ok_b = false;
     double err = __builtin_inf();
     if (ok_f && inside) {
-        ok_b = track_dir<W>(Q, P, max_iter, min_lmin, qa, qb, ra, rb, sI, sJ, iters);
+        ok_b = track_dir<W>(Q, P, seq_floats, max_iter, min_lmin, qa, qb, ra, rb, sI, sJ, iters);
         const double ea = ra - pa, eb = rb - pb;
         err = sqrt(ea * ea + eb * eb);
     }
@@ -687,8 +698,11 @@ int vohip_klt_enqueue(vohip_ctx *ctx, int slot_prev, int slot_cur, const double 
 }
 
 int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vohip_klt_set *sets, int nsets,
-                           int block_size, int max_iter, double max_bidir_error)
+                           int block_size, int max_iter, double max_bidir_error, const vohip_seqs *seqs)
 {
+    const vohip_seqs SQ = seqs ? *seqs : vohip_seqs();
+    const int ny = vohip_seq_count(SQ);
+    if (ny < 1) return VOHIP_OK;
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, sets && nsets >= 1 && nsets <= 3 && max_iter >= 1, "bad argument");
     klt_sets S;
@@ -718,11 +732,11 @@ int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vo
     }
     unsigned long long *d_stats = ctx->opt_klt_stats ? (unsigned long long *)ctx->bufs[B_KLT_STATS].ptr : nullptr;
     if (block_size == 21)
-        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(total), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
-                           max_bidir_error, lmin_threshold(21), d_stats);
+        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(total, ny), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
+                           max_bidir_error, lmin_threshold(21), d_stats, SQ);
     else if (block_size == 31)
-        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(total), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
-                           max_bidir_error, lmin_threshold(31), d_stats);
+        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(total, ny), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
+                           max_bidir_error, lmin_threshold(31), d_stats, SQ);
     else
         return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "BlockSize %d not built (21 and 31 are)", block_size);
     VOHIP_HIP(ctx, hipGetLastError());

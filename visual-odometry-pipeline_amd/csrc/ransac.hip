@@ -55,6 +55,7 @@
 //   SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
 #include "vohip_internal.h"
 #include "inlier_test.h"
+#include "seq_index.h"
 #include "ordered_select.h"
 
 #include <cmath>
@@ -380,8 +381,16 @@ __global__ __launch_bounds__(64) void p3p_solve_kernel(const double *__restrict_
                                                        const int32_t *__restrict__ samples, int h,
                                                        double *__restrict__ Rt_out,
                                                        double *__restrict__ M_out,
-                                                       int32_t *__restrict__ zero_counts)
+                                                       int32_t *__restrict__ zero_counts, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(kp_rc);
+    VOHIP_SEQ_STATE(X);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_STATE(samples);
+    VOHIP_SEQ_STATE(Rt_out);
+    VOHIP_SEQ_STATE(M_out);
+    VOHIP_SEQ_STATE_OPT(zero_counts);
     // four lanes per hypothesis: the part the four solutions share is computed by each of them (same
     // operations, same bits), then every lane finishes ONE solution -- the dependent chain of a lane is
     // what this launch lasts, and the four back-substitutions were more than half of it
@@ -439,8 +448,27 @@ __device__ __forceinline__ unsigned nonzero_bytes_to_bits(unsigned w)
 __global__ __launch_bounds__(256) void p3p_solve_select_kernel(vohip_select_tracked S, vohip_K K, int h, int nb_solve,
                                                                double *__restrict__ Rt_out,
                                                                double *__restrict__ M_out,
-                                                               int32_t *__restrict__ zero_counts)
+                                                               int32_t *__restrict__ zero_counts, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(S.out_xy);
+    VOHIP_SEQ_STATE(S.valid);
+    VOHIP_SEQ_STATE(S.L_X);
+    VOHIP_SEQ_STATE(S.L_id);
+    VOHIP_SEQ_STATE(S.mv_rc);
+    VOHIP_SEQ_STATE(S.Xv);
+    VOHIP_SEQ_STATE(S.idv);
+    VOHIP_SEQ_STATE(S.rowv);
+    VOHIP_SEQ_STATE(S.n_valid);
+    VOHIP_SEQ_STATE(S.idx);
+    VOHIP_SEQ_STATE(S.idx_next);
+    VOHIP_SEQ_STATE(S.samples);
+    VOHIP_SEQ_STATE_OPT(S.n_dev);
+    VOHIP_SEQ_PIN(S.u3);
+    VOHIP_SEQ_STATE(Rt_out);
+    VOHIP_SEQ_STATE(M_out);
+    VOHIP_SEQ_STATE_OPT(zero_counts);
+    if (S.n_dev) S.n = min(S.n, *S.n_dev);   // (a group of loops: the count of each is known on the device only)
     __shared__ int sh[12];
     __shared__ int sPref[SEL_GROUPS];
     __shared__ unsigned short sMask[SEL_GROUPS];
@@ -609,9 +637,15 @@ constexpr int SCORE_WAVES = 8;  // default hypotheses per workgroup (chunk granu
 template <int WAVES, int TILE>
 __global__ __launch_bounds__(WAVES * 64) void p3p_score_kernel(
     const double *__restrict__ kp_rc, const double *__restrict__ X, int n, const int *__restrict__ n_dev,
-    const double *__restrict__ M, int h, int32_t *__restrict__ counts)
+    const double *__restrict__ M, int h, int32_t *__restrict__ counts, vohip_seqs SQ)
 {
     constexpr int NT = WAVES * 64;
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(kp_rc);
+    VOHIP_SEQ_STATE(X);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_STATE(M);
+    VOHIP_SEQ_STATE(counts);
     if (n_dev) n = *n_dev;
     constexpr int PER_X = (3 * TILE + NT - 1) / NT;
     constexpr int PER_K = (2 * TILE + NT - 1) / NT;
@@ -727,8 +761,14 @@ __global__ __launch_bounds__(256) void p3p_score_split_kernel(const double *__re
                                                               const double *__restrict__ X, int n,
                                                               const int *__restrict__ n_dev,
                                                               const double *__restrict__ M, int h, int split,
-                                                              int32_t *__restrict__ counts)
+                                                              int32_t *__restrict__ counts, vohip_seqs SQ)
 {
+    const int seq__ = vohip_dev::seq_index(SQ);
+    VOHIP_SEQ_STATE(kp_rc);
+    VOHIP_SEQ_STATE(X);
+    VOHIP_SEQ_STATE_OPT(n_dev);
+    VOHIP_SEQ_STATE(M);
+    VOHIP_SEQ_STATE(counts);
     if (n_dev) n = *n_dev;
     const int lane = threadIdx.x & 63;
     const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -856,21 +896,21 @@ int launch_solve(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n
     const vohip_K Kv = vohip_make_K(K);
     hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n,
                        (const int *)nullptr, Kv, d_samples, h, (double *)ctx->bufs[B_RANSAC_RT].ptr,
-                       (double *)ctx->bufs[B_RANSAC_M].ptr, (int32_t *)nullptr);
+                       (double *)ctx->bufs[B_RANSAC_M].ptr, (int32_t *)nullptr, vohip_seqs());
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
 
 template <int WAVES, int TILE>
 void launch_score_t(hipStream_t st, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
-                    const double *d_M, int h, int32_t *d_counts)
+                    const double *d_M, int h, int32_t *d_counts, const vohip_seqs &SQ)
 {
-    hipLaunchKernelGGL((p3p_score_kernel<WAVES, TILE>), dim3((h + WAVES - 1) / WAVES), dim3(WAVES * 64), 0, st,
-                       d_kp_rc, d_X, n, d_n, d_M, h, d_counts);
+    hipLaunchKernelGGL((p3p_score_kernel<WAVES, TILE>), dim3((h + WAVES - 1) / WAVES, vohip_seq_count(SQ)), dim3(WAVES * 64), 0,
+                       st, d_kp_rc, d_X, n, d_n, d_M, h, d_counts, SQ);
 }
 
 int launch_score_variant(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const double *d_M,
-                         int h, int32_t *d_counts, const int *d_n = nullptr)
+                         int h, int32_t *d_counts, const int *d_n = nullptr, const vohip_seqs &SQ = vohip_seqs())
 {
     // Geometry: many hypotheses -> 16 per workgroup share each staged tile (fewest L2->LDS bytes);
     // few hypotheses -> small workgroups so that more CUs take part.  Measured on MI355X:
@@ -878,12 +918,12 @@ int launch_score_variant(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
     int variant = ctx->opt_ransac_variant;
     if (variant < 0) variant = h >= 2048 ? 2 : (h < 512 ? 3 : 0);
     switch (variant) {
-    case 1: launch_score_t<8, 512>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
-    case 2: launch_score_t<16, 1024>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
-    case 3: launch_score_t<4, 512>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
-    case 4: launch_score_t<16, 512>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
-    case 5: launch_score_t<4, 256>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
-    default: launch_score_t<8, 1024>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts); break;
+    case 1: launch_score_t<8, 512>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts, SQ); break;
+    case 2: launch_score_t<16, 1024>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts, SQ); break;
+    case 3: launch_score_t<4, 512>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts, SQ); break;
+    case 4: launch_score_t<16, 512>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts, SQ); break;
+    case 5: launch_score_t<4, 256>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts, SQ); break;
+    default: launch_score_t<8, 1024>(ctx->stream, d_kp_rc, d_X, n, d_n, d_M, h, d_counts, SQ); break;
     }
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
@@ -899,8 +939,11 @@ int launch_count(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n
 // Solve + score hypotheses [first, first + h) for points whose count may live on the device.
 int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                          const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts,
-                         double *d_Rt_all, double *d_M_all, const vohip_select_tracked *select)
+                         double *d_Rt_all, double *d_M_all, const vohip_select_tracked *select, const vohip_seqs *seqs)
 {
+    const vohip_seqs SQ = seqs ? *seqs : vohip_seqs();
+    const int ny = vohip_seq_count(SQ);
+    if (ny < 1) return VOHIP_OK;
     // the candidate poses go to the caller's arrays (48 doubles per hypothesis each, hypothesis 0 first)
     VOHIP_REQUIRE(ctx, d_Rt_all && d_M_all, "NULL pose buffers");
     double *d_Rt = d_Rt_all + (size_t)first * 48;
@@ -915,20 +958,20 @@ int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
                                (reinterpret_cast<uintptr_t>(select->valid) & 15) == 0,
                       "the selection cannot ride with these hypotheses");
         const int nb_solve = (4 * h + 255) / 256, nb_select = select->n < 1 ? 1 : (select->n + 255) / 256;
-        hipLaunchKernelGGL(p3p_solve_select_kernel, dim3(nb_solve + nb_select), dim3(256), 0, ctx->stream, *select, Kv, h,
-                           nb_solve, d_Rt, d_M, split_points ? d_counts : (int32_t *)nullptr);
+        hipLaunchKernelGGL(p3p_solve_select_kernel, dim3(nb_solve + nb_select, ny), dim3(256), 0, ctx->stream, *select, Kv, h,
+                           nb_solve, d_Rt, d_M, split_points ? d_counts : (int32_t *)nullptr, SQ);
     } else {
-        hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n, d_n, Kv,
+        hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16, ny), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n, d_n, Kv,
                            d_samples + 3 * (size_t)first, h, d_Rt, d_M,
-                           split_points ? d_counts + 4 * (size_t)first : (int32_t *)nullptr);
+                           split_points ? d_counts + 4 * (size_t)first : (int32_t *)nullptr, SQ);
     }
     if (split_points) {
         const int split = 1024 / h < 1 ? 1 : (1024 / h > 16 ? 16 : 1024 / h);
-        hipLaunchKernelGGL(p3p_score_split_kernel, dim3((h * split + 3) / 4), dim3(256), 0, ctx->stream, d_kp_rc, d_X, n,
-                           d_n, d_M, h, split, d_counts + 4 * (size_t)first);
+        hipLaunchKernelGGL(p3p_score_split_kernel, dim3((h * split + 3) / 4, ny), dim3(256), 0, ctx->stream, d_kp_rc, d_X, n,
+                           d_n, d_M, h, split, d_counts + 4 * (size_t)first, SQ);
         VOHIP_HIP(ctx, hipGetLastError());
     } else {
-        VOHIP_TRY(launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, h, d_counts + 4 * (size_t)first, d_n));
+        VOHIP_TRY(launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, h, d_counts + 4 * (size_t)first, d_n, SQ));
     }
     return VOHIP_OK;
 }
@@ -1011,7 +1054,7 @@ int vohip_ransac_p3p_score_noalloc(vohip_ctx *ctx, const double *d_kp_rc, const 
     double *d_M = d_Rt + (size_t)NOALLOC_MAX_H * 48;
     const vohip_K Kv = vohip_make_K(K);
     hipLaunchKernelGGL(p3p_solve_kernel, dim3((h + 15) / 16), dim3(64), 0, ctx->stream, d_kp_rc, d_X, n,
-                       (const int *)nullptr, Kv, d_samples, h, d_Rt, d_M, (int32_t *)nullptr);
+                       (const int *)nullptr, Kv, d_samples, h, d_Rt, d_M, (int32_t *)nullptr, vohip_seqs());
     VOHIP_HIP(ctx, hipGetLastError());
     return launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, h, d_counts);
 }
@@ -1101,7 +1144,7 @@ int vohip_ransac_p3p(vohip_ctx *ctx, const double *kp_rc, const double *X, int n
             if (want > hcap - evaluated) want = hcap - evaluated;
             hipLaunchKernelGGL(p3p_solve_kernel, dim3((want + 15) / 16), dim3(64), 0, st, d_kp, d_X, n,
                                (const int *)nullptr, Kv, d_samples + 3 * (size_t)evaluated, want, d_Rt + (size_t)evaluated * 48,
-                               d_M + (size_t)evaluated * 48, (int32_t *)nullptr);
+                               d_M + (size_t)evaluated * 48, (int32_t *)nullptr, vohip_seqs());
             VOHIP_TRY(launch_score_variant(ctx, d_kp, d_X, n, d_M + (size_t)evaluated * 48, want,
                                            d_counts + 4 * (size_t)evaluated));
             VOHIP_HIP(ctx, hipMemcpyAsync(h_counts + 4 * (size_t)evaluated, d_counts + 4 * (size_t)evaluated,

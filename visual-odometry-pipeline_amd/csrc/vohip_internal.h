@@ -65,6 +65,21 @@ struct vohip_ctx {
     unsigned harris_calls = 0;    // uses of B_HARRIS_SCRATCH (its two maximum slots alternate)
 };
 
+// The independent sequences one launch of a frame-loop kernel serves (a group of loops advanced in lockstep,
+// vohip_group_*).  A kernel of the loop is launched with gridDim.y = the number of bits set in `mask`; the
+// workgroups with blockIdx.y = j work on the sequence whose index is the position of the j-th set bit, and
+// find its arrays by adding index * stride to the pointers they were given (those of sequence 0): the
+// per-sequence state blocks, pinned staging blocks and prepared-sequence blocks all have one layout and lie a
+// constant number of bytes apart.  A single loop is the group {sequence 0}: mask 1, gridDim.y 1, offsets 0.
+constexpr int VOHIP_MAX_SEQ = 64;
+struct vohip_seqs {
+    unsigned long long stride_state = 0;   // bytes between the device state blocks of consecutive sequences
+    unsigned long long stride_pin = 0;     // ... between their pinned host blocks (draws in, summary out)
+    unsigned long long stride_prep = 0;    // ... between their prepared data (images, pyramids, corner lists)
+    unsigned long long mask = 1;
+};
+static inline int vohip_seq_count(const vohip_seqs &q) { return __builtin_popcountll(q.mask); }
+
 int vohip_fail(vohip_ctx *ctx, int status, const char *fmt, ...);
 int vohip_reserve(vohip_ctx *ctx, vohip_buf &b, size_t bytes);
 int vohip_reserve_pinned(vohip_ctx *ctx, vohip_buf &b, size_t bytes);
@@ -127,8 +142,10 @@ struct vohip_klt_set {
 };
 // Up to three sets in one launch (a launch lasts as long as its slowest track however many tracks
 // it carries).
+// `seqs` (may be NULL: a single sequence): the sequences of a group the launch serves; the sets then name the
+// arrays of sequence 0 and the pyramid slots show sequence 0's pyramids.
 int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vohip_klt_set *sets, int nsets,
-                           int block_size, int max_iter, double max_bidir_error);
+                           int block_size, int max_iter, double max_bidir_error, const vohip_seqs *seqs = nullptr);
 // The ordered selection of the valid landmark tracks (main_demo.m:380-381, :387) as it rides in the launch
 // that solves a frame's first hypotheses: track i of the table (x column then y column, leading dimension
 // ld) with valid[i] != 0 goes, in order, to mv_rc (row, col), Xv, idv and rowv; *n_valid receives their
@@ -148,27 +165,31 @@ struct vohip_select_tracked {
     const double *u3;
     int h0;
     int32_t *samples;
+    const int *n_dev;   // may be NULL; else the table holds min(n, *n_dev) tracks (n then only sizes the grid)
 };
 // `select` (may be NULL): see vohip_select_tracked; then first must be 0, h <= select->h0 and d_kp_rc, d_X, d_n
 // name the lists the selection writes.
 int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                          const double K[9], const int32_t *d_samples, int first, int h, int32_t *d_counts,
-                         double *d_Rt_all, double *d_M_all, const vohip_select_tracked *select);
+                         double *d_Rt_all, double *d_M_all, const vohip_select_tracked *select,
+                         const vohip_seqs *seqs = nullptr);
 int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                               const double *d_M12, uint8_t *d_mask);
 double vohip_ransac_adaptive_iterations(int max_num_inliers, int n);
 int vohip_ransac_scratch_init(vohip_ctx *ctx);   // once per device, with that device current
 int vohip_fm_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int *d_n,
                      const int32_t *d_samples, int num_trials, double threshold, double *d_nrm, double *d_F,
-                     int32_t *d_counts);
+                     int32_t *d_counts, const vohip_seqs *seqs = nullptr);
 int vohip_fm_mask_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int *d_n,
                           const double *d_F9, double threshold, uint8_t *d_mask);
 int vohip_candidate_filter_enqueue(vohip_ctx *ctx, const float *d_new_xy, int ld, int n_new_cap, const double *d_C_rc,
-                                   const double *d_P_rc, const int *d_counts3, double r, uint8_t *d_keep);
+                                   const double *d_P_rc, const int *d_counts3, double r, uint8_t *d_keep,
+                                   const vohip_seqs *seqs = nullptr);
 int vohip_candidate_triangulate_enqueue(vohip_ctx *ctx, const double *d_cur_rc, const double *d_first_rc,
                                         const double *d_T_first, int n_cap, const int *d_n, const double *d_T_W_C,
                                         const double K[9], double angle_threshold_deg, double min_depth,
-                                        double max_depth, int is_BA, uint8_t *d_status, double *d_X);
+                                        double max_depth, int is_BA, uint8_t *d_status, double *d_X,
+                                        const vohip_seqs *seqs = nullptr);
 size_t vohip_corner_scratch_bytes(int rows, int cols);
 int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, unsigned *calls, const uint8_t *d_img,
                                  int rows, int cols, int colmajor, double min_quality, int filter_size, int border,
@@ -180,7 +201,7 @@ int vohip_detect_corners_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, in
                                        float *d_metric, int cap, int *d_counts);
 int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, const double *d_X, int n,
                               const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
-                              double *d_stats);
+                              double *d_stats, const vohip_seqs *seqs = nullptr);
 
 vohip_ctx *vohip_window_context(vohip_window *w);
 

@@ -292,3 +292,228 @@ class VOPipelineDevice:
             self.close()
         except Exception:
             pass
+
+
+class VOGroupDevice:
+    """Several independent loops of one image shape, camera matrix and parameter set, advanced in lockstep:
+    one library call (vohip_group_begin / _finish) per frame for ALL of them, every kernel launched once with
+    the sequence as a grid dimension.  This is how the independent runs of main_eval.m:22-23 (feature variant x
+    repetition, each the loop of main_demo.m:377-427 over a stored sequence) share one GPU: a single loop
+    leaves most of it idle and is bound by launch latencies and the host's enqueue work, which a group shares.
+
+    Every sequence keeps its own two generators and its own state; its counts, ids and poses are those of a
+    VOPipelineDevice run over the same images with the same generators, bit for bit.
+
+    add_sequence(images, ...): images[0] is the image the loop starts from (main_demo.m:342-344: the last
+    bootstrap image), images[1:] are its frames; all of them go to the GPU at once, with their pyramids and
+    corner lists from batched launches.  run() processes every frame of every sequence; step() one frame."""
+
+    def __init__(self, K, image_shape, n_sequences, max_frames, hyper_paras=None, ctx=None, tracker_options=None,
+                 cap_landmarks=8192, cap_candidates=8192, cap_corners=16384, colmajor_images=False):
+        self.ctx = ctx or _lib.default_context()
+        self.K = np.asarray(K, dtype=np.float64)
+        self.hp = hyper_paras or default_hyper_paras()
+        if self.hp.is_BA:
+            raise NotImplementedError("bundle adjustment is not available in a group of loops")
+        if self.hp.feature_extract not in ("Harris", "MinEigen"):
+            raise NotImplementedError("a group of loops reads prepared corner lists: Harris or MinEigen")
+        lib = _lib.load()
+        prm = _lib.FrameParams()
+        lib.vohip_frame_default_params(C.byref(prm))
+        opts = dict(BlockSize=[21, 21], NumPyramidLevels=5, MaxIterations=20, MaxBidirectionalError=6)  # main_demo.m:342-349
+        opts.update(tracker_options or {})
+        prm.klt_block = int(np.atleast_1d(opts["BlockSize"])[0])
+        prm.klt_levels = int(opts["NumPyramidLevels"])
+        prm.klt_max_iter = int(opts["MaxIterations"])
+        e = float(opts["MaxBidirectionalError"])
+        prm.klt_max_bidir_error = e if np.isfinite(e) else 1e300
+        fo = dict(zip(self.hp.feature_extract_options[::2], self.hp.feature_extract_options[1::2]))
+        prm.detector = DETECTORS[self.hp.feature_extract]
+        prm.min_quality = float(fo.get("MinQuality", DEFAULT_MIN_QUALITY[self.hp.feature_extract]))
+        prm.filter_size = int(fo.get("FilterSize", 5))
+        prm.r_discard_redundant = float(self.hp.r_discard_redundant)
+        prm.angle_threshold_deg = float(self.hp.angle_threshold)
+        prm.min_depth = float(self.hp.min_depth)
+        prm.max_depth = float(self.hp.max_depth)
+        prm.refine_pose = int(bool(self.hp.is_refine_pose))
+        prm.is_BA = 0
+        prm.cap_landmarks, prm.cap_candidates, prm.cap_corners = int(cap_landmarks), int(cap_candidates), int(cap_corners)
+        free = self.ctx.__dict__.setdefault("_free_pyr_slots", list(range(16)))
+        if len(free) < 3:
+            raise RuntimeError("the context has fewer than 3 free pyramid slots")
+        self._slots = [free.pop(), free.pop(), free.pop()]
+        prm.slot_a, prm.slot_b, prm.slot_c = self._slots
+        self.params = prm
+        self._shape = tuple(image_shape)
+        self._colmajor = int(bool(colmajor_images))
+        self.n_sequences = int(n_sequences)
+        self.max_frames = int(max_frames)
+        h = C.c_void_p()
+        self.ctx.check(lib.vohip_group_create(self.ctx.handle, dptr(colmajor(self.K)), self._shape[0], self._shape[1],
+                                              self._colmajor, C.byref(prm), self.n_sequences, self.max_frames, C.byref(h)))
+        self._h = h
+        _lib._live_frames.add(self)
+        self.first_hypotheses = 104
+        self.seqs = [None] * self.n_sequences
+        self.frames = 0                 # frames processed by the run under way
+        self.host_enqueue_us = 0.0      # summed over the frames of the run
+        self.host_wait_us = 0.0
+
+    def add_sequence(self, seq, images, p_W_landmarks, keypoints_xy, T_init_WC, rng=None, rng_map=None,
+                     feature_extract=None, min_quality=None):
+        """Sequence `seq` of the group: its stored images, the state its loop starts from (as VOPipelineDevice's
+        constructor takes it) and its generators.  feature_extract / min_quality: this sequence's detector when it
+        differs from the group's (the feature variants of main_eval.m:165-174)."""
+        if self.frames:
+            self.frames = 0   # (the library starts a new run with the first reset after a frame)
+            self.host_enqueue_us = self.host_wait_us = 0.0
+            self.seqs = [None] * self.n_sequences
+        lib = _lib.load()
+        if len(images) < 2 or len(images) > self.max_frames:
+            raise ValueError("a sequence holds 2..max_frames images")
+        ptrs, keep, on_dev = [], [], None
+        for im in images:
+            if hasattr(im, "data_ptr"):
+                if tuple(im.shape) != self._shape:
+                    raise ValueError("image shape differs from the group's")
+                ptr, dev, k = im.data_ptr(), 1, im
+            else:
+                img = np.asarray(im)
+                if img.dtype != np.uint8 or img.shape != self._shape:
+                    raise TypeError("images must be uint8 arrays of shape %s" % (self._shape,))
+                img = np.asfortranarray(img) if self._colmajor else np.ascontiguousarray(img)
+                ptr, dev, k = img.ctypes.data, 0, img
+            if on_dev is None:
+                on_dev = dev
+            if dev != on_dev:
+                raise ValueError("host and device images cannot be mixed in one sequence")
+            ptrs.append(ptr)
+            keep.append(k)
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        det = -1 if feature_extract is None else DETECTORS[feature_extract]
+        if det not in (-1, 0, 1):
+            raise NotImplementedError("a group of loops reads prepared corner lists: Harris or MinEigen")
+        mq = float(min_quality) if min_quality is not None else (
+            DEFAULT_MIN_QUALITY[feature_extract] if feature_extract is not None else 0.0)
+        self.ctx.check(lib.vohip_group_prepare(self._h, int(seq), arr, len(ptrs), int(on_dev), det, mq, 0.0))
+        X = np.ascontiguousarray(np.asarray(p_W_landmarks, dtype=np.float64).reshape(-1, 3))
+        P_rc = np.ascontiguousarray(np.asarray(keypoints_xy, dtype=np.float64).reshape(-1, 2)[:, ::-1])
+        T = np.asarray(T_init_WC, dtype=np.float64)
+        self.ctx.check(lib.vohip_group_reset(self._h, int(seq), dptr(X), None, dptr(P_rc), X.shape[0], dptr(colmajor(T))))
+        rng = rng or np.random.default_rng()
+        rng_map = rng_map or rng.spawn(1)[0]
+        self.seqs[seq] = SimpleNamespace(
+            n_frames=len(images), rng=rng, rng_map=rng_map,
+            rewind=type(rng.bit_generator).__name__ in ("PCG64", "PCG64DXSM"),
+            est_trans=[T[:3, 3].copy()], est_rot=[T[:3, :3].reshape(-1, order="F").copy()],
+            num_X=[X.shape[0]], num_C=[0], num_new=[0], error=None, last_pose=None, last_counts=None)
+
+    def active(self):
+        """Indices of the sequences that take part in the next frame."""
+        k = self.frames + 1
+        return [i for i, q in enumerate(self.seqs) if q is not None and q.error is None and k < q.n_frames]
+
+    def step(self):
+        """One frame of every active sequence.  Returns {sequence: T_W_C}; a sequence whose frame fails (where
+        the reference's script stops with an error, main_demo.m:389-391) records the exception in
+        seqs[i].error and takes no further part."""
+        lib = _lib.load()
+        act = self.active()
+        if not act:
+            raise RuntimeError("no sequence of the group has a frame left")
+        S, T = self.n_sequences, self.params.fm_trials
+        have = int(self.first_hypotheses)
+        have_map = self.seqs[act[0]].num_C[-1] > 0                                          # main_demo.m:406
+        u3 = np.zeros((S, have, 3))
+        u8 = np.zeros((S, T, 8)) if have_map else None
+        states = {}
+        for i in act:
+            q = self.seqs[i]
+            if have_map:                                                                    # update_landmarks.m:13
+                u8[i] = q.rng_map.random((T, 8))
+            states[i] = None if q.rewind else q.rng.bit_generator.state
+            u3[i] = q.rng.random((have, 3))                                                 # :387-388
+        self.ctx.check(lib.vohip_group_begin(self._h, dptr(u3), have, dptr(u8) if have_map else None))
+        poses = (_lib.FramePose * S)()
+        counts = (_lib.FrameCounts * S)()
+        status = (C.c_int * S)()
+        self.ctx.check(lib.vohip_group_finish(self._h, poses, counts, status))
+        self.frames += 1
+        out = {}
+        for i in act:
+            q = self.seqs[i]
+            st, pose, cnt = status[i], poses[i], counts[i]
+            drawn, state = have, states[i]
+            while st == VOHIP_SAMPLES_EXHAUSTED and drawn < MAX_ITERATIONS:
+                more = min(max(8 * drawn, int(np.ceil(pose.num_iterations)) + 8), MAX_ITERATIONS)
+                if state is None:
+                    q.rng.bit_generator.advance(-3 * drawn)
+                else:
+                    q.rng.bit_generator.state = state
+                u = q.rng.random((more, 3))         # the same leading draws, then more
+                drawn = more
+                pose, cnt = _lib.FramePose(), _lib.FrameCounts()
+                st = lib.vohip_group_retry(self._h, i, dptr(u), more, C.byref(pose), C.byref(cnt))
+            # the generator as n_iter executed iterations leave it (ransacLocalization.m:46-47)
+            if state is None:
+                if drawn != pose.n_iter:
+                    q.rng.bit_generator.advance(-3 * (drawn - max(pose.n_iter, 0)))
+            else:
+                q.rng.bit_generator.state = state
+                if pose.n_iter > 0:
+                    q.rng.random((pose.n_iter, 3))
+            q.last_pose, q.last_counts = pose, cnt
+            if st != 0:
+                msg = "sequence %d stopped in frame %d (%s)" % (i, self.frames, _lib.STATUS_NAMES.get(st, st))
+                q.error = RuntimeError(msg) if st == VOHIP_NO_MODEL else _lib.VohipError(st, msg)
+                continue
+            T_W_C = np.array(pose.T_W_C).reshape(4, 4).T.copy()
+            q.est_trans.append(T_W_C[:3, 3].copy())                                         # :401-403
+            q.est_rot.append(T_W_C[:3, :3].reshape(-1, order="F").copy())
+            if have_map:
+                q.num_new.append(cnt.num_new)                                               # update_landmarks.m:124
+            q.num_X.append(cnt.n_landmarks)                                                 # :426-427
+            q.num_C.append(cnt.n_candidates)
+            out[i] = T_W_C
+        i0 = act[0]
+        self.host_enqueue_us += counts[i0].host_enqueue_us
+        self.host_wait_us += counts[i0].host_wait_us
+        return out
+
+    def run(self):
+        """Every frame of every sequence.  Returns the number of (sequence, frame) pairs processed."""
+        done = 0
+        while self.active():
+            done += len(self.step())
+        return done
+
+    def trajectory(self, seq):
+        q = self.seqs[seq]
+        return np.array(q.est_trans).T.copy(), np.array(q.est_rot).T.copy()
+
+    def S(self, seq):
+        """The state struct of main_demo.m:272-286 of sequence `seq`, downloaded from the GPU."""
+        lib = _lib.load()
+        q = self.seqs[seq]
+        nL, nC = C.c_int(0), C.c_int(0)
+        self.ctx.check(lib.vohip_group_sizes(self._h, int(seq), C.byref(nL), C.byref(nC), None))
+        nL, nC = nL.value, nC.value
+        P, X, ids = np.zeros((max(nL, 1), 2)), np.zeros((max(nL, 1), 3)), np.zeros(max(nL, 1))
+        Cc, F, T = np.zeros((max(nC, 1), 2)), np.zeros((max(nC, 1), 2)), np.zeros((max(nC, 1), 12))
+        self.ctx.check(lib.vohip_group_state(self._h, int(seq), dptr(P), dptr(X), dptr(ids), dptr(Cc), dptr(F), dptr(T)))
+        et, er = self.trajectory(seq)
+        return SimpleNamespace(P=P[:nL].T.copy(), X=np.vstack([X[:nL].T, ids[:nL]]), C=Cc[:nC].T.copy(), F=F[:nC].T.copy(),
+                               T=T[:nC].T.copy(), est_trans=et, est_rot=er, num_X=list(q.num_X), num_C=list(q.num_C),
+                               num_new=list(q.num_new))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None:
+            _lib.load().vohip_group_destroy(self._h)
+            self._h = None
+            self.ctx.__dict__.setdefault("_free_pyr_slots", []).extend(self._slots)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
