@@ -27,6 +27,31 @@ for k, r in enumerate(recs):
     assert abs(r["fps"] - (2 + k) / (0.5 * (k + 1))) < 1e-12 and r["num_C"][0] == 20
 mine = batch.shard(list(range(5)), dist.get_rank(), dist.get_world_size())
 assert mine == ([0, 2, 4] if dist.get_rank() == 0 else [1, 3])
+# longest first: one long run and six short ones -- rank 0 holds 1 item, rank 1 holds 6 (more than
+# ceil(7 / 2) slots), records of different lengths, one run failed, the share run as a whole
+items = ["long"] + ["short%%d" %% k for k in range(6)]
+costs = [60, 10, 10, 10, 10, 10, 10]
+def runner2(item_id, item):
+    if item_id == 4:
+        return batch.failed_record(item_id, 0.25)
+    T = costs[item_id] // 2
+    et = np.full((3, T), float(item_id)); er = np.tile(np.eye(3).reshape(9, 1), (1, T))
+    return batch.pack_record(item_id, 1.0, et, er, [item_id] * T, [2] * T, [3] * T, errs=np.full((3, item_id %% 4), 0.5))
+seen = []
+def share_runner(mine):
+    seen.extend(i for i, _ in mine)
+    return [runner2(i, it) for i, it in mine]
+timing = {}
+recs = batch.run_batch(items, None, costs=costs, share_runner=share_runner, timing=timing)
+assert seen == ([0] if dist.get_rank() == 0 else [1, 2, 3, 4, 5, 6]), seen
+assert timing["items"] == len(seen) and timing["gather_s"] >= 0.0
+assert len(recs) == 7 and all(r is not None for r in recs)
+for k, r in enumerate(recs):
+    assert r["item"] == k and r["failed"] == (k == 4)
+    if k != 4:
+        assert r["frames"] == costs[k] // 2 and r["num_X"][0] == k and r["errs"].shape == (3, k %% 4)
+    else:
+        assert r["frames"] == 0 and r["est_trans"].shape == (3, 0)
 dist.barrier()
 dist.destroy_process_group()
 print("rank ok")
@@ -60,3 +85,13 @@ def test_record_roundtrip_and_single_process(vo):
     recs = b.run_batch(["a", "b"], lambda i, it: b.pack_record(i, 1.0, et, er, range(7), range(7), range(7)))
     assert [x["item"] for x in recs] == [0, 1]
     assert b.shard(list(range(7)), 1, 3) == [1, 4]
+    # longest first: every item lands on exactly one rank whatever the number of ranks, shares keep item order,
+    # and 20 runs of unequal length on 8 ranks end within one short run of each other
+    costs = [540] * 4 + [270] * 8 + [135] * 8
+    for world in (1, 2, 3, 8):
+        shares = [b.shard(list(range(20)), r, world, costs) for r in range(world)]
+        assert sorted(sum(shares, [])) == list(range(20)) and all(s == sorted(s) for s in shares)
+        loads = [sum(costs[k] for k in s) for s in shares]
+        assert max(loads) - min(loads) <= 270, (world, loads)
+    assert max(sum(costs[k] for k in b.shard(list(range(20)), r, 8, costs)) for r in range(8)) == 675
+    assert max(sum(costs[k] for k in b.shard(list(range(20)), r, 8)) for r in range(8)) == 945   # (round-robin)

@@ -102,6 +102,16 @@ def test_main_eval_grid_is_independent_of_world_size(vo, ctx, tmp_path):
     for k in range(4):
         for key in ("est_trans", "est_rot", "num_X", "num_C", "num_new", "errs"):
             np.testing.assert_array_equal(whole[k][key], together[k][key], err_msg="concurrent %d %s" % (k, key))
+    # ... and of whether its loop advances alone or in a group of loops in lockstep (the Harris and MinEigen
+    # runs of both sequences in one group, three at a time; the FAST runs one by one)
+    feats3 = ("Harris", "FAST", "MinEigen")
+    alone = vo.main_eval(sequences, feats=feats3, repetition=1, save_dir=str(tmp_path / "w4"), seed=9, ctx=ctx)
+    grouped = vo.main_eval(sequences, feats=feats3, repetition=1, save_dir=str(tmp_path / "w5"), seed=9, ctx=ctx, group=3)
+    for k in range(6):
+        for key in ("est_trans", "est_rot", "num_X", "num_C", "num_new", "errs", "frame_ct", "frame_init"):
+            np.testing.assert_array_equal(alone[k][key], grouped[k][key], err_msg="grouped %d %s" % (k, key))
+        assert grouped[k]["fps_ct"] > 0 and grouped[k]["toc_ct"] > 0 and grouped[k]["feat"] == feats3[k % 3]
+    assert len(glob.glob(str(tmp_path / "w5" / "*_res.mat"))) == 6
     # the two feature variants are different runs
     assert not np.array_equal(whole[0]["num_C"], whole[1]["num_C"])
     for d in ("w1", "w2", "w3"):
@@ -134,3 +144,11 @@ def test_main_eval_records_a_failed_run(vo, ctx, tmp_path):
         assert [r["failed"] for r in recs] == [True, True, False, False]
         assert recs[0]["frames"] == 0 and recs[0]["est_trans"].shape == (3, 0) and recs[0]["sequence"] == "blank"
         assert recs[2]["frames"] == 8 and recs[2]["fps_ct"] > 0 and recs[2]["errs"].shape[0] == 3
+    # the same grid with the four loops in one group: the failed runs stop, the others' records do not change
+    grouped = vo.main_eval(sequences, feats=("Harris",), repetition=2, seed=9, ctx=ctx, on_error="record", group=4)
+    assert [r["failed"] for r in grouped] == [True, True, False, False]
+    for k in (2, 3):
+        for key in ("est_trans", "est_rot", "num_X", "num_C", "num_new", "errs"):
+            np.testing.assert_array_equal(recs[k][key], grouped[k][key], err_msg="%d %s" % (k, key))
+    with pytest.raises((RuntimeError, vo.VohipError)):
+        vo.main_eval(sequences, feats=("Harris",), repetition=2, seed=9, ctx=ctx, group=4)

@@ -1,0 +1,68 @@
+"""Throughput of a group of loops (VOGroupDevice) on the headline workload: S sequences of the KITTI-shape
+rendered corridor advanced in lockstep, aggregate frames/s against the single loop's.
+python tools/group_loop.py [--frames 60] [--seqs 1,2,4,8,16] [--distinct]"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--seqs", default="1,2,4,8,16")
+    ap.add_argument("--distinct", action="store_true", help="every sequence its own rendered corridor")
+    args = ap.parse_args()
+    import torch
+    vo = importlib.import_module("visual_odometry_pipeline_amd")
+    ctx = vo.Context(0)
+    n = args.frames + args.warmup + 1
+    worlds = {}
+
+    def world(item):
+        if item not in worlds:
+            scene, frames, poses = bench.make_sequence(vo, n, item)
+            d = [torch.from_numpy(f).cuda() for f in frames[:n]]
+            X0, xy0 = bench.init_points(vo, ctx, scene, frames[0], poses[0])
+            worlds[item] = (d, X0, xy0, poses[0])
+        return worlds[item]
+
+    hp = vo.default_hyper_paras("kitti")
+    hp.r_discard_redundant = bench.KITTI_EXCLUSION_RADIUS
+    out = {}
+    for S in [int(x) for x in args.seqs.split(",")]:
+        g = vo.VOGroupDevice(vo.synth.K_KITTI, (vo.synth.KITTI_H, vo.synth.KITTI_W), S, n, hyper_paras=hp, ctx=ctx)
+        for rep in range(2):   # (the first run loads code objects and maps buffers)
+            for s in range(S):
+                d, X0, xy0, T0 = world(s if args.distinct else 0)
+                g.add_sequence(s, d, X0, xy0, T0, rng=np.random.default_rng(1000 + s))
+            for _ in range(args.warmup):
+                g.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0, w0 = g.host_enqueue_us, g.host_wait_us
+            pairs = 0
+            for _ in range(args.frames):
+                pairs += len(g.step())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        out[S] = dict(frames_per_s=pairs / dt, ms_per_step=1e3 * dt / args.frames,
+                      host_enqueue_us_per_step=(g.host_enqueue_us - e0) / args.frames,
+                      host_wait_us_per_step=(g.host_wait_us - w0) / args.frames,
+                      landmarks=int(np.mean([q.num_X[-1] for q in g.seqs])), candidates=int(np.mean([q.num_C[-1] for q in g.seqs])))
+        print(S, json.dumps(out[S]), flush=True)
+        g.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -20,9 +20,25 @@ RECORD_DOUBLES = HEADER + ERRS + 15 * T_MAX   # ... + est_trans 3xT + est_rot 9x
 TIMING_KEYS = ("total_time", "frame_init", "frame_ct", "toc_param", "toc_bootstrap", "toc_ct", "fps_ct")
 
 
-def shard(items, rank, world):
-    """Round-robin assignment of work items to ranks (static, so results do not depend on timing)."""
-    return [it for k, it in enumerate(items) if k % world == rank]
+def shard(items, rank, world, costs=None):
+    """Static assignment of work items to ranks (a run's result never depends on it: every run carries its own
+    seed).  Without `costs`: round-robin.  With `costs` (one number per item, e.g. its frame count): longest
+    first -- the items in order of decreasing cost (ties: in order of their index), each to the rank with the
+    smallest load so far (ties: the lowest rank) -- so that 20 runs of unequal length on 8 GPUs end together
+    instead of 3 + 3 + 3 + 3 + 2 + 2 + 2 + 2 by count.  The share keeps the items' original order."""
+    items = list(items)
+    if costs is None:
+        return [it for k, it in enumerate(items) if k % world == rank]
+    if len(costs) != len(items):
+        raise ValueError("one cost per item")
+    load = [0.0] * world
+    mine = []
+    for k in sorted(range(len(items)), key=lambda k: (-float(costs[k]), k)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        load[r] += float(costs[k])
+        if r == rank:
+            mine.append(k)
+    return [items[k] for k in sorted(mine)]
 
 
 def failed_record(item_id, seconds):
@@ -74,7 +90,8 @@ def unpack_record(rec):
 
 def gather_records(local_records, n_items, device=None):
     """All ranks receive every record (list indexed by item id).  Ranks hold different numbers of
-    items, so each contributes ceil(n_items / world) slots, unused ones marked with id -1."""
+    items, so each contributes as many slots as the fullest rank holds (one MAX all_reduce of the
+    counts), unused ones marked with id -1."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -83,7 +100,11 @@ def gather_records(local_records, n_items, device=None):
             out[int(r[0])] = unpack_record(r)
         return out
     world = dist.get_world_size()
-    slots = (n_items + world - 1) // world
+    count = torch.tensor([len(local_records)], dtype=torch.int64)
+    if device is not None:
+        count = count.to(device)
+    dist.all_reduce(count, op=dist.ReduceOp.MAX)
+    slots = max(int(count.item()), 1)
     buf = np.zeros((slots, RECORD_DOUBLES))
     buf[:, 0] = -1.0
     for k, r in enumerate(local_records):
@@ -112,20 +133,30 @@ def run_items(mine, runner, concurrent=1):
         return list(pool.map(lambda p: runner(p[0], p[1]), mine))   # (in the order of `mine`)
 
 
-def run_batch(items, runner, device=None, rank=None, world=None, concurrent=1):
+def run_batch(items, runner, device=None, rank=None, world=None, concurrent=1, costs=None, share_runner=None, timing=None):
     """Runs `runner(item_id, item) -> record` for this rank's share of `items` and gathers all
     records on every rank.  `runner` builds and drives one full pipeline run.
     rank / world given explicitly (without a process group): only that share is run and returned, the
     other entries of the result are None -- one GPU can then rehearse every rank's share in turn.
-    concurrent: runs a rank has in flight at once (see run_items)."""
+    concurrent: runs a rank has in flight at once (see run_items).
+    costs: see shard.  share_runner(mine) -> records (may be given instead of running item by item: the
+    rank's whole share [(item_id, item), ...] at once, e.g. as groups of loops in lockstep).
+    timing (a dict, filled in): seconds this rank spent running its share and in the gather."""
+    import time
     import torch.distributed as dist
+    run = (lambda mine: share_runner(mine)) if share_runner else (lambda mine: run_items(mine, runner, concurrent))
     if rank is not None:
         out = [None] * len(items)
-        mine = shard(list(enumerate(items)), rank, world)
-        for (item_id, _), rec in zip(mine, run_items(mine, runner, concurrent)):
+        mine = shard(list(enumerate(items)), rank, world, costs)
+        for (item_id, _), rec in zip(mine, run(mine)):
             out[item_id] = unpack_record(rec)
         return out
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    mine = shard(list(enumerate(items)), rank, world)
-    local = run_items(mine, runner, concurrent)
-    return gather_records(local, len(items), device=device)
+    mine = shard(list(enumerate(items)), rank, world, costs)
+    t0 = time.perf_counter()
+    local = run(mine)
+    t1 = time.perf_counter()
+    out = gather_records(local, len(items), device=device)
+    if timing is not None:
+        timing.update(run_s=t1 - t0, gather_s=time.perf_counter() - t1, items=len(mine))
+    return out

@@ -194,13 +194,90 @@ def run_sequence(images, K, hyper_paras, ground_truth=None, bootstrap_frames=(0,
     return out
 
 
+def run_group(runs, ctx=None, group=None, n_slots=None, max_frames=None):
+    """Several full runs (each what run_sequence does: bootstrap, continuous operation, timing, evaluation,
+    result file) whose loops advance together as ONE group of loops in lockstep (VOGroupDevice): every kernel
+    of a frame is launched once for all of them.  The runs must share the image shape and camera matrix and
+    differ at most in images, generator and corner detector (Harris / MinEigen with their thresholds): the
+    independent runs of main_eval.m:22-23.  A run's trajectory, counts, state and errs are those run_sequence
+    gives it, bit for bit.
+
+    runs: list of dicts with keys images, K, hyper_paras, rng and optionally ground_truth, bootstrap_frames,
+    dataset, save_dir, now (the arguments of run_sequence).
+    Timing: the runs bootstrap one after the other (toc_bootstrap is each run's own); the loops share their wall
+    time, so a run's toc_ct is its share of the group's loop time by frames, and fps_ct = frame_ct / toc_ct
+    is the rate at which the group as a whole processed frames.
+    group: a VOGroupDevice to use (and keep open) instead of creating one with n_slots x max_frames.
+    Returns one dict per run (the keys of run_sequence's result, plus 'error' for a run that stopped)."""
+    from .bootstrap import bootstrap
+    from .frame_pipeline import VOGroupDevice
+    ctx = ctx or _lib.default_context()
+    if not runs:
+        return []
+    boots = []
+    for r in runs:
+        t_param = time.perf_counter()
+        b1, b2 = (int(v) for v in r.get("bootstrap_frames", (0, 2)))
+        toc_param = time.perf_counter() - t_param
+        t_boot = time.perf_counter()                                        # main_demo.m:162
+        images = r["images"]
+        img_seqs = list(images[b1 + 1:b2 + 1])
+        p_W, kp, T0 = bootstrap(images[b1], img_seqs, np.asarray(r["K"], dtype=np.float64), r["hyper_paras"], rng=r["rng"],
+                                ctx=ctx)                                    # :252-264
+        boots.append(dict(b1=b1, b2=b2, p_W=p_W, kp=kp, T0=T0, toc_param=toc_param,
+                          toc_bootstrap=time.perf_counter() - t_boot, frame_init=len(img_seqs) + 1))
+    t_ct = time.perf_counter()                                              # :270
+    own = group is None
+    hp0 = runs[0]["hyper_paras"]
+    if own:
+        longest = max(len(r["images"]) - b["b2"] for r, b in zip(runs, boots))
+        shape = tuple(np.asarray(runs[0]["images"][boots[0]["b2"]]).shape) if not hasattr(runs[0]["images"][0], "data_ptr") \
+            else tuple(runs[0]["images"][0].shape)
+        group = VOGroupDevice(runs[0]["K"], shape, n_slots or len(runs), max_frames or longest, hyper_paras=hp0, ctx=ctx)
+    try:
+        for s, (r, b) in enumerate(zip(runs, boots)):
+            hp = r["hyper_paras"]
+            fo = dict(zip(hp.feature_extract_options[::2], hp.feature_extract_options[1::2]))
+            # the loop's images: the last bootstrap image (the one the trackers are initialised on, :342-349),
+            # then the frames of :351
+            group.add_sequence(s, list(r["images"][b["b2"]:]), b["p_W"], b["kp"], b["T0"], rng=r["rng"],
+                               feature_extract=hp.feature_extract, min_quality=fo.get("MinQuality"))
+        group.run()
+        loop_s = time.perf_counter() - t_ct                                 # :446
+        states = [group.S(s) if group.seqs[s].error is None else None for s in range(len(runs))]
+        errors = [group.seqs[s].error for s in range(len(runs))]
+    finally:
+        if own:
+            group.close()
+    total_frames = sum(len(r["images"]) - b["b2"] - 1 for r, b in zip(runs, boots))
+    outs = []
+    for r, b, S, err in zip(runs, boots, states, errors):
+        frame_ct = len(r["images"]) - b["b2"] - 1                           # :448
+        toc_ct = loop_s * frame_ct / max(total_frames, 1)
+        out = dict(errs=None, S=S, total_time=b["toc_param"] + b["toc_bootstrap"] + toc_ct, frame_init=b["frame_init"],
+                   frame_ct=frame_ct, toc_param=b["toc_param"], toc_bootstrap=b["toc_bootstrap"], toc_ct=toc_ct,
+                   fps_ct=frame_ct / toc_ct if toc_ct > 0 else 0.0, path=None, error=err, group_loop_s=loop_s)
+        if err is None:
+            if r.get("ground_truth") is not None:                           # :465-471
+                out["errs"] = quantitative_eval(r["ground_truth"], S, (b["b1"], b["b2"]), ctx=ctx)
+            if r.get("save_dir") is not None:
+                import os
+                os.makedirs(r["save_dir"], exist_ok=True)
+                name = experiment_name(r.get("dataset", "synthetic"), r["hyper_paras"], r.get("now"))
+                out["path"] = save_results(os.path.join(r["save_dir"], name), out["errs"], S, out["total_time"],
+                                           out["frame_init"], frame_ct, out["toc_param"], out["toc_bootstrap"], toc_ct,
+                                           out["fps_ct"])
+        outs.append(out)
+    return outs
+
+
 EVAL_FEATURE_OPTIONS = {"Harris": ["MinQuality", 2e-4],      # main_eval.m:168-169
                         "MinEigen": ["MinQuality", 1e-2],    # genKeypoints.m:18 (no entry in main_eval's switch)
                         "FAST": ["MinContrast", 0.11]}       # main_eval.m:172-173
 
 
 def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0, device=None, rank=None, world=None,
-              ctx=None, now=None, concurrent=1, on_error="raise"):
+              ctx=None, now=None, concurrent=1, on_error="raise", group=0, balance=True, timing=None):
     """The batch evaluation of main_eval.m: for every sequence, every feature variant (main_eval.m:19,22,
     165-174) and every repetition (:20,23) one full, independent run (run_sequence: bootstrap, loop,
     timing, quantitative_eval, '<experiment>_res.mat' as :483-494 saves it).
@@ -223,7 +300,13 @@ def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0,
     run's result does not depend on it.
     on_error: "raise" -- a run that fails (the localisation finds no pose, too few tracks: where the reference's
     script stops with an error, main_demo.m:389-391) ends the grid, as in the reference; "record" -- its record
-    is marked failed (no trajectory) and the grid goes on."""
+    is marked failed (no trajectory) and the grid goes on.
+    group: > 1 -- a rank advances up to that many of its runs together as a group of loops in lockstep
+    (run_group: one launch sequence per frame for all of them; Harris / MinEigen runs without bundle adjustment
+    of one image shape and camera; the others run one at a time).  A run's record does not depend on it, apart
+    from its timings (see run_group).
+    balance: deal the runs longest first by frame count (batch.shard) instead of round-robin.
+    timing: a dict that receives this rank's run and gather seconds."""
     import copy
     import datetime
     from . import batch
@@ -265,8 +348,62 @@ def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0,
         return batch.pack_record(item_id, time.perf_counter() - t0, S.est_trans, S.est_rot, S.num_X, S.num_C,
                                  S.num_new, errs=out["errs"], timing=out)
 
+    def groupable(item):
+        si, feat, _ = item
+        hp = sequences[si].get("hyper_paras") or default_hyper_paras(sequences[si]["name"])
+        return feat in ("Harris", "MinEigen") and not hp.is_BA
+
+    def share_runner(mine):
+        """This rank's share: groupable runs in groups of `group` (same shape and camera), the rest one by one."""
+        out = {}
+        buckets = {}
+        for item_id, item in mine:
+            if not groupable(item):
+                out[item_id] = runner(item_id, item)
+                continue
+            seq = sequences[item[0]]
+            key = (tuple(seq["images"][0].shape), np.asarray(seq["K"], dtype=np.float64).tobytes())
+            buckets.setdefault(key, []).append((item_id, item))
+        for bucket in buckets.values():
+            # (longest first, so that the runs of a group end together)
+            bucket.sort(key=lambda p: (-len(sequences[p[1][0]]["images"]), p[0]))
+            for c in range(0, len(bucket), int(group)):
+                chunk = bucket[c:c + int(group)]
+                runs = []
+                for item_id, (si, feat, rep) in chunk:
+                    seq = sequences[si]
+                    hp = copy.copy(seq.get("hyper_paras") or default_hyper_paras(seq["name"]))
+                    hp.feature_extract = feat
+                    hp.feature_extract_options = list(EVAL_FEATURE_OPTIONS[feat])
+                    runs.append(dict(images=seq["images"], K=seq["K"], hyper_paras=hp, ground_truth=seq.get("ground_truth"),
+                                     bootstrap_frames=seq.get("bootstrap_frames", (0, 2)), dataset=seq["name"],
+                                     save_dir=save_dir, rng=np.random.default_rng([seed, item_id]),
+                                     now=now + datetime.timedelta(seconds=item_id)))
+                t0 = time.perf_counter()
+                try:
+                    results = run_group(runs, ctx=ctx)
+                except (RuntimeError, _lib.VohipError):   # (a bootstrap that fails: where the reference stops)
+                    if on_error != "record":
+                        raise
+                    for item_id, item in chunk:   # one by one, so that the others of the group still get their record
+                        out[item_id] = runner(item_id, item)
+                    continue
+                dt = time.perf_counter() - t0
+                for (item_id, _), res in zip(chunk, results):
+                    if res["error"] is not None:
+                        if on_error != "record":
+                            raise res["error"]
+                        out[item_id] = batch.failed_record(item_id, dt / len(chunk))
+                        continue
+                    S = res["S"]
+                    out[item_id] = batch.pack_record(item_id, res["total_time"], S.est_trans, S.est_rot, S.num_X, S.num_C,
+                                                     S.num_new, errs=res["errs"], timing=res)
+        return [out[item_id] for item_id, _ in mine]
+
+    costs = [len(sequences[si]["images"]) for si, _, _ in items] if balance else None
     try:
-        records = batch.run_batch(items, runner, device=device, rank=rank, world=world, concurrent=concurrent)
+        records = batch.run_batch(items, runner, device=device, rank=rank, world=world, concurrent=concurrent, costs=costs,
+                                  share_runner=share_runner if group and group > 1 else None, timing=timing)
     finally:
         for c in extra:
             c.close()
