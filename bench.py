@@ -6,17 +6,22 @@ python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch
 Workload (N = 1): the per-frame continuous-operation loop on a rendered KITTI-shape sequence
 (1241 x 376, ~2k tracked keypoints, Harris MinQuality 2e-4, 21x21 / 5-level KLT, adaptive P3P
 RANSAC, pose refinement, F-matrix filter, triangulation, candidate filter; no BA) -- one step = one
-frame, frames resident in HBM before the timed region; the loop state stays on the GPU
+frame of one sequence, frames resident in HBM before the timed region; the loop state stays on the GPU
 (VOPipelineDevice over the vohip_frame_* entry points).  N > 1: the reference's batch mode
 (main_eval.m:22-23) shards independent runs, so every rank runs its own work item of the run grid --
 its own rendered sequence and random seed, dealt by batch.shard -- with no exchange while it runs, and
-the result records are gathered with one all_gather (RCCL) inside the timed region.
+the result records are gathered with one all_gather (RCCL) inside the timed region (the collective's
+first use happens in the set-up run before it; its duration is reported).  At N > 1 the line also
+carries the batch mode proper: every rank advancing four runs of the grid as a group of loops.
 
-Also measured and reported in the same JSON line (N = 1): the same loop over 200 frames, with bundle
-adjustment (main_BA.m's window), in the parking configuration, at stress sizes and for four sequences at
-once; the tracker kernel's roofline (`roofline`: the kernel the headline is bound by); the RANSAC stress
-configuration (4096 P3P hypotheses x 8192 correspondences per step) as hypotheses/s with the roofline of
-its scoring kernel (`roofline_ransac`).  The CPU oracle is used only for the cpu_baseline leg.
+Also measured and reported in the same JSON line (N = 1): the same loop with its images in pinned host
+memory (upload included), with bundle adjustment (main_BA.m's window), in the parking configuration, at
+stress sizes; 4, 8 and 16 independent sequences advanced as a group of loops in lockstep (one launch
+sequence per frame for all of them: what the batch evaluation runs on a GPU) and four sequences on four host
+threads; the batch evaluation itself (main_eval); the roofline entry of the tracker kernel (`roofline`:
+the loop's own launches, event-timed in an untimed replay); the RANSAC stress configuration (4096 P3P
+hypotheses x 8192 correspondences per step) as hypotheses/s with the roofline of its scoring kernel
+(`roofline_ransac`).  The CPU oracle is used only for the cpu_baseline leg.
 """
 import argparse
 import importlib
@@ -176,20 +181,129 @@ def bench_frames_concurrent(vo, torch, scene, frames, poses, steps, warmup, n_se
     return n_seq * steps / max(seconds)
 
 
-def bench_main_eval(vo, ctx, frames, poses, concurrent):
-    """The batch evaluation of main_eval.m:20-23 on one GPU: a grid of 2 feature variants x 4 repetitions = 8 full
-    runs (bootstrap on the first three frames, continuous operation on the rest, quantitative_eval, result record)
-    of one KITTI-shape sequence whose images live in host memory, `concurrent` runs in flight at a time.
-    Returns runs/s and the frames/s of the grid as a whole (continuous-operation frames / wall time)."""
+def kitti_hyper_paras(vo):
+    hp = vo.default_hyper_paras("kitti", is_BA=False)
+    hp.r_discard_redundant = KITTI_EXCLUSION_RADIUS
+    return hp
+
+
+def bench_group(vo, torch, ctx, scene, frames, poses, steps, warmup, n_seq, seed=1000, measure_tracker=False):
+    """A group of n_seq loops in lockstep (VOGroupDevice: the independent runs of main_eval.m:22-23 sharing every
+    launch of a frame) on the headline workload.  Sequence s starts s frames into the rendered corridor (its own
+    images, start set and random draws).  One step = one frame of every sequence; returns the aggregate frames/s.
+    measure_tracker: the same run once more with the tracker launches bracketed by timing events and once
+    more with the tracker's work counters on (neither while timing) -> the roofline entry of those launches."""
+    import ctypes as C
+    lib = vo._lib.load()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = warmup + steps + 1
+    if len(frames) < n + n_seq - 1:
+        raise ValueError("the rendered sequence is too short for %d staggered sequences" % n_seq)
+    d_frames = [torch.from_numpy(f).to(dev) for f in frames[:n + n_seq - 1]]
+    starts = [init_points(vo, ctx, scene, frames[s], poses[s]) for s in range(n_seq)]
+    g = vo.VOGroupDevice(vo.synth.K_KITTI, tuple(frames[0].shape), n_seq, n, hyper_paras=kitti_hyper_paras(vo), ctx=ctx)
+
+    def run(timed):
+        for s in range(n_seq):
+            g.add_sequence(s, d_frames[s:s + n], starts[s][0], starts[s][1], poses[s], rng=np.random.default_rng(seed + s))
+        for _ in range(warmup):
+            g.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0, w0 = g.host_enqueue_us, g.host_wait_us
+        pairs = 0
+        for _ in range(steps):
+            pairs += len(g.step())
+        torch.cuda.synchronize()
+        return pairs, time.perf_counter() - t0, g.host_enqueue_us - e0, g.host_wait_us - w0
+
+    run(False)   # (code objects, staging buffers, the group's first use of its memory)
+    pairs, dt, enq, wait = run(True)
+    out = {"sequences": n_seq, "frames_per_s": pairs / dt, "ms_per_step": 1e3 * dt / steps,
+           "host_enqueue_us_per_step": enq / steps, "host_wait_us_per_step": wait / steps,
+           "tracked_landmarks_per_sequence": int(np.mean([q.num_X[-1] for q in g.seqs])),
+           "candidates_per_sequence": int(np.mean([q.num_C[-1] for q in g.seqs])),
+           "final_position_error_m": float(max(np.linalg.norm(q.est_trans[-1] - poses[s + warmup + steps][:3, 3])
+                                               for s, q in enumerate(g.seqs)))}
+    if measure_tracker:
+        tot, longest, launches = C.c_double(0), C.c_double(0), C.c_int(0)
+        ctx.set_option("klt_time", 1)
+        run(False)
+        ctx.check(lib.vohip_klt_time(ctx.handle, C.byref(tot), C.byref(longest), C.byref(launches), 1))
+        ctx.set_option("klt_time", 0)
+        tr, it = C.c_longlong(0), C.c_longlong(0)
+        ctx.set_option("klt_stats", 1)
+        ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
+        run(False)
+        ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
+        ctx.set_option("klt_stats", 0)
+        out["tracker"] = tracker_roofline(tot.value, longest.value, launches.value, tr.value, it.value,
+                                          frames[0].shape, frames_of_run=(warmup + steps) * n_seq)
+    g.close()
+    return out
+
+
+def tracker_roofline(total_ms, longest_ms, launches, tracks, iterations, shape, frames_of_run):
+    """Roofline entry of the tracker launches of a loop (or group of loops): the launches' own durations (event pairs
+    on their streams) against the work their tracks did (the kernel's counters, same run repeated)."""
+    passes = tracks * 5 * 2                             # (track, level, direction) triples
+    flop = 11907.0 * passes + 5292.0 * iterations      # 441 px x (27 set-up + 12 per iteration) fp32 flop
+    lds = 441.0 * 4 * 4 * iterations                   # 4 bilinear taps x 4 B per window pixel per iteration
+    rows, cols = shape
+    pyr = 4.0 * rows * cols * sum(0.25 ** l for l in range(5))
+    s = total_ms * 1e-3
+    return {"kernel": "klt_track_kernel<21>", "launches": launches, "tracks": tracks, "tracks_per_launch": tracks / max(launches, 1),
+            "kernel_ms_total": total_ms, "kernel_ms_mean": total_ms / max(launches, 1), "kernel_ms_longest": longest_ms,
+            "tracker_us_per_frame": 1e3 * total_ms / max(frames_of_run, 1),
+            "mean_iterations_per_pass": iterations / max(passes, 1), "algorithmic_flop": flop, "algorithmic_lds_bytes": lds,
+            "compulsory_hbm_bytes_per_frame": 2 * pyr + 40.0 * tracks / max(frames_of_run, 1),
+            "achieved_lds_tbs": lds / s / 1e12, "peak_lds_tbs": LDS_PEAK_TBS, "frac_lds": lds / s / 1e12 / LDS_PEAK_TBS,
+            "achieved_tflops": flop / s / 1e12, "peak_tflops": FP32_VALU_PEAK_TFLOPS,
+            "frac_valu": flop / s / 1e12 / FP32_VALU_PEAK_TFLOPS}
+
+
+def tracker_of_loop(vo, torch, ctx, scene, frames, poses, steps, warmup, seed):
+    """The headline loop twice more, untimed: once with the tracker launches bracketed by timing events, once with
+    the tracker's work counters on -> the roofline entry of the loop's OWN tracker launches (two per frame: the
+    kept landmarks', and the appended landmarks' + candidates')."""
+    import ctypes as C
+    lib = vo._lib.load()
+    tot, longest, launches = C.c_double(0), C.c_double(0), C.c_int(0)
+    tr, it = C.c_longlong(0), C.c_longlong(0)
+    nosync = lambda: torch.cuda.synchronize()   # noqa: E731
+    nogather = lambda pipe, seconds: []          # noqa: E731
+    ctx.set_option("klt_time", 1)
+    bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, nosync, nogather)
+    ctx.check(lib.vohip_klt_time(ctx.handle, C.byref(tot), C.byref(longest), C.byref(launches), 1))
+    ctx.set_option("klt_time", 0)
+    ctx.set_option("klt_stats", 1)
+    ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
+    bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, nosync, nogather)
+    ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
+    ctx.set_option("klt_stats", 0)
+    return tracker_roofline(tot.value, longest.value, launches.value, tr.value, it.value, frames[0].shape,
+                            frames_of_run=warmup + steps)
+
+
+def bench_main_eval(vo, ctx, frames, poses, concurrent=1, group=0):
+    """The batch evaluation of main_eval.m:20-23 on one GPU: a grid of 3 feature variants (Harris, MinEigen, FAST) x 4
+    repetitions = 12 full runs (bootstrap on the first three frames, continuous operation on the rest,
+    quantitative_eval, result record) of one KITTI-shape sequence whose images live in host memory; `concurrent`
+    runs in flight at a time (a thread and a context each), or -- group -- the Harris and MinEigen runs as groups
+    of that many loops in lockstep.  Returns runs/s and the frames/s of the grid as a whole (continuous-operation
+    frames / wall time, bootstraps and evaluations included)."""
     seq = dict(name="kitti", images=frames, K=vo.synth.K_KITTI,
                ground_truth=np.array([[T[0, 3], T[2, 3]] for T in poses[:len(frames)]]))
-    vo.main_eval([seq], feats=("Harris",), repetition=1, seed=10, ctx=ctx)   # code objects, staging buffers
+    short = dict(seq, images=frames[:12])
+    vo.main_eval([short], feats=("Harris", "FAST"), repetition=1, seed=10, ctx=ctx, group=group)   # code objects, staging buffers
     t0 = time.perf_counter()
-    records = vo.main_eval([seq], feats=("Harris", "FAST"), repetition=4, seed=10, ctx=ctx, concurrent=concurrent)
+    records = vo.main_eval([seq], feats=("Harris", "MinEigen", "FAST"), repetition=4, seed=10, ctx=ctx, concurrent=concurrent,
+                           group=group)
     dt = time.perf_counter() - t0
     n_frames = sum(int(r["frame_ct"]) for r in records)
     return {"runs": len(records), "runs_per_s": len(records) / dt, "frames_per_s": n_frames / dt,
-            "frames_per_run": n_frames // len(records), "mean_fps_ct_of_a_run": float(np.mean([r["fps_ct"] for r in records]))}
+            "frames_per_run": n_frames // len(records), "mean_fps_ct_of_a_run": float(np.mean([r["fps_ct"] for r in records])),
+            "errs_columns": [int(r["errs"].shape[1]) for r in records]}
 
 
 def bench_parking(vo, torch, ctx, steps, warmup, bundle_adjust):
@@ -449,13 +563,17 @@ def bench_ba(vo, ctx, with_cpu):
     return out
 
 
-def traffic_from_profile(kernel):
+def traffic_from_profile(kernel, prefer=None):
     """HBM bytes per launch of `kernel` as the committed rocprofv3 counter passes saw them (newest
-    profiles/*_summary.csv that lists it): FETCH_SIZE + WRITE_SIZE, which rocprofv3 reports in KB, as read
-    (the kernel's loads are 8 bytes per lane, for which the counter is not calibrated).  None without a profile."""
+    profiles/*_summary.csv that lists it; with `prefer`, files whose name holds that word first): FETCH_SIZE +
+    WRITE_SIZE, which rocprofv3 reports in KB, as read (the kernel's loads are 8 bytes per lane, for which the
+    counter is not calibrated).  None without a profile."""
     import csv
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.csv")), reverse=True):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.csv")), reverse=True)
+    if prefer:
+        paths = [q for q in paths if prefer in os.path.basename(q)] + [q for q in paths if prefer not in os.path.basename(q)]
+    for path in paths:
         try:
             for row in csv.DictReader(open(path, newline="")):
                 if row.get("kernel") == kernel and row.get("FETCH_SIZE") and row.get("WRITE_SIZE"):
@@ -489,15 +607,18 @@ def cpu_baseline_frames(vo, scene, frames, poses, X0, xy0, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--hypotheses", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--thin-cell", type=float, default=KITTI_THIN_CELL, help="thinning cell of the first frame's corners, px")
     ap.add_argument("--exclusion-radius", type=float, default=KITTI_EXCLUSION_RADIUS,
                     help="r_discard_redundant of the KITTI-shape workload, px (the reference's value is 10)")
-    ap.add_argument("--only-headline", action="store_true", help="skip the secondary legs")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="the headline loop and the roofline entry of its own tracker launches, nothing else")
+    ap.add_argument("--only-group", type=int, default=0, metavar="S",
+                    help="the headline loop and a group of S loops in lockstep, nothing else (for profiles)")
     args = ap.parse_args()
     globals().update(KITTI_THIN_CELL=args.thin_cell, KITTI_EXCLUSION_RADIUS=args.exclusion_radius)
 
@@ -523,6 +644,7 @@ def main():
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         ctx = vo.Context(local_rank, stream=stream.cuda_stream)
+        gather_s = []
 
         def barrier():
             torch.cuda.synchronize()
@@ -531,45 +653,74 @@ def main():
             torch.cuda.synchronize()
 
         def gather(pipe, seconds):
+            t0 = time.perf_counter()
             et, er = pipe.trajectory()
             rec = vo.batch.pack_record(rank, seconds, et, er, pipe.num_X, pipe.num_C, pipe.num_new,
                                        timing=dict(toc_ct=seconds, frame_ct=len(pipe.num_X) - 1,
                                                    fps_ct=(len(pipe.num_X) - 1) / seconds))
-            return vo.batch.gather_records([rec], world, device=coll_device if (world > 1 and backend == "nccl") else None)
+            out = vo.batch.gather_records([rec], world, device=coll_device if (world > 1 and backend == "nccl") else None)
+            gather_s.append(time.perf_counter() - t0)
+            return out
 
+        grid_group = 4   # (N > 1) work items of the run grid a rank advances together in the grid leg
         n_frames = max(args.warmup + args.steps + 2, 8)   # (the priming run below needs 8)
-        # with the CPU baseline leg the sequence is longer, so that its sample is about 10 s of CPU work and the
-        # long timed run below has 200 frames
-        n_seq = n_frames if (args.no_cpu_baseline or world > 1) else max(n_frames, 212)
+        # with the CPU baseline leg the sequence is longer, so that its sample is about 10 s of CPU work; the group
+        # legs stagger their sequences by a frame each
+        quick = args.only_headline or args.only_group
+        n_seq = n_frames + (max(args.only_group, 1) if quick else 16)
+        if world > 1:
+            n_seq = n_frames + grid_group
+        elif not args.no_cpu_baseline and not quick:
+            n_seq = max(n_seq, 212)
         # work item of this rank (the batch grid main_eval.m:22-23 shards): its own rendered sequence and seed
         item = vo.batch.shard(list(range(world)), rank, world)[0]
         scene, frames_all, poses_all = make_sequence(vo, n_seq, item)
         frames, poses = frames_all[:n_frames], poses_all[:n_frames]
         # set-up, not steps: a throw-away run of a few frames loads every kernel's code object and maps the
-        # staging buffers, so that the W warm-up steps below start from a process that has run the path once
-        bench_frames(vo, torch, ctx, scene, frames, poses, 4, 2, 99, lambda: torch.cuda.synchronize(),
-                     lambda pipe, seconds: [])
+        # staging buffers, so that the W warm-up steps below start from a process that has run the path once;
+        # its gather is the first use of the collective (communicator set-up, buffers), which is not the job's cost
+        bench_frames(vo, torch, ctx, scene, frames, poses, 4, 2, 99, barrier, gather)
+        gather_s.clear()
         elapsed, info = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + item, barrier,
                                      gather)
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+            t = torch.tensor([elapsed, gather_s[-1]], dtype=torch.float64, device=coll_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed, gather_max = float(t[0].item()), float(t[1].item())
+        else:
+            gather_max = gather_s[-1]
         fps = world * args.steps / elapsed
         extra = {}
-        if world == 1 and not args.only_headline:
-            nosync = lambda: torch.cuda.synchronize()   # noqa: E731
-            nogather = lambda pipe, seconds: []          # noqa: E731
+        nosync = lambda: torch.cuda.synchronize()   # noqa: E731
+        nogather = lambda pipe, seconds: []          # noqa: E731
+        if world > 1:
+            # The unit the reference's batch mode shards (main_eval.m:22-23) as this build runs it on a GPU: every
+            # rank advances `grid_group` work items of the run grid together, as a group of loops in lockstep (own
+            # seed and start frame each, the rank's own rendered corridor); no exchange while they run; the records
+            # are gathered afterwards (timed apart).
+            barrier()
+            grid = bench_group(vo, torch, ctx, scene, frames_all, poses_all, args.steps, args.warmup, grid_group,
+                               seed=1000 + 100 * rank)
+            t = torch.tensor([grid["ms_per_step"]], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            extra["run_grid_groups_of_%d" % grid_group] = {
+                "frames_per_s": world * grid_group * 1e3 / float(t.item()), "ms_per_step_slowest_rank": float(t.item()),
+                "items_per_rank": grid_group, "frames_per_item": args.steps,
+                "note": "scaling of the batch mode proper: world x %d runs, each rank its group of loops in lockstep; "
+                        "divide by the same field of the 1-GPU line (frames_per_s_group_of_4)" % grid_group}
+        if world == 1:
+            # the same loop with its images in pinned host memory: every frame's 466 KB upload is part of the frame
+            # (frames of the loop / wall time of the loop, image decode excluded, upload included)
             el, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync, nogather,
                                  resident=False)
             extra["frames_per_s_pcie_inclusive"] = args.steps / el
+        if world == 1 and args.only_group:
+            extra["frames_per_s_group_of_%d" % args.only_group] = bench_group(
+                vo, torch, ctx, scene, frames_all, poses_all, args.steps, args.warmup, args.only_group, measure_tracker=True)
+        if world == 1 and not quick:
             el, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync, nogather,
                                  ahead=False)
             extra["frames_per_s_without_lookahead"] = args.steps / el
-            if len(frames_all) >= 212:   # a longer timed region (clocks settled), same workload
-                el, inf = bench_frames(vo, torch, ctx, scene, frames_all, poses_all, 200, 10, 100, nosync, nogather)
-                extra["frames_per_s_200_frames"] = {"value": 200 / el, "tracked_landmarks": inf["n_landmarks"],
-                                                    "candidates": inf["n_candidates"]}
             # main_BA.m's configuration on the same KITTI-shape sequence: bundle adjustment over a window of 5
             # keyframes, every 2nd frame a keyframe (runBA and the normal-frame re-refinements on the GPU, the
             # window bookkeeping on the host, one copy of the landmarks each way)
@@ -581,13 +732,17 @@ def main():
                 "reference_published_fps": MATLAB_PARKING_BA_FPS,
                 "note": "KITTI shape; the reference's only published figure with bundle adjustment is parking, MATLAB"}
             # the reference's parking configuration (BASELINE config 1 and, with bundle adjustment, config 3)
+            steps_p = min(args.steps, 60)
             extra["parking_640x480"] = {
-                "no_ba": dict(bench_parking(vo, torch, ctx, args.steps, args.warmup, False),
+                "note": "a proxy of ds = 2: the reference's data/parking/K.txt is absent, so the rendered 640 x 480 corridor is "
+                        "seen through data/epfl_parking/calibration/K.txt at half resolution",
+                "no_ba": dict(bench_parking(vo, torch, ctx, steps_p, args.warmup, False),
                               reference_published_fps=MATLAB_PARKING_FPS),
-                "with_ba_window5_every_2nd_frame": dict(bench_parking(vo, torch, ctx, args.steps, args.warmup, True),
+                "with_ba_window5_every_2nd_frame": dict(bench_parking(vo, torch, ctx, steps_p, args.warmup, True),
                                                         reference_published_fps=MATLAB_PARKING_BA_FPS)}
             # the whole loop at the stress sizes (the kernel-level stress figures follow below)
-            el_s, info_s = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync,
+            steps_s = min(args.steps, 40)
+            el_s, info_s = bench_frames(vo, torch, ctx, scene, frames, poses, steps_s, args.warmup, 100, nosync,
                                         nogather, stress_hypotheses=args.hypotheses)
             extra["frame_loop_stress_config"] = {
                 "workload": "every corner of the frames (Harris MinQuality %g: about 8 250 per frame, all of the first "
@@ -595,31 +750,35 @@ def main():
                             "per frame; the rendered frames hold no more corners than that, so 8 192 + 8 192 distinct "
                             "tracks do not exist in them (the tracker and RANSAC kernels alone are measured at 8 192 below)"
                             % (STRESS_MIN_QUALITY, STRESS_EXCLUSION_RADIUS, args.hypotheses),
-                "frames_per_s": args.steps / el_s, "tracked_landmarks": info_s["n_landmarks"],
+                "frames_per_s": steps_s / el_s, "tracked_landmarks": info_s["n_landmarks"],
                 "candidates": info_s["n_candidates"], "final_position_error_m": info_s["final_position_error_m"]}
-            # (over 100 frames per sequence when the long sequence is there: the threads' first frames stall one
-            # another in the runtime, which a timed region of a few frames would mostly measure)
-            if len(frames_all) >= 212:
-                extra["frames_per_s_4_sequences_at_once"] = bench_frames_concurrent(vo, torch, scene, frames_all, poses_all,
-                                                                                    100, 10, 4)
-                extra["frames_per_sequence_in_that_figure"] = 100
-            else:
-                extra["frames_per_s_4_sequences_at_once"] = bench_frames_concurrent(vo, torch, scene, frames, poses,
-                                                                                    args.steps, args.warmup, 4)
-                extra["frames_per_sequence_in_that_figure"] = args.steps
-            # BASELINE's batch configuration on one GPU (with N GPUs the grid is dealt round-robin to the ranks)
+            # Independent sequences on one GPU (the runs of main_eval.m:22-23).  As a group of loops in lockstep:
+            # every kernel of a frame launched once for all of them ...
+            for S in (4, 8, 16):
+                extra["frames_per_s_group_of_%d" % S] = bench_group(vo, torch, ctx, scene, frames_all, poses_all, args.steps,
+                                                                    args.warmup, S, measure_tracker=S == 16)
+            # ... and as four loops on four host threads, a context and stream set each (what the group replaces)
+            steps_c = min(args.steps, 100)
+            extra["frames_per_s_4_sequences_at_once"] = bench_frames_concurrent(vo, torch, scene, frames_all, poses_all,
+                                                                                steps_c, args.warmup, 4)
+            extra["frames_per_sequence_in_that_figure"] = steps_c
+            # BASELINE's batch configuration on one GPU (with N GPUs the grid is dealt to the ranks longest first)
             extra["main_eval_grid_one_gpu"] = {
-                "workload": "main_eval.m:20-23: 2 feature variants (Harris, FAST) x 4 repetitions of one KITTI-shape sequence, "
-                            "images in host memory, bootstrap + loop + evaluation per run",
-                "one_run_at_a_time": bench_main_eval(vo, ctx, frames, poses, 1),
-                "four_runs_in_flight": bench_main_eval(vo, ctx, frames, poses, 4)}
+                "workload": "main_eval.m:20-23: 3 feature variants (Harris, MinEigen, FAST) x 4 repetitions of one KITTI-shape "
+                            "sequence of %d frames, images in host memory; bootstrap + loop + evaluation per run" % len(frames),
+                "one_run_at_a_time": bench_main_eval(vo, ctx, frames, poses),
+                "four_runs_in_flight": bench_main_eval(vo, ctx, frames, poses, concurrent=4),
+                "groups_of_8_loops_in_lockstep": bench_main_eval(vo, ctx, frames, poses, group=8)}
 
-        klt_frame = klt_stress = image_kernels = ba_runs = None
+        klt_loop = klt_stress = image_kernels = ba_runs = None
         n, h = args.points, args.hypotheses
+        hyps_per_s = score_ms = achieved = None
         if rank == 0:
+            # the roofline entry of the headline loop's own tracker launches (untimed replays of the timed frames)
+            klt_loop = tracker_of_loop(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100 + item)
+        if rank == 0 and not quick:
             d2 = [torch.from_numpy(f).to(torch.device("cuda", local_rank)) for f in frames[:2]]
             _, xy0 = init_points(vo, ctx, scene, frames[0], poses[0])
-            klt_frame = bench_klt(vo, torch, ctx, d2, xy0, info["n_landmarks"] + info["n_candidates"])
             klt_stress = bench_klt(vo, torch, ctx, d2, xy0, 8192)
             d_many = [torch.from_numpy(f).to(torch.device("cuda", local_rank)) for f in frames[:32]]
             image_kernels = bench_image_kernels(vo, torch, ctx, d2[0], d_frames=d_many)
@@ -630,7 +789,7 @@ def main():
 
     if rank == 0:
         traffic = traffic_from_profile("p3p_score_kernel<16, 1024>") if (n, h) == (8192, 4096) else None
-        klt_traffic = traffic_from_profile("klt_track_kernel<21>")
+        klt_traffic = traffic_from_profile("klt_track_kernel<21>", prefer="headline")
         out = {
             "metric": METRIC,
             "value": fps,
@@ -646,7 +805,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "KITTI-shape continuous operation: rendered corridor sequence 1241x376, Harris "
                                    "MinQuality 2e-4, 2 x KLT 21x21/5 levels, adaptive P3P RANSAC, pose refinement, "
-                                   "F-matrix filter, triangulation, candidate filter, no BA; one step = one frame; "
+                                   "F-matrix filter, triangulation, candidate filter, no BA; one step = one frame of ONE "
+                                   "sequence, frames resident in HBM; "
                                    "the sequence is stored, so each call also hands over the following frame, whose pyramid "
                                    "and corners are prepared beside the current localisation (results identical); "
                                    "every rank runs its own work item of the batch grid (own rendered sequence, own "
@@ -656,48 +816,55 @@ def main():
                        "final_position_error_m": info["final_position_error_m"],
                        "host_enqueue_us_per_frame": info["host_enqueue_us_per_frame"],
                        "host_wait_us_per_frame": info["host_wait_us_per_frame"],
+                       "gather_ms_inside_the_timed_region": 1e3 * gather_max,
                        "baseline_note": "vs_baseline divides by the reference's published 3.817 frames/s "
                                         "(MATLAB, Ryzen 7 5800H, real KITTI 05, Harris)"},
-            # The kernel the headline is bound by: the tracker (one launch per frame, landmarks + candidates).
-            # One wavefront per track; its hot loop reads the search region from LDS and runs fp32 FMAs, so the
-            # launch is priced against the LDS bandwidth (primary) and the fp32 vector peak; it is not HBM-bound
-            # (both pyramids, 5 MB, stay in L2 / Infinity Cache).
-            "roofline": {"kernel": "klt_track_kernel<21> (frame configuration: the tracks of one frame)",
+            # The kernel the headline is bound by: the tracker (two launches per frame: the landmarks the previous
+            # frame kept, and the landmarks it appended + the candidates).  One wavefront per track; its hot loop
+            # reads the search region from LDS and runs fp32 FMAs, so the launches are priced against the LDS
+            # bandwidth (primary) and the fp32 vector peak; they are not HBM-bound (both pyramids, 5 MB, stay in
+            # L2 / Infinity Cache).  Measured on the loop's OWN launches: durations from event pairs around every
+            # tracker launch of an untimed replay of the timed frames, work from the kernel's counters.
+            "roofline": {"kernel": "klt_track_kernel<21> (the headline loop's own launches, two per frame)",
                          "bound": "lds",
                          "bound_note": "neither hbm nor mfma: the binding resource is LDS read bandwidth / fp32 VALU issue, and at "
                                        "these sizes the latency of the slowest wavefront (a lost track runs all 200 iterations); "
                                        "achieved = algorithmic LDS bytes (441 px x 4 taps x 4 B per iteration) / kernel time",
-                         "achieved": klt_frame["achieved_lds_tbs"] * 1e3, "peak": LDS_PEAK_TBS * 1e3, "unit": "GB/s",
-                         "frac": klt_frame["frac_lds"],
-                         "frac_fp32_valu": klt_frame["frac_valu"], "achieved_tflops": klt_frame["achieved_tflops"],
+                         "achieved": klt_loop["achieved_lds_tbs"] * 1e3, "peak": LDS_PEAK_TBS * 1e3, "unit": "GB/s",
+                         "frac": klt_loop["frac_lds"],
+                         "frac_fp32_valu": klt_loop["frac_valu"], "achieved_tflops": klt_loop["achieved_tflops"],
                          "peak_tflops": FP32_VALU_PEAK_TFLOPS,
-                         "kernel_ms": klt_frame["kernel_ms"], "tracks": klt_frame["tracks"],
-                         "mean_iterations_per_pass": klt_frame["mean_iterations_per_pass"],
+                         "kernel_ms": klt_loop["kernel_ms_mean"], "kernel_ms_longest": klt_loop["kernel_ms_longest"],
+                         "launches": klt_loop["launches"], "tracks_per_launch": klt_loop["tracks_per_launch"],
+                         "tracker_us_per_frame": klt_loop["tracker_us_per_frame"],
+                         "mean_iterations_per_pass": klt_loop["mean_iterations_per_pass"],
                          "traffic": klt_traffic["bytes"] if klt_traffic else None,
                          "traffic_source": klt_traffic["source"] if klt_traffic else None,
-                         "traffic_note": "FETCH_SIZE + WRITE_SIZE per launch as rocprofv3 reports them (KB x 1024), averaged over the "
-                                         "launches of the profiled bench run (frame and stress legs); the kernel's loads are 4 B per lane, "
+                         "traffic_note": "FETCH_SIZE + WRITE_SIZE per launch as rocprofv3 reports them (KB x 1024) in the committed "
+                                         "counter passes of `bench.py --only-headline`; the kernel's loads are 4 B per lane, "
                                          "for which the counter is not calibrated on gfx950",
-                         "compulsory_hbm_bytes": klt_frame["compulsory_hbm_bytes"],
+                         "compulsory_hbm_bytes_per_frame": klt_loop["compulsory_hbm_bytes_per_frame"],
                          "stress_config_8192_tracks": klt_stress},
-            "ransac_hypotheses_per_s": hyps_per_s,
-            "ransac_config": {"workload": "RANSAC stress: %d P3P hypotheses x %d correspondences per step" % (h, n)},
-            "roofline_ransac": {"bound": "valu_fp64",
-                                "bound_note": "compute-bound on the fp64 vector ALUs (no MFMA is issued: a 3x4 projection per "
-                                              "point is no matrix-core shape); 78.6 TFLOP/s is the fp64 vector peak, 72 TFLOP/s "
-                                              "what a register-only FMA loop sustains (tools/micro/fp64_peak.hip)",
-                                "kernel": "p3p_score_kernel<16, 1024> (RANSAC stress)", "achieved": achieved,
-                                "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS,
-                                "traffic": traffic["bytes"] if traffic else None,
-                                "traffic_source": traffic["source"] if traffic else None,
-                                # 40 B per correspondence once, 4 x 12 doubles of K[R|t] in and 4 counts out per hypothesis
-                                "algorithmic_bytes": 40.0 * n + (384.0 + 16.0) * h,
-                                "kernel_ms": score_ms},
-            "roofline_image_kernels": image_kernels,
-            "bundle_adjustment": ba_runs,
         }
+        if hyps_per_s is not None:
+            out.update({
+                "ransac_hypotheses_per_s": hyps_per_s,
+                "ransac_config": {"workload": "RANSAC stress: %d P3P hypotheses x %d correspondences per step" % (h, n)},
+                "roofline_ransac": {"bound": "valu_fp64",
+                                    "bound_note": "compute-bound on the fp64 vector ALUs (no MFMA is issued: a 3x4 projection per "
+                                                  "point is no matrix-core shape); 78.6 TFLOP/s is the fp64 vector peak, 72 TFLOP/s "
+                                                  "what a register-only FMA loop sustains (tools/micro/fp64_peak.hip)",
+                                    "kernel": "p3p_score_kernel<16, 1024> (RANSAC stress)", "achieved": achieved,
+                                    "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VALU_PEAK_TFLOPS,
+                                    "traffic": traffic["bytes"] if traffic else None,
+                                    "traffic_source": traffic["source"] if traffic else None,
+                                    # 40 B per correspondence once, 4 x 12 doubles of K[R|t] in and 4 counts out per hypothesis
+                                    "algorithmic_bytes": 40.0 * n + (384.0 + 16.0) * h,
+                                    "kernel_ms": score_ms},
+                "roofline_image_kernels": image_kernels,
+                "bundle_adjustment": ba_runs})
         out.update(extra)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not quick:
             X0, xy0 = init_points(vo, ctx, scene, frames_all[0], poses_all[0])
             v, done, dt = cpu_baseline_frames(vo, scene, frames_all, poses_all, X0, xy0)
             out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "kind": "port",

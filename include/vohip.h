@@ -63,7 +63,8 @@ int vohip_synchronize(vohip_ctx *ctx);
 /* Tuning knobs (no reference counterpart).  "ransac_score_variant" 0..5 (-1 = automatic, the default) selects the workgroup
  * geometry (hypotheses per workgroup x points per LDS tile) of the RANSAC scoring kernel; results
  * do not depend on it.  "klt_stats" 1 makes the tracker count its work (see vohip_klt_stats; two
- * atomics per track, off by default). */
+ * atomics per track, off by default).  "klt_time" 1 brackets every tracker launch with a pair of timing
+ * events on the stream it runs on (see vohip_klt_time; measurement only, off by default). */
 int vohip_set_option(vohip_ctx *ctx, const char *name, int value);
 /* Library version, "major.minor". */
 const char *vohip_version(void);
@@ -299,7 +300,7 @@ int vohip_frame_finish(vohip_frame *f, vohip_frame_pose *pose, vohip_frame_count
 /* For a stored sequence (the loop of main_demo.m:352-375 reads its images from a directory): the n images
  * (pointers to host memory, or to device memory when the flag is set) are copied to the device and the
  * pyramids and corner lists of ALL of them are made by one batched launch sequence each (image = a grid
- * dimension; the FAST variant's corners are still detected frame by frame).  A later vohip_frame_begin /
+ * dimension).  A later vohip_frame_begin /
  * _step / _step_ahead whose `image` or `next_image` is one of these pointers then transfers nothing, builds no
  * pyramid and detects no corners for it; the results are those of the unprepared calls, bit for bit.  The
  * prepared data (about 2.7 MB per KITTI-shape image) lives until the next vohip_frame_prepare (n = 0 frees
@@ -321,8 +322,9 @@ int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, doub
  * The sequences are stored ones: vohip_group_prepare copies sequence `seq`'s n images (n <= max_frames;
  * image 0 is the one the loop is reset on, main_demo.m:342-344, images 1.. are the loop's frames) to the
  * device and makes all their pyramids and corner lists by batched launches, as vohip_frame_prepare does
- * (detector < 0: the group's detector and thresholds; else 0 Harris / 1 MinEigen with min_quality: the
- * feature variants of main_eval.m:165-174 may share a group, the loop only reads the corner lists).
+ * (detector < 0: the group's detector and thresholds; else 0 Harris / 1 MinEigen / 2 FAST with min_quality
+ * and, for FAST, min_contrast: the feature variants of main_eval.m:165-174 may share a group, the loop only
+ * reads the corner lists).
  * vohip_group_reset gives sequence `seq` its initial state (as vohip_frame_reset; the image is prepared
  * image 0).  The first reset after a frame was processed starts a new run of the group: sequences that
  * are not reset again stay idle in it.
@@ -472,6 +474,10 @@ int vohip_klt_track_dev(vohip_ctx *ctx, int slot_prev, int slot_cur, const doubl
  * tracks processed and Gauss-Newton iterations executed over all levels and both directions.
  * Synchronises the device. */
 int vohip_klt_stats(vohip_ctx *ctx, long long *tracks, long long *iterations, int reset);
+/* With the option "klt_time": the tracker launches since the last reset (at most 1024 are recorded) -- the sum
+ * and the longest of their durations in milliseconds, as the event pair around each launch measured it on the
+ * launch's own stream, and their number.  Synchronises the device.  No reference counterpart. */
+int vohip_klt_time(vohip_ctx *ctx, double *total_ms, double *longest_ms, int *launches, int reset);
 
 /* ---- fundamental-matrix RANSAC -----------------------------------------------------------
  * Stands in for [F, inliersIndex] = estimateFundamentalMatrix(p1, p2, 'NumTrials', 500, 'Method',

@@ -84,6 +84,7 @@ SIGNATURES = {
     "vohip_frame_bundle_adjust": (C.c_int, [C.c_void_p, C.c_void_p, c_double_p, c_int_p, c_int_p, c_int_p, c_double_p,
                                              C.c_int]),
     "vohip_klt_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_int]),
+    "vohip_klt_time": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_int_p, C.c_int]),
     "vohip_frame_default_params": (None, [C.POINTER(FrameParams)]),
     "vohip_frame_create": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams),
                                       C.POINTER(C.c_void_p)]),

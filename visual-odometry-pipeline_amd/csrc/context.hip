@@ -112,6 +112,11 @@ int vohip_destroy(vohip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < VOHIP_NBUF; ++i) vohip_release(ctx->bufs[i]);
+    if (ctx->klt_ev) {
+        for (int i = 0; i < 2 * vohip_ctx::KLT_TIME_PAIRS; ++i)
+            if (ctx->klt_ev[i]) (void)hipEventDestroy(ctx->klt_ev[i]);
+        delete[] ctx->klt_ev;
+    }
     if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VOHIP_OK;
@@ -127,6 +132,17 @@ int vohip_set_option(vohip_ctx *ctx, const char *name, int value)
     VOHIP_REQUIRE(ctx, name, "NULL option name");
     if (std::strcmp(name, "klt_stats") == 0) {
         ctx->opt_klt_stats = value ? 1 : 0;
+        return VOHIP_OK;
+    }
+    if (std::strcmp(name, "klt_time") == 0) {
+        if (value && !ctx->klt_ev) {
+            VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+            ctx->klt_ev = new (std::nothrow) hipEvent_t[2 * vohip_ctx::KLT_TIME_PAIRS]();
+            if (!ctx->klt_ev) return vohip_fail(ctx, VOHIP_ERR_HIP, "out of host memory");
+            for (int i = 0; i < 2 * vohip_ctx::KLT_TIME_PAIRS; ++i) VOHIP_HIP(ctx, hipEventCreate(&ctx->klt_ev[i]));
+        }
+        ctx->opt_klt_time = value ? 1 : 0;
+        ctx->klt_ev_used = 0;
         return VOHIP_OK;
     }
     if (std::strcmp(name, "ransac_score_variant") == 0) {

@@ -1837,7 +1837,7 @@ int vohip_frame_prepare(vohip_frame *f, const uint8_t *const *images, int n, int
     const vohip_frame_params &p = f->prm;
     const size_t img_bytes = (size_t)f->rows * f->cols;
     const size_t pyr_floats = vohip_pyramid_floats(f->rows, f->cols, f->colmajor, p.klt_levels);
-    const bool corners = p.detector != 2 && f->capK <= 16384;   // (the FAST variant is detected frame by frame)
+    const bool corners = f->capK <= 16384;
     auto round256 = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t b_img = round256(img_bytes * n), b_pyr = round256(sizeof(float) * pyr_floats * n),
                  b_xy = corners ? round256(sizeof(float) * 2 * (size_t)f->capK * n) : 0,
@@ -1869,7 +1869,7 @@ int vohip_frame_prepare(vohip_frame *f, const uint8_t *const *images, int n, int
             VOHIP_TRY(vohip_detect_corners_batch_enqueue(ctx, f->prep_imgs + img_bytes * c, m, f->rows, f->cols, f->colmajor,
                                                          p.min_quality, p.filter_size, p.border, p.detector,
                                                          xy + 2 * (size_t)f->capK * c, f->prep_metric + (size_t)f->capK * c, f->capK,
-                                                         f->prep_counts + c));
+                                                         f->prep_counts + c, p.min_contrast));
         }
     }
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
@@ -2100,7 +2100,7 @@ int vohip_group_prepare(vohip_group *g, int seq, const uint8_t *const *images, i
         min_quality = p.min_quality;
         min_contrast = p.min_contrast;
     }
-    VOHIP_REQUIRE(ctx, detector == 0 || detector == 1, "prepared sequences: Harris or MinEigen corners");
+    VOHIP_REQUIRE(ctx, detector >= 0 && detector <= 2, "detector: 0 = Harris, 1 = MinEigen, 2 = FAST");
     const size_t img_bytes = (size_t)f->rows * f->cols;
     uint8_t *imgs = prep_of_seq(f, f->prep_imgs, seq);
     for (int k = 0; k < n; ++k) {
@@ -2116,7 +2116,7 @@ int vohip_group_prepare(vohip_group *g, int seq, const uint8_t *const *images, i
         const int m = n - c < chunk ? n - c : chunk;
         VOHIP_TRY(vohip_detect_corners_batch_enqueue(ctx, imgs + img_bytes * c, m, f->rows, f->cols, f->colmajor, min_quality,
                                                      p.filter_size, p.border, detector, xy + 2 * (size_t)f->capK * c,
-                                                     metric + (size_t)f->capK * c, f->capK, counts + c));
+                                                     metric + (size_t)f->capK * c, f->capK, counts + c, min_contrast));
     }
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
     f->seqs[seq].n_frames = n;

@@ -282,8 +282,13 @@ __global__ __launch_bounds__(256) void fast_tile_kernel(const uint8_t *__restric
                                                         int tiles_b, int threshold, int lo,
                                                         corner_rec *__restrict__ recs, int *__restrict__ tile_count,
                                                         unsigned *__restrict__ max_now,
-                                                        unsigned *__restrict__ max_next)
+                                                        unsigned *__restrict__ max_next, corner_batch bt)
 {
+    img += blockIdx.y * bt.img;
+    recs += blockIdx.y * bt.recs;
+    tile_count += blockIdx.y * (size_t)bt.tiles;
+    max_now += blockIdx.y * (size_t)bt.max_slots;
+    max_next += blockIdx.y * (size_t)bt.max_slots;
     constexpr int FA = TA + 8, FB = TB + 8;
     __shared__ int sI[FA * FB];
     __shared__ float sR[RA * RB];
@@ -541,7 +546,7 @@ int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, 
     if (method == 2)   // the contrast threshold on the uint8 scale, rounded as MATLAB's uint8() rounds
         hipLaunchKernelGGL(fast_tile_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, st, d_img, A, B, tiles_a, tiles_b,
                            (int)std::floor(min_contrast * 255.0 + 0.5), lo, recs, tile_count, max2 + slot,
-                           max2 + (slot ^ 1u));
+                           max2 + (slot ^ 1u), corner_batch());
     else
         hipLaunchKernelGGL(corner_tile_kernel, dim3(8 * ((ntiles + 7) / 8)), dim3(256), 0, st, d_img, A, B, tiles_a,
                            tiles_b, G, method, lo, recs, tile_count, max2 + slot, max2 + (slot ^ 1u), corner_batch());
@@ -560,13 +565,14 @@ int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, 
 // counts, maximum and output lists, so the lists are those of n single calls, bit for bit.
 int vohip_detect_corners_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
                                        double min_quality, int filter_size, int border, int method, float *d_xy,
-                                       float *d_metric, int cap, int *d_counts)
+                                       float *d_metric, int cap, int *d_counts, double min_contrast)
 {
     VOHIP_REQUIRE(ctx, d_imgs && d_xy && d_metric && d_counts, "NULL argument");
     VOHIP_REQUIRE(ctx, n >= 1 && n <= 65535, "1..65535 images per call");
     VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
-    VOHIP_REQUIRE(ctx, method == 0 || method == 1, "method: 0 = Harris, 1 = MinEigen");
-    VOHIP_REQUIRE(ctx, filter_size == FS, "only FilterSize 5 (the toolbox default) is built");
+    VOHIP_REQUIRE(ctx, method >= 0 && method <= 2, "method: 0 = Harris, 1 = MinEigen, 2 = FAST");
+    VOHIP_REQUIRE(ctx, method == 2 || filter_size == FS, "only FilterSize 5 (the toolbox default) is built");
+    VOHIP_REQUIRE(ctx, method != 2 || (min_contrast > 0.0 && min_contrast < 1.0), "MinContrast must lie in (0, 1)");
     VOHIP_REQUIRE(ctx, cap >= 1 && cap <= 16384, "cap must be 1..16384");
     VOHIP_REQUIRE(ctx, border >= 0, "negative border");
     const int A = colmajor ? rows : cols, B = colmajor ? cols : rows;
@@ -602,8 +608,12 @@ int vohip_detect_corners_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, in
     taps5 G;
     gaussian_taps(filter_size, G.w);
     const int lo = border < 1 ? 1 : border;
-    hipLaunchKernelGGL(corner_tile_kernel, dim3(8 * ((ntiles + 7) / 8), n), dim3(256), 0, st, d_imgs, A, B, tiles_a, tiles_b,
-                       G, method, lo, recs, tile_count, maxima, spare, bt);
+    if (method == 2)
+        hipLaunchKernelGGL(fast_tile_kernel, dim3(8 * ((ntiles + 7) / 8), n), dim3(256), 0, st, d_imgs, A, B, tiles_a, tiles_b,
+                           (int)std::floor(min_contrast * 255.0 + 0.5), lo, recs, tile_count, maxima, spare, bt);
+    else
+        hipLaunchKernelGGL(corner_tile_kernel, dim3(8 * ((ntiles + 7) / 8), n), dim3(256), 0, st, d_imgs, A, B, tiles_a, tiles_b,
+                           G, method, lo, recs, tile_count, maxima, spare, bt);
     hipLaunchKernelGGL(corner_count_kernel, dim3((ntiles + 3) / 4, n), dim3(256), 0, st, (const corner_rec *)recs,
                        (const int *)tile_count, ntiles, tiles_a, A, (float)min_quality, (const unsigned *)maxima, cells, totals,
                        bt);

@@ -731,6 +731,9 @@ int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vo
         VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     unsigned long long *d_stats = ctx->opt_klt_stats ? (unsigned long long *)ctx->bufs[B_KLT_STATS].ptr : nullptr;
+    // (measurement only: an event pair around the launch, on the stream it runs on)
+    const bool timed = ctx->opt_klt_time && ctx->klt_ev && ctx->klt_ev_used < vohip_ctx::KLT_TIME_PAIRS;
+    if (timed) VOHIP_HIP(ctx, hipEventRecord(ctx->klt_ev[2 * ctx->klt_ev_used], ctx->stream));
     if (block_size == 21)
         hipLaunchKernelGGL(klt_track_kernel<21>, dim3(total, ny), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
                            max_bidir_error, lmin_threshold(21), d_stats, SQ);
@@ -740,6 +743,10 @@ int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vo
     else
         return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "BlockSize %d not built (21 and 31 are)", block_size);
     VOHIP_HIP(ctx, hipGetLastError());
+    if (timed) {
+        VOHIP_HIP(ctx, hipEventRecord(ctx->klt_ev[2 * ctx->klt_ev_used + 1], ctx->stream));
+        ctx->klt_ev_used += 1;
+    }
     return VOHIP_OK;
 }
 
@@ -761,6 +768,25 @@ int vohip_klt_stats(vohip_ctx *ctx, long long *tracks, long long *iterations, in
     if (std::getenv("VOHIP_KLT_CYCLES")) std::fprintf(stderr, "vohip klt: longest track %llu ticks\n", h[2]);
     if (tracks) *tracks = (long long)h[0];
     if (iterations) *iterations = (long long)h[1];
+    return VOHIP_OK;
+}
+
+int vohip_klt_time(vohip_ctx *ctx, double *total_ms, double *longest_ms, int *launches, int reset)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    VOHIP_HIP(ctx, hipDeviceSynchronize());   // (tracker launches run on several streams of a frame loop)
+    double sum = 0.0, longest = 0.0;
+    for (int k = 0; k < ctx->klt_ev_used; ++k) {
+        float ms = 0.f;
+        VOHIP_HIP(ctx, hipEventElapsedTime(&ms, ctx->klt_ev[2 * k], ctx->klt_ev[2 * k + 1]));
+        sum += ms;
+        longest = ms > longest ? ms : longest;
+    }
+    if (total_ms) *total_ms = sum;
+    if (longest_ms) *longest_ms = longest;
+    if (launches) *launches = ctx->klt_ev_used;
+    if (reset) ctx->klt_ev_used = 0;
     return VOHIP_OK;
 }
 

@@ -63,6 +63,11 @@ struct vohip_ctx {
     int opt_ransac_variant = -1;  // scoring-kernel geometry, see vohip_set_option
     int opt_klt_stats = 0;        // count tracker work (two atomics per track), see vohip_klt_stats
     unsigned harris_calls = 0;    // uses of B_HARRIS_SCRATCH (its two maximum slots alternate)
+    // tracker launches timed with event pairs on the streams they run on (option "klt_time", see vohip_klt_time)
+    int opt_klt_time = 0;
+    static constexpr int KLT_TIME_PAIRS = 1024;
+    hipEvent_t *klt_ev = nullptr;   // 2 * KLT_TIME_PAIRS events, created with the option
+    int klt_ev_used = 0;            // pairs recorded since the last reset
 };
 
 // The independent sequences one launch of a frame-loop kernel serves (a group of loops advanced in lockstep,
@@ -198,7 +203,7 @@ int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, 
 int vohip_pyramid_attach(vohip_ctx *ctx, int slot, const float *d_pyr, int rows, int cols, int colmajor, int levels);
 int vohip_detect_corners_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
                                        double min_quality, int filter_size, int border, int method, float *d_xy,
-                                       float *d_metric, int cap, int *d_counts);
+                                       float *d_metric, int cap, int *d_counts, double min_contrast = 0.2);
 int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, const double *d_X, int n,
                               const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
                               double *d_stats, const vohip_seqs *seqs = nullptr);

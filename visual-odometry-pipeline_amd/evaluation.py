@@ -198,8 +198,8 @@ def run_group(runs, ctx=None, group=None, n_slots=None, max_frames=None):
     """Several full runs (each what run_sequence does: bootstrap, continuous operation, timing, evaluation,
     result file) whose loops advance together as ONE group of loops in lockstep (VOGroupDevice): every kernel
     of a frame is launched once for all of them.  The runs must share the image shape and camera matrix and
-    differ at most in images, generator and corner detector (Harris / MinEigen with their thresholds): the
-    independent runs of main_eval.m:22-23.  A run's trajectory, counts, state and errs are those run_sequence
+    differ at most in images, generator and corner detector (with its thresholds): the independent runs of
+    main_eval.m:22-23.  A run's trajectory, counts, state and errs are those run_sequence
     gives it, bit for bit.
 
     runs: list of dicts with keys images, K, hyper_paras, rng and optionally ground_truth, bootstrap_frames,
@@ -241,7 +241,8 @@ def run_group(runs, ctx=None, group=None, n_slots=None, max_frames=None):
             # the loop's images: the last bootstrap image (the one the trackers are initialised on, :342-349),
             # then the frames of :351
             group.add_sequence(s, list(r["images"][b["b2"]:]), b["p_W"], b["kp"], b["T0"], rng=r["rng"],
-                               feature_extract=hp.feature_extract, min_quality=fo.get("MinQuality"))
+                               feature_extract=hp.feature_extract, min_quality=fo.get("MinQuality"),
+                               min_contrast=fo.get("MinContrast"))
         group.run()
         loop_s = time.perf_counter() - t_ct                                 # :446
         states = [group.S(s) if group.seqs[s].error is None else None for s in range(len(runs))]
@@ -302,8 +303,8 @@ def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0,
     script stops with an error, main_demo.m:389-391) ends the grid, as in the reference; "record" -- its record
     is marked failed (no trajectory) and the grid goes on.
     group: > 1 -- a rank advances up to that many of its runs together as a group of loops in lockstep
-    (run_group: one launch sequence per frame for all of them; Harris / MinEigen runs without bundle adjustment
-    of one image shape and camera; the others run one at a time).  A run's record does not depend on it, apart
+    (run_group: one launch sequence per frame for all of them; runs without bundle adjustment of one image
+    shape and camera; the others run one at a time).  A run's record does not depend on it, apart
     from its timings (see run_group).
     balance: deal the runs longest first by frame count (batch.shard) instead of round-robin.
     timing: a dict that receives this rank's run and gather seconds."""
@@ -351,7 +352,7 @@ def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0,
     def groupable(item):
         si, feat, _ = item
         hp = sequences[si].get("hyper_paras") or default_hyper_paras(sequences[si]["name"])
-        return feat in ("Harris", "MinEigen") and not hp.is_BA
+        return not hp.is_BA
 
     def share_runner(mine):
         """This rank's share: groupable runs in groups of `group` (same shape and camera), the rest one by one."""

@@ -315,8 +315,8 @@ class VOGroupDevice:
         self.hp = hyper_paras or default_hyper_paras()
         if self.hp.is_BA:
             raise NotImplementedError("bundle adjustment is not available in a group of loops")
-        if self.hp.feature_extract not in ("Harris", "MinEigen"):
-            raise NotImplementedError("a group of loops reads prepared corner lists: Harris or MinEigen")
+        if self.hp.feature_extract not in DETECTORS:
+            raise NotImplementedError("detector '%s' is not built" % self.hp.feature_extract)
         lib = _lib.load()
         prm = _lib.FrameParams()
         lib.vohip_frame_default_params(C.byref(prm))
@@ -330,6 +330,7 @@ class VOGroupDevice:
         fo = dict(zip(self.hp.feature_extract_options[::2], self.hp.feature_extract_options[1::2]))
         prm.detector = DETECTORS[self.hp.feature_extract]
         prm.min_quality = float(fo.get("MinQuality", DEFAULT_MIN_QUALITY[self.hp.feature_extract]))
+        prm.min_contrast = float(fo.get("MinContrast", 0.2))
         prm.filter_size = int(fo.get("FilterSize", 5))
         prm.r_discard_redundant = float(self.hp.r_discard_redundant)
         prm.angle_threshold_deg = float(self.hp.angle_threshold)
@@ -360,10 +361,10 @@ class VOGroupDevice:
         self.host_wait_us = 0.0
 
     def add_sequence(self, seq, images, p_W_landmarks, keypoints_xy, T_init_WC, rng=None, rng_map=None,
-                     feature_extract=None, min_quality=None):
+                     feature_extract=None, min_quality=None, min_contrast=None):
         """Sequence `seq` of the group: its stored images, the state its loop starts from (as VOPipelineDevice's
-        constructor takes it) and its generators.  feature_extract / min_quality: this sequence's detector when it
-        differs from the group's (the feature variants of main_eval.m:165-174)."""
+        constructor takes it) and its generators.  feature_extract / min_quality / min_contrast: this sequence's
+        detector when it differs from the group's (the feature variants of main_eval.m:165-174)."""
         if self.frames:
             self.frames = 0   # (the library starts a new run with the first reset after a frame)
             self.host_enqueue_us = self.host_wait_us = 0.0
@@ -391,11 +392,10 @@ class VOGroupDevice:
             keep.append(k)
         arr = (C.c_void_p * len(ptrs))(*ptrs)
         det = -1 if feature_extract is None else DETECTORS[feature_extract]
-        if det not in (-1, 0, 1):
-            raise NotImplementedError("a group of loops reads prepared corner lists: Harris or MinEigen")
         mq = float(min_quality) if min_quality is not None else (
             DEFAULT_MIN_QUALITY[feature_extract] if feature_extract is not None else 0.0)
-        self.ctx.check(lib.vohip_group_prepare(self._h, int(seq), arr, len(ptrs), int(on_dev), det, mq, 0.0))
+        mc = float(min_contrast) if min_contrast is not None else 0.2     # detectFASTFeatures' default
+        self.ctx.check(lib.vohip_group_prepare(self._h, int(seq), arr, len(ptrs), int(on_dev), det, mq, mc))
         X = np.ascontiguousarray(np.asarray(p_W_landmarks, dtype=np.float64).reshape(-1, 3))
         P_rc = np.ascontiguousarray(np.asarray(keypoints_xy, dtype=np.float64).reshape(-1, 2)[:, ::-1])
         T = np.asarray(T_init_WC, dtype=np.float64)
