@@ -344,6 +344,12 @@ int vohip_group_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
 int vohip_group_destroy(vohip_group *g);
 int vohip_group_prepare(vohip_group *g, int seq, const uint8_t *const *images, int n, int on_device, int detector,
                         double min_quality, double min_contrast);
+/* vohip_group_prepare for a sequence that holds the same images as the prepared sequence from_seq (the
+ * repetitions and feature variants of main_eval.m:22-23 run over one image sequence): images and pyramids
+ * are copied on the device instead of being uploaded and built again; detector -2 copies the corner lists
+ * too, otherwise they are detected as vohip_group_prepare would. */
+int vohip_group_prepare_like(vohip_group *g, int seq, int from_seq, int detector, double min_quality,
+                             double min_contrast);
 int vohip_group_reset(vohip_group *g, int seq, const double *X, const double *ids, const double *P_rc, int n,
                       const double T_W_C[16]);
 int vohip_group_begin(vohip_group *g, const double *u3, int h, const double *u8);
@@ -419,6 +425,13 @@ int vohip_frame_bundle_adjust(vohip_frame *f, vohip_window *w, const double T_W_
  * Levenberg-Marquardt of vohip_pose_refine with analytic Jacobians. */
 int vohip_align_sim3(vohip_ctx *ctx, const double *pp_G_C, const double *p_V_C, int n, int max_iter, double ftol,
                      double xtol, double *x, double *p_G_C, double *stats);
+/* The alignments of utils/quantitative_eval.m:20-27 for one trajectory at once: checkpoint b aligns the first
+ * lengths[b] points of the estimate to the first lengths[b] points of the ground truth (:23-24), k checkpoints
+ * side by side in one launch, each exactly as vohip_align_sim3 computes it.  x (7 x k), stats (3 x k) may be
+ * NULL; first_last (6 x k) receives the first and the last aligned point of every prefix, the two points
+ * :25-26 read. */
+int vohip_align_sim3_prefixes(vohip_ctx *ctx, const double *pp_G_C, const double *p_V_C, int n, int k, const int *lengths,
+                              int max_iter, double ftol, double xtol, double *x, double *first_last, double *stats);
 
 /* ---- relative pose (bootstrap) ---------------------------------------------------------------
  * Stands in for [orientation, location] = relativeCameraPose(E, cameraParams, pts1, pts2) at

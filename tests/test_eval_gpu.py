@@ -32,6 +32,26 @@ def test_alignment_matches_oracle(vo, ctx, oracle, n, seed):
     np.testing.assert_allclose(vo.alignError(xg, gt, est, ctx=ctx), oracle.align_error(xg, gt, est), atol=1e-12)
 
 
+def test_prefix_alignments_equal_single_calls(vo, ctx):
+    """vohip_align_sim3_prefixes (the checkpoints of quantitative_eval.m:20-27 side by side in one launch) gives each
+    prefix what vohip_align_sim3 gives it alone, bit for bit."""
+    import ctypes as C
+    lib = vo._lib.load()
+    gt, est = _trajectory(vo, 540, 7)
+    lengths = [21, 83, 84, 256, 257, 540, 1]
+    k = len(lengths)
+    g, e = vo._lib.colmajor(gt), vo._lib.colmajor(est)
+    x, fl, st = np.zeros((k, 7)), np.zeros((k, 6)), np.zeros((k, 3))
+    ctx.check(lib.vohip_align_sim3_prefixes(ctx.handle, vo._lib.dptr(g), vo._lib.dptr(e), 540, k, (C.c_int * k)(*lengths), 400,
+                                            1e-6, 1e-6, vo._lib.dptr(x), vo._lib.dptr(fl), vo._lib.dptr(st)))
+    for b, n in enumerate(lengths):
+        al, xs, ss = vo.alignEstimateToGroundTruth(gt[:, :n], est[:, :n], return_x=True, ctx=ctx)
+        np.testing.assert_array_equal(x[b], xs)
+        np.testing.assert_array_equal(fl[b, :3], al[:, 0])
+        np.testing.assert_array_equal(fl[b, 3:], al[:, -1])
+        assert (st[b, 0], st[b, 2]) == (ss["iterations"], ss["cost"])
+
+
 def test_quantitative_eval_matches_oracle(vo, ctx, oracle):
     from types import SimpleNamespace
     from oracle import pipeline_oracle as po

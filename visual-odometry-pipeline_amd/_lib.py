@@ -104,11 +104,14 @@ SIGNATURES = {
     "vohip_frame_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                      c_double_p]),
     "vohip_frame_apply_ba": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
+    "vohip_align_sim3_prefixes": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, C.c_int, c_int_p, C.c_int, C.c_double,
+                                            C.c_double, c_double_p, c_double_p, c_double_p]),
     "vohip_group_create": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int, C.c_int, C.POINTER(FrameParams), C.c_int,
                                      C.c_int, C.POINTER(C.c_void_p)]),
     "vohip_group_destroy": (C.c_int, [C.c_void_p]),
     "vohip_group_prepare": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_double,
                                       C.c_double]),
+    "vohip_group_prepare_like": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]),
     "vohip_group_reset": (C.c_int, [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p]),
     "vohip_group_begin": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
     "vohip_group_finish": (C.c_int, [C.c_void_p, C.POINTER(FramePose), C.POINTER(FrameCounts), c_int_p]),

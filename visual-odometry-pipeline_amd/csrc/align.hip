@@ -10,6 +10,8 @@
 #include "vohip_internal.h"
 #include "se3_device.h"
 
+#include <vector>
+
 using namespace vohip_dev;
 
 namespace {
@@ -73,30 +75,59 @@ __device__ __forceinline__ void sim3_apply(const sim3_lin &f, const double p[3],
     for (int i = 0; i < 3; ++i) y[i] = f.s * (f.R[i][0] * p[0] + f.R[i][1] * p[1] + f.R[i][2] * p[2]) + f.t[i];
 }
 
-__device__ __forceinline__ double al_block_sum(double v, double *sWave)
+// Sums over the workgroup of the NS values every thread holds: butterflies inside each wavefront, the
+// wavefronts' partial sums through LDS (one barrier), added in wavefront order by the first NS threads and left
+// in sOut (visible after the second barrier).  Two barriers per set of sums, whatever their number.
+template <int NS>
+__device__ __forceinline__ void al_block_sums(double (&v)[NS], double *sPart, double *sOut)
 {
+    constexpr int NW = AL_THREADS / 64;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sWave[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double t = 0.0;
+    for (int q = 0; q < NS; ++q) {
 #pragma unroll
-    for (int w = 0; w < AL_THREADS / 64; ++w) t += sWave[w];
-    return t;
+        for (int m = 32; m >= 1; m >>= 1) v[q] += __shfl_xor(v[q], m, 64);
+    }
+    __syncthreads();   // (sPart and sOut of the previous round have been read)
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q) sPart[NW * q + (threadIdx.x >> 6)] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += sPart[NW * threadIdx.x + w];
+        sOut[threadIdx.x] = t;
+    }
+    __syncthreads();
 }
 
+// One workgroup per problem.  desc == NULL: a single problem over points [0, n).  Otherwise problem b =
+// blockIdx.x reads points [desc[3b], desc[3b] + desc[3b + 1]) of gt / est and writes its aligned points from
+// point desc[3b + 2] of `aligned` on, x_out + 7 b and stats + 3 b (the checkpoints of quantitative_eval.m:20-27
+// are prefixes of one trajectory: they share their input and run side by side).
 // gt, est 3 x n column-major.  x_out[7]; aligned 3 x n; stats = {iterations, cost0, cost}.
 __global__ __launch_bounds__(AL_THREADS) void align_sim3_kernel(const double *__restrict__ gt,
                                                                 const double *__restrict__ est, int n, int max_iter,
                                                                 double ftol, double xtol, double *__restrict__ x_out,
                                                                 double *__restrict__ aligned,
-                                                                double *__restrict__ stats)
+                                                                double *__restrict__ stats,
+                                                                const int *__restrict__ desc)
 {
+    constexpr int NH = NP * (NP + 1) / 2, NS = NH + NP;
     __shared__ sim3_lin sF, sFn;
-    __shared__ double sX[NP], sXn[NP], sH[NP * NP], sG[NP], sD[NP], sWave[AL_THREADS / 64];
+    __shared__ double sX[NP], sXn[NP], sH[NP * NP], sG[NP], sD[NP], sPart[(AL_THREADS / 64) * NS], sSum[NS];
     __shared__ int sOk;
     const int tid = threadIdx.x;
+    if (desc) {
+        const int b = blockIdx.x;
+        gt += 3 * (size_t)desc[3 * b];
+        est += 3 * (size_t)desc[3 * b];
+        n = desc[3 * b + 1];
+        aligned += 3 * (size_t)desc[3 * b + 2];
+        x_out += NP * (size_t)b;
+        stats += 3 * (size_t)b;
+    }
     if (tid == 0) {
         for (int k = 0; k < NP; ++k) sX[k] = k == 6 ? 1.0 : 0.0;
         double x[NP];
@@ -105,26 +136,26 @@ __global__ __launch_bounds__(AL_THREADS) void align_sim3_kernel(const double *__
     }
     __syncthreads();
     auto cost_of = [&](const sim3_lin &f) {
-        double c = 0.0;
+        double c[1] = {0.0};
         for (int k = tid; k < n; k += AL_THREADS) {
             const double p[3] = {est[3 * k], est[3 * k + 1], est[3 * k + 2]};
             double y[3];
             sim3_apply(f, p, y);
             for (int i = 0; i < 3; ++i) {
                 const double e = gt[3 * k + i] - y[i];
-                c += e * e;
+                c[0] += e * e;
             }
         }
-        return al_block_sum(c, sWave);
+        al_block_sums<1>(c, sPart, sSum);
+        return sSum[0];
     };
     double cost = cost_of(sF);
     const double cost0 = cost;
     double lambda = 1e-3;
     int iter = 0, rejects = 0;
     while (iter < max_iter) {
-        double h[NP * (NP + 1) / 2], g[NP];
-        for (int q = 0; q < NP * (NP + 1) / 2; ++q) h[q] = 0.0;
-        for (int q = 0; q < NP; ++q) g[q] = 0.0;
+        double hg[NS];   // upper triangle of J'J, then J'e
+        for (int q = 0; q < NS; ++q) hg[q] = 0.0;
         for (int k = tid; k < n; k += AL_THREADS) {
             const double p[3] = {est[3 * k], est[3 * k + 1], est[3 * k + 2]};
             double y[3], e[3], J[3][NP];   // J = d error / d x = -dy/dx
@@ -143,22 +174,17 @@ __global__ __launch_bounds__(AL_THREADS) void align_sim3_kernel(const double *__
             int q = 0;
 #pragma unroll
             for (int a = 0; a < NP; ++a) {
-                g[a] += J[0][a] * e[0] + J[1][a] * e[1] + J[2][a] * e[2];
+                hg[NH + a] += J[0][a] * e[0] + J[1][a] * e[1] + J[2][a] * e[2];
 #pragma unroll
-                for (int b = a; b < NP; ++b) h[q++] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b];
+                for (int b = a; b < NP; ++b) hg[q++] += J[0][a] * J[0][b] + J[1][a] * J[1][b] + J[2][a] * J[2][b];
             }
         }
-        {
+        al_block_sums<NS>(hg, sPart, sSum);
+        if (tid == 0) {
             int q = 0;
             for (int a = 0; a < NP; ++a)
-                for (int b = a; b < NP; ++b) {
-                    const double s = al_block_sum(h[q++], sWave);
-                    if (tid == 0) sH[NP * a + b] = sH[NP * b + a] = s;
-                }
-            for (int a = 0; a < NP; ++a) {
-                const double s = al_block_sum(g[a], sWave);
-                if (tid == 0) sG[a] = s;
-            }
+                for (int b = a; b < NP; ++b) sH[NP * a + b] = sH[NP * b + a] = sSum[q++];
+            for (int a = 0; a < NP; ++a) sG[a] = sSum[NH + a];
         }
         __syncthreads();
         bool accepted = false, stop = false;
@@ -267,8 +293,10 @@ __global__ __launch_bounds__(AL_THREADS) void align_sim3_kernel(const double *__
 
 }  // namespace
 
-extern "C" int vohip_align_sim3(vohip_ctx *ctx, const double *pp_G_C, const double *p_V_C, int n, int max_iter,
-                                double ftol, double xtol, double *x, double *p_G_C, double *stats)
+extern "C" {
+
+int vohip_align_sim3(vohip_ctx *ctx, const double *pp_G_C, const double *p_V_C, int n, int max_iter,
+                     double ftol, double xtol, double *x, double *p_G_C, double *stats)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, pp_G_C && p_V_C && p_G_C, "NULL argument");
@@ -280,7 +308,7 @@ extern "C" int vohip_align_sim3(vohip_ctx *ctx, const double *pp_G_C, const doub
     VOHIP_TRY(vohip_upload(ctx, B_STAGE2, nullptr, bytes + sizeof(double) * 10, &d_out));
     double *d_x = (double *)d_out + 3 * (size_t)n;
     hipLaunchKernelGGL(align_sim3_kernel, dim3(1), dim3(AL_THREADS), 0, ctx->stream, (const double *)d_gt,
-                       (const double *)d_est, n, max_iter, ftol, xtol, d_x, (double *)d_out, d_x + 7);
+                       (const double *)d_est, n, max_iter, ftol, xtol, d_x, (double *)d_out, d_x + 7, (const int *)nullptr);
     VOHIP_HIP(ctx, hipGetLastError());
     double tail[10];
     VOHIP_TRY(vohip_download(ctx, p_G_C, d_out, bytes));
@@ -292,3 +320,45 @@ extern "C" int vohip_align_sim3(vohip_ctx *ctx, const double *pp_G_C, const doub
         for (int k = 0; k < 3; ++k) stats[k] = tail[7 + k];
     return VOHIP_OK;
 }
+
+int vohip_align_sim3_prefixes(vohip_ctx *ctx, const double *pp_G_C, const double *p_V_C, int n, int k, const int *lengths,
+                              int max_iter, double ftol, double xtol, double *x, double *first_last, double *stats)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, pp_G_C && p_V_C && lengths && first_last, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 1 && max_iter >= 0 && k >= 0 && k <= 4096, "bad sizes");
+    if (k == 0) return VOHIP_OK;
+    std::vector<int> desc(3 * (size_t)k);
+    size_t total = 0;
+    for (int b = 0; b < k; ++b) {
+        VOHIP_REQUIRE(ctx, lengths[b] >= 1 && lengths[b] <= n, "a prefix holds 1..n points");
+        desc[3 * b] = 0;
+        desc[3 * b + 1] = lengths[b];
+        desc[3 * b + 2] = (int)total;
+        total += (size_t)lengths[b];
+        VOHIP_REQUIRE(ctx, total < 0x3fffffff, "too many points");
+    }
+    void *d_gt, *d_est, *d_out, *d_desc;
+    const size_t bytes = sizeof(double) * 3 * (size_t)n;
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE0, pp_G_C, bytes, &d_gt));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE1, p_V_C, bytes, &d_est));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE2, nullptr, sizeof(double) * (3 * total + 10 * (size_t)k), &d_out));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE3, desc.data(), sizeof(int) * desc.size(), &d_desc));
+    double *d_x = (double *)d_out + 3 * total, *d_stats = d_x + 7 * (size_t)k;
+    hipLaunchKernelGGL(align_sim3_kernel, dim3(k), dim3(AL_THREADS), 0, ctx->stream, (const double *)d_gt,
+                       (const double *)d_est, n, max_iter, ftol, xtol, d_x, (double *)d_out, d_stats, (const int *)d_desc);
+    VOHIP_HIP(ctx, hipGetLastError());
+    std::vector<double> tail(10 * (size_t)k);
+    for (int b = 0; b < k; ++b) {   // the aligned prefix's first and last point (quantitative_eval.m:25-26 reads no other)
+        const double *o = (const double *)d_out + 3 * (size_t)desc[3 * b + 2];
+        VOHIP_TRY(vohip_download(ctx, first_last + 6 * (size_t)b, o, sizeof(double) * 3));
+        VOHIP_TRY(vohip_download(ctx, first_last + 6 * (size_t)b + 3, o + 3 * ((size_t)lengths[b] - 1), sizeof(double) * 3));
+    }
+    VOHIP_TRY(vohip_download(ctx, tail.data(), d_x, sizeof(double) * tail.size()));
+    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (desc and tail are released after it)
+    if (x) std::memcpy(x, tail.data(), sizeof(double) * 7 * (size_t)k);
+    if (stats) std::memcpy(stats, tail.data() + 7 * (size_t)k, sizeof(double) * 3 * (size_t)k);
+    return VOHIP_OK;
+}
+
+}  // extern "C"

@@ -2124,6 +2124,53 @@ int vohip_group_prepare(vohip_group *g, int seq, const uint8_t *const *images, i
     return VOHIP_OK;
 }
 
+int vohip_group_prepare_like(vohip_group *g, int seq, int from_seq, int detector, double min_quality, double min_contrast)
+{
+    vohip_frame *f = g ? g->f : nullptr;
+    VOHIP_TRY(group_check(f, seq));
+    VOHIP_TRY(group_check(f, from_seq));
+    vohip_ctx *ctx = f->ctx;
+    VOHIP_REQUIRE(ctx, seq != from_seq && f->seqs[from_seq].n_frames >= 2, "the other sequence must be a prepared one");
+    VOHIP_REQUIRE(ctx, !f->g_inflight, "a frame is in flight (vohip_group_finish)");
+    VOHIP_REQUIRE(ctx, detector >= -2 && detector <= 2, "detector: -2 = the other sequence's corner lists, -1 = the group's, 0..2");
+    VOHIP_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const vohip_frame_params &p = f->prm;
+    const int n = f->seqs[from_seq].n_frames;
+    const size_t img_bytes = (size_t)f->rows * f->cols;
+    uint8_t *imgs = prep_of_seq(f, f->prep_imgs, seq);
+    VOHIP_HIP(ctx, hipMemcpyAsync(imgs, prep_of_seq(f, f->prep_imgs, from_seq), img_bytes * n, hipMemcpyDeviceToDevice, s));
+    VOHIP_HIP(ctx, hipMemcpyAsync(prep_of_seq(f, f->prep_pyr, seq), prep_of_seq(f, f->prep_pyr, from_seq),
+                                  sizeof(float) * f->prep_pyr_floats * n, hipMemcpyDeviceToDevice, s));
+    float *xy = prep_of_seq(f, f->prep_xy, seq), *metric = prep_of_seq(f, f->prep_metric, seq);
+    int *counts = prep_of_seq(f, f->prep_counts, seq);
+    if (detector == -2) {
+        VOHIP_HIP(ctx, hipMemcpyAsync(xy, prep_of_seq(f, f->prep_xy, from_seq), sizeof(float) * 2 * (size_t)f->capK * n,
+                                      hipMemcpyDeviceToDevice, s));
+        VOHIP_HIP(ctx, hipMemcpyAsync(metric, prep_of_seq(f, f->prep_metric, from_seq), sizeof(float) * (size_t)f->capK * n,
+                                      hipMemcpyDeviceToDevice, s));
+        VOHIP_HIP(ctx, hipMemcpyAsync(counts, prep_of_seq(f, f->prep_counts, from_seq), sizeof(int) * (size_t)n,
+                                      hipMemcpyDeviceToDevice, s));
+    } else {
+        if (detector < 0) {
+            detector = p.detector;
+            min_quality = p.min_quality;
+            min_contrast = p.min_contrast;
+        }
+        const int chunk = 64;
+        for (int c = 0; c < n; c += chunk) {
+            const int m = n - c < chunk ? n - c : chunk;
+            VOHIP_TRY(vohip_detect_corners_batch_enqueue(ctx, imgs + img_bytes * c, m, f->rows, f->cols, f->colmajor, min_quality,
+                                                         p.filter_size, p.border, detector, xy + 2 * (size_t)f->capK * c,
+                                                         metric + (size_t)f->capK * c, f->capK, counts + c, min_contrast));
+        }
+    }
+    VOHIP_HIP(ctx, hipStreamSynchronize(s));
+    f->seqs[seq].n_frames = n;
+    f->seqs[seq].reset = false;
+    return VOHIP_OK;
+}
+
 int vohip_group_reset(vohip_group *g, int seq, const double *X, const double *ids, const double *P_rc, int n,
                       const double T_W_C[16])
 {

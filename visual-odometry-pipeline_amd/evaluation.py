@@ -14,6 +14,7 @@ The alignment's non-linear least squares runs in libvohip.so on the GPU.  The re
 MAT v5 file with the key set the reference saves, which is what its evaluation notebook reads
 (errs, fps_ct, frame_ct, toc_ct, S).
 """
+import ctypes as C
 import datetime
 import time
 
@@ -72,19 +73,30 @@ def quantitative_eval(ground_truth, S, bootstrap_frames, save_name=None, ctx=Non
     GT = np.vstack([GT[0], np.zeros(T), GT[1]])                             # :6
     dist = np.linalg.norm(GT[:, 1:] - GT[:, :-1], axis=0)                   # :9
     checkpoints = list(DIST_CHECKPOINTS)
-    errs = np.zeros((3, 0))
+    lengths = []                     # the prefixes the reference aligns, one per checkpoint passed
     current = 0.0
     nxt = checkpoints.pop(0)                                                # :16-17
     for i in range(1, T):                                                   # :20 (1-based i)
         current += dist[i - 1]
         if current > nxt:
-            aligned = alignEstimateToGroundTruth(GT[:, :i], est[:, :i], ctx=ctx)        # :23-24
-            replacement_gt = GT[:, i - 1] - GT[:, 0]
-            replacement_est = aligned[:, -1] - aligned[:, 0]
-            errs = np.hstack([errs, np.abs(replacement_est - replacement_gt).reshape(3, 1)])   # :27
+            lengths.append(i)                                               # :23-24 align GT(:, 1:i), est(:, 1:i)
             if not checkpoints:                                             # :53-61
                 break
             nxt = checkpoints.pop(0)
+    if not lengths:
+        return np.zeros((3, 0))
+    # the alignments are independent of one another (each starts from the identity, :10-13): one launch for all
+    ctx = ctx or _lib.default_context()
+    g, e = colmajor(GT), colmajor(est)
+    k = len(lengths)
+    first_last = np.zeros((k, 6))
+    ctx.check(_lib.load().vohip_align_sim3_prefixes(ctx.handle, dptr(g), dptr(e), T, k, (C.c_int * k)(*lengths), ALIGN_MAX_ITER,
+                                                    ALIGN_FTOL, ALIGN_XTOL, None, dptr(first_last), None))
+    errs = np.zeros((3, k))
+    for b, i in enumerate(lengths):
+        replacement_gt = GT[:, i - 1] - GT[:, 0]
+        replacement_est = first_last[b, 3:] - first_last[b, :3]
+        errs[:, b] = np.abs(replacement_est - replacement_gt)               # :25-27
     return errs
 
 
@@ -235,14 +247,17 @@ def run_group(runs, ctx=None, group=None, n_slots=None, max_frames=None):
             else tuple(runs[0]["images"][0].shape)
         group = VOGroupDevice(runs[0]["K"], shape, n_slots or len(runs), max_frames or longest, hyper_paras=hp0, ctx=ctx)
     try:
+        uploaded = {}   # (image list, first loop image) -> the sequence of the group that holds those images
         for s, (r, b) in enumerate(zip(runs, boots)):
             hp = r["hyper_paras"]
             fo = dict(zip(hp.feature_extract_options[::2], hp.feature_extract_options[1::2]))
+            key = (id(r["images"]), b["b2"])
             # the loop's images: the last bootstrap image (the one the trackers are initialised on, :342-349),
             # then the frames of :351
             group.add_sequence(s, list(r["images"][b["b2"]:]), b["p_W"], b["kp"], b["T0"], rng=r["rng"],
                                feature_extract=hp.feature_extract, min_quality=fo.get("MinQuality"),
-                               min_contrast=fo.get("MinContrast"))
+                               min_contrast=fo.get("MinContrast"), same_images_as=uploaded.get(key))
+            uploaded.setdefault(key, s)
         group.run()
         loop_s = time.perf_counter() - t_ct                                 # :446
         states = [group.S(s) if group.seqs[s].error is None else None for s in range(len(runs))]

@@ -361,10 +361,12 @@ class VOGroupDevice:
         self.host_wait_us = 0.0
 
     def add_sequence(self, seq, images, p_W_landmarks, keypoints_xy, T_init_WC, rng=None, rng_map=None,
-                     feature_extract=None, min_quality=None, min_contrast=None):
+                     feature_extract=None, min_quality=None, min_contrast=None, same_images_as=None):
         """Sequence `seq` of the group: its stored images, the state its loop starts from (as VOPipelineDevice's
         constructor takes it) and its generators.  feature_extract / min_quality / min_contrast: this sequence's
-        detector when it differs from the group's (the feature variants of main_eval.m:165-174)."""
+        detector when it differs from the group's (the feature variants of main_eval.m:165-174).
+        same_images_as: a sequence of this run of the group that was added with these very images (repetitions and
+        feature variants run over one image sequence): they are copied on the GPU instead of uploaded again."""
         if self.frames:
             self.frames = 0   # (the library starts a new run with the first reset after a frame)
             self.host_enqueue_us = self.host_wait_us = 0.0
@@ -372,7 +374,18 @@ class VOGroupDevice:
         lib = _lib.load()
         if len(images) < 2 or len(images) > self.max_frames:
             raise ValueError("a sequence holds 2..max_frames images")
+        det = -1 if feature_extract is None else DETECTORS[feature_extract]
+        mq = float(min_quality) if min_quality is not None else (
+            DEFAULT_MIN_QUALITY[feature_extract] if feature_extract is not None else 0.0)
+        mc = float(min_contrast) if min_contrast is not None else 0.2     # detectFASTFeatures' default
         ptrs, keep, on_dev = [], [], None
+        other = self.seqs[same_images_as] if same_images_as is not None else None
+        if other is not None:
+            if other.n_frames != len(images):
+                raise ValueError("the other sequence holds a different number of images")
+            same = (det, mq, mc) == other.detector
+            self.ctx.check(lib.vohip_group_prepare_like(self._h, int(seq), int(same_images_as), -2 if same else det, mq, mc))
+            images = []
         for im in images:
             if hasattr(im, "data_ptr"):
                 if tuple(im.shape) != self._shape:
@@ -390,12 +403,10 @@ class VOGroupDevice:
                 raise ValueError("host and device images cannot be mixed in one sequence")
             ptrs.append(ptr)
             keep.append(k)
-        arr = (C.c_void_p * len(ptrs))(*ptrs)
-        det = -1 if feature_extract is None else DETECTORS[feature_extract]
-        mq = float(min_quality) if min_quality is not None else (
-            DEFAULT_MIN_QUALITY[feature_extract] if feature_extract is not None else 0.0)
-        mc = float(min_contrast) if min_contrast is not None else 0.2     # detectFASTFeatures' default
-        self.ctx.check(lib.vohip_group_prepare(self._h, int(seq), arr, len(ptrs), int(on_dev), det, mq, mc))
+        if other is None:
+            arr = (C.c_void_p * len(ptrs))(*ptrs)
+            self.ctx.check(lib.vohip_group_prepare(self._h, int(seq), arr, len(ptrs), int(on_dev), det, mq, mc))
+        n_images = other.n_frames if other is not None else len(ptrs)
         X = np.ascontiguousarray(np.asarray(p_W_landmarks, dtype=np.float64).reshape(-1, 3))
         P_rc = np.ascontiguousarray(np.asarray(keypoints_xy, dtype=np.float64).reshape(-1, 2)[:, ::-1])
         T = np.asarray(T_init_WC, dtype=np.float64)
@@ -403,7 +414,7 @@ class VOGroupDevice:
         rng = rng or np.random.default_rng()
         rng_map = rng_map or rng.spawn(1)[0]
         self.seqs[seq] = SimpleNamespace(
-            n_frames=len(images), rng=rng, rng_map=rng_map,
+            n_frames=n_images, detector=(det, mq, mc), rng=rng, rng_map=rng_map,
             rewind=type(rng.bit_generator).__name__ in ("PCG64", "PCG64DXSM"),
             est_trans=[T[:3, 3].copy()], est_rot=[T[:3, :3].reshape(-1, order="F").copy()],
             num_X=[X.shape[0]], num_C=[0], num_new=[0], error=None, last_pose=None, last_counts=None)
