@@ -95,6 +95,20 @@ int vohip_ransac_p3p(vohip_ctx *ctx, const double *kp_rc, const double *X, int n
                      double R_C_W[9], double t_C_W[3], uint8_t *mask,
                      double *max_num_inliers_history, double *num_iteration_history, int *n_iter);
 
+/* The DLT branch of the same function (use_p3p = false, ransacLocalization.m:9,20-24,69-74,145-151): six samples
+ * per hypothesis (samples is 6 x hcap, 0-based, six distinct indices each, as datasample(..., 6, 2, 'Replace',
+ * false) draws them), the hypothesis' pose from estimatePoseDLT, one pose scored per iteration, the adaptive bound
+ * with exponent 6, and the returned pose re-estimated by estimatePoseDLT over the inliers of the best hypothesis
+ * (mask is that hypothesis' inlier mask, as in the reference).  Arguments and status codes as vohip_ransac_p3p;
+ * VOHIP_TOO_FEW_POINTS below 6 correspondences.  The branch is dead in the reference (use_p3p = true at :9). */
+int vohip_ransac_dlt(vohip_ctx *ctx, const double *kp_rc, const double *X, int n, const double K[9],
+                     const int32_t *samples, int hcap, double R_C_W[9], double t_C_W[3], uint8_t *mask,
+                     double *max_num_inliers_history, double *num_iteration_history, int *n_iter);
+/* M_tilde = estimatePoseDLT(p, P, K), utils/exe7_Ransac/estimatePoseDLT.m:1-60: p n x 2 undistorted (u, v), P n x 3,
+ * K 3 x 3, M 3 x 4 = [R_tilde | alpha t], all column-major as MATLAB passes them; n >= 6. */
+int vohip_estimate_pose_dlt(vohip_ctx *ctx, const double *p_uv, const double *P, int n, const double K[9],
+                            double M[12]);
+
 /* Hypothesis generation + inlier scoring only (ransacLocalization.m:46-101 for h hypotheses at
  * once), everything resident on the GPU: d_kp_rc (2xN), d_X (3xN), d_samples (3xh int32) and
  * d_counts (4xh int32, out: inlier count of each of the 4 P3P solutions) are device pointers.

@@ -61,6 +61,20 @@ int vo_ransac_localization(const double *kp_rc, const double *X, int n, const do
  * maximum inlier count and point count. */
 double vo_ransac_num_iterations(int max_num_inliers, int n);
 
+/* ---- dlt_oracle.c ---------------------------------------------------------------------- */
+
+/* M_tilde = estimatePoseDLT(p, P, K), utils/exe7_Ransac/estimatePoseDLT.m:1-60: p_uv n x 2 (u, v) and P n x 3
+ * as rows, K column-major; M 3 x 4 row-major [R_tilde | alpha t].  Returns 0, or -1 when n < 6. */
+int vo_estimate_pose_dlt(const double *p_uv, const double *P, int n, const double K[9], double M[12]);
+
+/* utils/exe7_Ransac/ransacLocalization.m:1-157 with use_p3p = false (k = 6 samples per hypothesis, one pose per
+ * iteration, refit on the best hypothesis' inliers at :145-151); arguments as vo_ransac_localization, samples
+ * 6 x hcap.  M_hyp (may be NULL): the [R | t] (row-major 3 x 4) of every executed iteration. */
+int vo_ransac_localization_dlt(const double *kp_rc, const double *X, int n, const double K[9], const int32_t *samples,
+                               int hcap, double R_C_W[9], double t_C_W[3], uint8_t *best_mask, int *found,
+                               double *max_hist, double *iter_hist, int32_t *per_hyp_counts, double *M_hyp);
+double vo_ransac_num_iterations_dlt(int max_num_inliers, int n);
+
 /* ---- geometry_oracle.c ---------------------------------------------------------------- */
 
 /* utils/exe9_BA/twist2HomogMatrix.m:1-16 (expm of the se(3) matrix; twist = [v; w]). */

@@ -120,6 +120,41 @@ def ransac_num_iterations(max_inliers, n):
     return lib().vo_ransac_num_iterations(int(max_inliers), int(n))
 
 
+def estimate_pose_dlt(p_uv, P, K):
+    """estimatePoseDLT.m: p_uv (n, 2) rows (u, v), P (n, 3) -> M 3x4 [R_tilde | alpha t]."""
+    p, Pw = _f64(p_uv), _f64(P)
+    Kc = _f64(np.asarray(K).T)
+    M = np.zeros(12)
+    lib().vo_estimate_pose_dlt.restype = C.c_int
+    if lib().vo_estimate_pose_dlt(_d(p), _d(Pw), C.c_int(p.shape[0]), _d(Kc), _d(M)) != 0:
+        raise ValueError("estimatePoseDLT needs at least 6 correspondences")
+    return M.reshape(3, 4)
+
+
+def ransac_localization_dlt(kp_rc_cols, X_cols, K, samples):
+    """The use_p3p = false branch of ransacLocalization.m.  kp_rc_cols (N,2) rows = (row, col); X_cols (N,3);
+    samples (H,6) 0-based int32.  Returns the dict of ransac_localization plus M_hyp (n_iter, 3, 4)."""
+    kp = _f64(kp_rc_cols)
+    X = _f64(X_cols)
+    Kc = _f64(np.asarray(K).T)
+    s = np.ascontiguousarray(samples, dtype=np.int32)
+    n, h = kp.shape[0], s.shape[0]
+    R, t = np.zeros(9), np.zeros(3)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    found = C.c_int(0)
+    mh, ih = np.zeros(max(h, 1)), np.zeros(max(h, 1))
+    pc = np.zeros(max(h, 1), dtype=np.int32)
+    Mh = np.zeros((max(h, 1), 12))
+    lib().vo_ransac_localization_dlt.restype = C.c_int
+    n_iter = lib().vo_ransac_localization_dlt(_d(kp), _d(X), C.c_int(n), _d(Kc), s.ctypes.data_as(_ip), C.c_int(h), _d(R),
+                                              _d(t), mask.ctypes.data_as(_bp), C.byref(found), _d(mh), _d(ih),
+                                              pc.ctypes.data_as(_ip), _d(Mh))
+    m = max(n_iter, 0) if n_iter >= 0 else h
+    return dict(R_C_W=R.reshape(3, 3).T.copy(), t_C_W=t, mask=mask[:n], found=bool(found.value), n_iter=n_iter,
+                max_num_inliers_history=mh[:m], num_iteration_history=ih[:m], per_hyp_counts=pc[:m],
+                M_hyp=Mh[:m].reshape(-1, 3, 4))
+
+
 # ---- geometry ---------------------------------------------------------------------------
 
 def twist2homog(twist):

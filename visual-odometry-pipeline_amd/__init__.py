@@ -16,7 +16,8 @@ from .keypoints import cornerPoints, genKeypoints
 from .klt import PointTracker, Pyramid
 from .pipeline import (VO_bundle_adjust, VOPipeline, default_hyper_paras, init_state, update_candidate,
                        update_landmarks)
-from .ransac import draw_triples, p3p, ransacLocalization, triples_from_uniforms
+from .ransac import (draw_sextets, draw_triples, estimatePoseDLT, p3p, ransacLocalization, sets_from_uniforms,
+                     triples_from_uniforms)
 from .geometry import (Cross2Matrix, HomogMatrix2twist, Matrix2Cross, candidate_filter, candidate_triangulate,
                        linearTriangulation, linearTriangulation_refinement, twist2HomogMatrix)
 

@@ -142,6 +142,9 @@ SIGNATURES = {
     "vohip_ransac_inlier_mask_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_double_p,
                                                 c_double_p, C.c_void_p]),
     "vohip_p3p": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, c_double_p]),
+    "vohip_ransac_dlt": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, c_double_p, c_int32_p, C.c_int, c_double_p,
+                                   c_double_p, c_uint8_p, c_double_p, c_double_p, c_int_p]),
+    "vohip_estimate_pose_dlt": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_int, c_double_p, c_double_p]),
     "vohip_twist2homog": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
     "vohip_homog2twist": (C.c_int, [C.c_void_p, c_double_p, C.c_int, c_double_p]),
     "vohip_triangulate": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int,

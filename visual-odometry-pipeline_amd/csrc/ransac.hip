@@ -976,6 +976,14 @@ int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
     return VOHIP_OK;
 }
 
+// Inlier counts of `slots` x 4 candidate poses (d_M: 48 doubles per slot, K [R | t] row-major 3x4 each) over n
+// correspondences: d_counts 4 ints per slot.  NaN poses count nothing.
+int vohip_ransac_score_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const double *d_M,
+                               int slots, int32_t *d_counts)
+{
+    return launch_score_variant(ctx, d_kp_rc, d_X, n, d_M, slots, d_counts);
+}
+
 int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                               const double *d_M12, uint8_t *d_mask)
 {

@@ -180,6 +180,8 @@ int vohip_ransac_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_
                          const vohip_seqs *seqs = nullptr);
 int vohip_ransac_mask_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const int *d_n,
                               const double *d_M12, uint8_t *d_mask);
+int vohip_ransac_score_enqueue(vohip_ctx *ctx, const double *d_kp_rc, const double *d_X, int n, const double *d_M,
+                               int slots, int32_t *d_counts);
 double vohip_ransac_adaptive_iterations(int max_num_inliers, int n);
 int vohip_ransac_scratch_init(vohip_ctx *ctx);   // once per device, with that device current
 int vohip_fm_enqueue(vohip_ctx *ctx, const double *d_p1, const double *d_p2, int n, const int *d_n,

@@ -116,10 +116,13 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     vohip_ctx *c = ctx();
     auto is = [&](const char *name) { return std::strcmp(opbuf, name) == 0; };
 
-    if (is("ransac_p3p")) {
+    if (is("ransac_p3p") || is("ransac_dlt")) {
         // [R, t, mask, max_hist, iter_hist, n_iter, status] = vohip_mex('ransac_p3p', kp_rc 2xN, X 3xN, K, samples 3xH (1-based))
         // status: 0 = a model, VOHIP_NO_MODEL (3) = none reached 30 inliers, VOHIP_SAMPLES_EXHAUSTED (4) = the
         // adaptive rule wants more than the H triples supplied (call again with more, the first H unchanged)
+        // 'ransac_dlt': the use_p3p = false branch (ransacLocalization.m:20-24,69-74,145-151), samples 6xH
+        const bool dlt = is("ransac_dlt");
+        if (rows(in[3]) != (dlt ? 6 : 3)) mexErrMsgIdAndTxt("vohip:size", "samples must hold 3 (P3P) or 6 (DLT) rows");
         const int n = cols(in[0]), h = cols(in[3]);
         int32_t *s = idx0(in[3]);
         plhs[0] = mxCreateDoubleMatrix(3, 3, mxREAL);
@@ -127,9 +130,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         mxArray *mask = mxCreateLogicalMatrix(1, n);
         double *mh = scratch<double>((size_t)h), *ih = scratch<double>((size_t)h);
         int n_iter = 0;
-        const int st = vohip_ransac_p3p(c, dbl(in[0], "keypoints"), dbl(in[1], "landmarks"), n, dbl(in[2], "K"), s, h,
-                                        mxGetDoubles(plhs[0]), mxGetDoubles(plhs[1]), (uint8_t *)mxGetLogicals(mask),
-                                        mh, ih, &n_iter);
+        const int st = (dlt ? vohip_ransac_dlt : vohip_ransac_p3p)(c, dbl(in[0], "keypoints"), dbl(in[1], "landmarks"), n,
+                                                                    dbl(in[2], "K"), s, h, mxGetDoubles(plhs[0]),
+                                                                    mxGetDoubles(plhs[1]), (uint8_t *)mxGetLogicals(mask),
+                                                                    mh, ih, &n_iter);
         if (st != VOHIP_SAMPLES_EXHAUSTED) check(st, true);
         plhs[2] = mask;
         plhs[3] = mxCreateDoubleMatrix(1, n_iter, mxREAL);
@@ -141,6 +145,12 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         mxFree(s);
         mxFree(mh);
         mxFree(ih);
+    } else if (is("estimate_pose_dlt")) {
+        // M_tilde = vohip_mex('estimate_pose_dlt', p n x 2, P n x 3, K)   (estimatePoseDLT.m:1)
+        const int n = rows(in[0]);
+        if (cols(in[0]) != 2 || cols(in[1]) != 3 || rows(in[1]) != n) mexErrMsgIdAndTxt("vohip:size", "p must be n x 2 and P n x 3");
+        plhs[0] = mxCreateDoubleMatrix(3, 4, mxREAL);
+        check(vohip_estimate_pose_dlt(c, dbl(in[0], "p"), dbl(in[1], "P"), n, dbl(in[2], "K"), mxGetDoubles(plhs[0])));
     } else if (is("twist2homog")) {
         plhs[0] = mxCreateDoubleMatrix(4, 4, mxREAL);
         check(vohip_twist2homog(c, dbl(in[0], "twist"), 1, mxGetDoubles(plhs[0])));

@@ -38,10 +38,49 @@ def draw_triples(rng, n, count):
     return triples_from_uniforms(rng.random((count, 3)), n)
 
 
+def sets_from_uniforms(r, n):
+    """Maps a (count, k) array of uniforms in [0, 1) to index sets, k distinct indices in [0, n) each: draw j picks
+    the floor(u_j (n - j))-th index not picked before (k = 3 gives triples_from_uniforms)."""
+    r = np.asarray(r, dtype=np.float64)
+    out = np.zeros(r.shape, dtype=np.int64)
+    for row in range(r.shape[0]):
+        chosen = []
+        for j in range(r.shape[1]):
+            idx = min(int(r[row, j] * (n - j)), n - j - 1)
+            for c in sorted(chosen):
+                idx += idx >= c
+            chosen.append(idx)
+            out[row, j] = idx
+    return out.astype(np.int32)
+
+
+def draw_sextets(rng, n, count):
+    """`count` sets of 6 distinct indices in [0, n) -- the stand-in for datasample(landmarks, 6, 2, 'Replace', false)
+    at ransacLocalization.m:46-47 with k = 6 (:23).  Consumes exactly 6*count draws, in set order."""
+    return sets_from_uniforms(rng.random((count, 6)), n)
+
+
+def estimatePoseDLT(p, P, K, ctx=None):
+    """M_tilde = estimatePoseDLT(p, P, K) (estimatePoseDLT.m:1-60): p n x 2 undistorted (u, v), P n x 3, K 3 x 3 ->
+    3 x 4 [R_tilde | alpha t]."""
+    ctx = ctx or _lib.default_context()
+    p = np.asarray(p, dtype=np.float64).reshape(-1, 2)
+    P = np.asarray(P, dtype=np.float64).reshape(-1, 3)
+    if p.shape[0] != P.shape[0]:
+        raise ValueError("p and P differ in count")
+    M = np.zeros(12)
+    ctx.check(_lib.load().vohip_estimate_pose_dlt(ctx.handle, dptr(colmajor(p)), dptr(colmajor(P)), p.shape[0],
+                                                  dptr(colmajor(K)), dptr(M)))
+    return M.reshape(4, 3).T.copy()
+
+
 def ransacLocalization(matched_query_keypoints, corresponding_landmarks, K, samples=None, rng=None,
-                       ctx=None):
+                       ctx=None, use_p3p=True):
     """[R_C_W, t_C_W, best_inlier_mask, max_num_inliers_history, num_iteration_history] =
     ransacLocalization(matched_query_keypoints, corresponding_landmarks, K)
+
+    use_p3p: the switch at ransacLocalization.m:9 (true in the reference).  False selects the DLT branch: six
+    samples per hypothesis (`samples` is then H x 6), estimatePoseDLT per hypothesis and over the inliers at the end.
 
     matched_query_keypoints 2xN in (row, col) order, corresponding_landmarks 3xN, K 3x3.
     `samples` (H x 3, 0-based) fixes the hypothesis set; otherwise triples are drawn from `rng`
@@ -62,14 +101,19 @@ def ransacLocalization(matched_query_keypoints, corresponding_landmarks, K, samp
     t = np.zeros(3)
     mask = np.zeros(max(n, 1), dtype=np.uint8)
     n_iter = C.c_int(0)
+    k = 3 if use_p3p else 6                                                             # :19, :23
+    draw = draw_triples if use_p3p else draw_sextets
+    entry = lib.vohip_ransac_p3p if use_p3p else lib.vohip_ransac_dlt
 
     def lib_call(smp, mh, ih, n_iter):
-        return lib.vohip_ransac_p3p(ctx.handle, dptr(kp), dptr(X), n, dptr(Kc), smp.ctypes.data_as(_lib.c_int32_p),
-                                    smp.shape[0], dptr(R), dptr(t), mask.ctypes.data_as(_lib.c_uint8_p), dptr(mh),
-                                    dptr(ih), C.byref(n_iter))
+        return entry(ctx.handle, dptr(kp), dptr(X), n, dptr(Kc), smp.ctypes.data_as(_lib.c_int32_p),
+                     smp.shape[0], dptr(R), dptr(t), mask.ctypes.data_as(_lib.c_uint8_p), dptr(mh),
+                     dptr(ih), C.byref(n_iter))
 
     if samples is not None:
         samples = np.ascontiguousarray(samples, dtype=np.int32)
+        if samples.ndim != 2 or samples.shape[1] != k:
+            raise ValueError("samples must be H x %d" % k)
         max_hist = np.zeros(samples.shape[0])
         iter_hist = np.zeros(samples.shape[0])
         st = lib_call(samples, max_hist, iter_hist, n_iter)
@@ -84,7 +128,7 @@ def ransacLocalization(matched_query_keypoints, corresponding_landmarks, K, samp
         have = 104
         while True:
             rng.bit_generator.state = rng_state
-            samples = draw_triples(rng, n, have) if n >= 3 else np.zeros((1, 3), np.int32)
+            samples = draw(rng, n, have) if n >= k else np.zeros((1, k), np.int32)
             max_hist = np.zeros(samples.shape[0])
             iter_hist = np.zeros(samples.shape[0])
             st = lib_call(samples, max_hist, iter_hist, n_iter)
@@ -96,7 +140,7 @@ def ransacLocalization(matched_query_keypoints, corresponding_landmarks, K, samp
         # leave the generator where n_iter single draws would have left it
         rng.bit_generator.state = rng_state
         if n_iter.value > 0:
-            draw_triples(rng, n, n_iter.value)
+            rng.random((n_iter.value, k))
     k = n_iter.value
     if st == VOHIP_NO_MODEL:
         return (np.zeros((0, 0)), np.zeros((0, 0)), np.zeros((1, n)), max_hist[:k].copy(),
