@@ -295,6 +295,14 @@ class Context:
 
     def close(self):
         if self._h is not None:
+            # frame loops and groups created on this context hold device state through it: they go first (one
+            # that outlives its context would touch freed memory when it is closed later)
+            for obj in list(_live_frames):
+                if getattr(obj, "ctx", None) is self:
+                    try:
+                        obj.close()
+                    except Exception:
+                        pass
             load().vohip_destroy(self._h)
             self._h = None
 
