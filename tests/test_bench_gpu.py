@@ -25,7 +25,9 @@ def test_two_rank_bench_rehearsal(tmp_path):
     assert rec["value"] > 0 and rec["vs_baseline"] is None
     assert rec["roofline"]["kernel"].startswith("klt_track_kernel") and 0 < rec["roofline"]["frac"] < 1
     assert rec["roofline_ransac"]["bound"] == "valu_fp64"
-    assert rec["roofline"]["launches"] == 2 * (4 + 2) - 1 and rec["roofline"]["tracks_per_launch"] > 100
+    # (two tracker launches per frame -- the kept landmarks', and the appended landmarks' + the candidates' -- plus the first
+    # frame's own, plus any that a frame in need of more hypotheses repeats)
+    assert 2 * (4 + 2) <= rec["roofline"]["launches"] <= 2 * (4 + 2) + 4 and rec["roofline"]["tracks_per_launch"] > 100
     grid = rec["run_grid_groups_of_4"]
     assert grid["items_per_rank"] == 4 and grid["frames_per_s"] > 0
     assert rec["config"]["gather_ms_inside_the_timed_region"] >= 0
