@@ -1,6 +1,6 @@
 """Timeline of one steady-state frame from a rocprofv3 kernel trace of the frame loop.
 Usage: python tools/frame_timeline.py <kernel_trace.csv> [frame index from the end, default 3]
-Prints every kernel between two consecutive select_tracked_kernel launches: start / end in us
+Prints every kernel between the first kernels of two consecutive frames: start / end in us
 relative to the first, stream and grid size."""
 import csv
 import re
@@ -15,7 +15,10 @@ def short(name):
 def main(path, back=3):
     rows = [r for r in csv.DictReader(open(path)) if r["Kind"] == "KERNEL_DISPATCH"]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "select_tracked_kernel" in r["Kernel_Name"]]
+    # a frame starts with the selection of the tracked landmarks (a launch of its own, or the launch it shares
+    # with the solve of the first hypotheses)
+    marks = [i for i, r in enumerate(rows) if "select_tracked_kernel" in r["Kernel_Name"] or
+             "p3p_solve_select_kernel" in r["Kernel_Name"]]
     a, b = marks[-back - 1], marks[-back]
     t0 = int(rows[a]["Start_Timestamp"])
     # include the trackers that ran just before the frame's first kernel
