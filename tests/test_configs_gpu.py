@@ -6,6 +6,10 @@ restatement of the loop (same sequence, same RNG seeds):
   parking, with BA   main_BA.m:197-198: is_BA = true, window of 5 keyframes, every 2nd frame a keyframe,
                      long enough for the window to slide three times
 
+  malaga, no BA      main_demo.m:79-97 (ds = 1): 800 x 600 frames, K of :87-89, hyper-parameters min_depth 2,
+                     max_depth 50, r_discard_redundant 10, angle_threshold 0.8 (the detector is Harris, as in every
+                     native run: the reference's SURF 'MetricThreshold' 400 of :92 is a closed-source detector)
+
 The parking images and the K.txt of that set are not in the reference repository; the sequence is the
 rendered corridor seen through the parking calibration the reference does hold
 (data/epfl_parking/calibration/K.txt, at half resolution).
@@ -61,6 +65,39 @@ def test_parking_configuration_without_bundle_adjustment(vo, ctx, parking):
         assert np.linalg.norm(Td[:3, 3] - poses[i][:3, 3]) < 0.1, i
     assert dev.num_new == ref.S.num_new and sum(dev.num_new) > 50      # landmarks were added under these thresholds
     np.testing.assert_array_equal(dev.S.X[3], ref.S.X[3])
+    dev.close()
+
+
+def test_malaga_configuration(vo, ctx, oracle):
+    """ds = 1 on a rendered street of Malaga's image size and calibration (the data set itself is not in the
+    reference repository): the device-resident loop with look-ahead, the stage-by-stage loop and the CPU
+    restatement agree as in the other configurations."""
+    from oracle import pipeline_oracle as po
+    K, W, H = vo.synth.K_MALAGA, vo.synth.MALAGA_W, vo.synth.MALAGA_H
+    scene = vo.synth.CorridorScene(K=K, width=W, height=H, half_width=6.0, roof=8.0, seed=77)
+    poses = vo.synth.corridor_trajectory(9, step=0.4)
+    frames = [scene.render(T) for T in poses]
+    assert frames[0].shape == (600, 800)
+    ab, _, _ = oracle.detect_corners(frames[0], min_quality=2e-4, border=16)
+    xy = (ab + 1.0).astype(np.float64)[::3]     # (every third corner: the loops' default capacity is 8192 landmarks)
+    assert 1000 < len(xy) < 6000
+    X0 = scene.backproject(poses[0], xy)
+    hp = vo.default_hyper_paras("malaga")
+    assert (hp.min_depth, hp.max_depth, hp.r_discard_redundant, hp.angle_threshold) == (2.0, 50.0, 10.0, 0.8)   # main_demo.m:93-96
+    ref = po.OraclePipeline(K, frames[0], X0, xy, poses[0], hp, 3, 2, np.random.default_rng(5), vo.draw_triples,
+                            vo.draw_octets)
+    stg = vo.VOPipeline(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(5), ctx=ctx)
+    dev = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(5), ctx=ctx)
+    for i in range(1, 8):
+        Tr = ref.process_frame(frames[i])
+        Ts = stg.process_frame(frames[i])
+        Td = dev.process_frame(frames[i], next_image=frames[i + 1])
+        assert dev.num_X[-1] == ref.S.num_X[-1] == stg.S.num_X[-1] and dev.num_C[-1] == ref.S.num_C[-1] == stg.S.num_C[-1], i
+        assert _pose_close(Tr, Td, 1e-5) and _pose_close(Ts, Td, 1e-8), i
+        assert np.linalg.norm(Td[:3, 3] - poses[i][:3, 3]) < 0.1, i
+    assert sum(dev.num_new) > 50
+    np.testing.assert_array_equal(dev.S.X[3], ref.S.X[3])
+    stg.close()
     dev.close()
 
 

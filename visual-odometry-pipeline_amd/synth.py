@@ -15,6 +15,9 @@ K_EPFL_PARKING = np.array([[973.223300, 0.0, 656.959936],
                            [0.0, 0.0, 1.0]])
 K_PARKING = np.array([[0.5, 0.0, 0.0], [0.0, 0.5, 0.0], [0.0, 0.0, 1.0]]) @ K_EPFL_PARKING
 PARKING_W, PARKING_H = 640, 480
+# Malaga 07 (main_demo.m:79-97, ds = 1): rectified 800 x 600 images
+K_MALAGA = np.array([[621.18428, 0.0, 404.0076], [0.0, 621.18428, 309.05989], [0.0, 0.0, 1.0]])
+MALAGA_W, MALAGA_H = 800, 600
 
 
 def rotation_from_rotvec(w):
