@@ -252,7 +252,9 @@ def tracker_roofline(total_ms, longest_ms, launches, tracks, iterations, shape, 
     rows, cols = shape
     pyr = 4.0 * rows * cols * sum(0.25 ** l for l in range(5))
     s = total_ms * 1e-3
-    return {"kernel": "klt_track_kernel<21>", "launches": launches, "tracks": tracks, "tracks_per_launch": tracks / max(launches, 1),
+    # (the library launches the build for 5 wavefronts per SIMD from 8 192 tracks per launch on, the one for 3 below)
+    name = "klt_track_kernel<21, 5>" if tracks / max(launches, 1) >= 8192 else "klt_track_kernel<21, 3>"
+    return {"kernel": name, "launches": launches, "tracks": tracks, "tracks_per_launch": tracks / max(launches, 1),
             "kernel_ms_total": total_ms, "kernel_ms_mean": total_ms / max(launches, 1), "kernel_ms_longest": longest_ms,
             "tracker_us_per_frame": 1e3 * total_ms / max(frames_of_run, 1),
             "mean_iterations_per_pass": iterations / max(passes, 1), "algorithmic_flop": flop, "algorithmic_lds_bytes": lds,
@@ -424,7 +426,7 @@ def bench_klt(vo, torch, ctx, d_frames, xy, n_points, reps=20):
     # compulsory HBM bytes of a launch: both pyramids once (float, 4/3 of the image each) + 40 B per track
     rows, cols = d_frames[0].shape
     hbm = 2 * 4.0 * rows * cols * sum(0.25 ** l for l in range(5)) + 40.0 * n_points
-    return dict(kernel="klt_track_kernel<21>", tracks=n_points, kernel_ms=ms, mean_iterations_per_pass=iters / max(passes, 1),
+    return dict(kernel="klt_track_kernel<21, 5>" if n_points >= 8192 else "klt_track_kernel<21, 3>", tracks=n_points, kernel_ms=ms, mean_iterations_per_pass=iters / max(passes, 1),
                 algorithmic_flop=flop, algorithmic_lds_bytes=lds, compulsory_hbm_bytes=hbm,
                 valid_fraction=float(d_valid.float().mean().item()), achieved_tflops=flop / (ms * 1e-3) / 1e12,
                 peak_tflops=FP32_VALU_PEAK_TFLOPS, frac_valu=flop / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
@@ -789,7 +791,7 @@ def main():
 
     if rank == 0:
         traffic = traffic_from_profile("p3p_score_kernel<16, 1024>") if (n, h) == (8192, 4096) else None
-        klt_traffic = traffic_from_profile("klt_track_kernel<21>", prefer="headline")
+        klt_traffic = traffic_from_profile("klt_track_kernel<21, 3>", prefer="headline")
         out = {
             "metric": METRIC,
             "value": fps,
@@ -825,7 +827,7 @@ def main():
             # bandwidth (primary) and the fp32 vector peak; they are not HBM-bound (both pyramids, 5 MB, stay in
             # L2 / Infinity Cache).  Measured on the loop's OWN launches: durations from event pairs around every
             # tracker launch of an untimed replay of the timed frames, work from the kernel's counters.
-            "roofline": {"kernel": "klt_track_kernel<21> (the headline loop's own launches, two per frame)",
+            "roofline": {"kernel": "klt_track_kernel<21, 3> (the headline loop's own launches, two per frame)",
                          "bound": "lds",
                          "bound_note": "neither hbm nor mfma: the binding resource is LDS read bandwidth / fp32 VALU issue, and at "
                                        "these sizes the latency of the slowest wavefront (a lost track runs all 200 iterations); "

@@ -1,6 +1,8 @@
 """Throughput of a group of loops (VOGroupDevice) on the headline workload: S sequences of the KITTI-shape
 rendered corridor advanced in lockstep, aggregate frames/s against the single loop's.
-python tools/group_loop.py [--frames 60] [--seqs 1,2,4,8,16] [--distinct]"""
+python tools/group_loop.py [--frames 60] [--seqs 1,2,4,8,16] [--distinct] [--split 2]
+--split N: the S sequences as N groups of S/N on N contexts, driven by one host thread in turn (one group's
+localisation chain and tail, which leave the GPU idle, beside another group's trackers)."""
 import argparse
 import importlib
 import json
@@ -21,6 +23,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--seqs", default="1,2,4,8,16")
     ap.add_argument("--distinct", action="store_true", help="every sequence its own rendered corridor")
+    ap.add_argument("--split", type=int, default=1)
     args = ap.parse_args()
     import torch
     vo = importlib.import_module("visual_odometry_pipeline_amd")
@@ -39,28 +42,40 @@ def main():
     hp = vo.default_hyper_paras("kitti")
     hp.r_discard_redundant = bench.KITTI_EXCLUSION_RADIUS
     out = {}
+    ctxs = [ctx] + [vo.Context(0) for _ in range(args.split - 1)]
     for S in [int(x) for x in args.seqs.split(",")]:
-        g = vo.VOGroupDevice(vo.synth.K_KITTI, (vo.synth.KITTI_H, vo.synth.KITTI_W), S, n, hyper_paras=hp, ctx=ctx)
+        N = args.split if S % args.split == 0 and S >= args.split else 1
+        per = S // N
+        gs = [vo.VOGroupDevice(vo.synth.K_KITTI, (vo.synth.KITTI_H, vo.synth.KITTI_W), per, n, hyper_paras=hp, ctx=ctxs[k])
+              for k in range(N)]
         for rep in range(2):   # (the first run loads code objects and maps buffers)
             for s in range(S):
                 d, X0, xy0, T0 = world(s if args.distinct else 0)
-                g.add_sequence(s, d, X0, xy0, T0, rng=np.random.default_rng(1000 + s))
+                gs[s // per].add_sequence(s % per, d, X0, xy0, T0, rng=np.random.default_rng(1000 + s))
             for _ in range(args.warmup):
-                g.step()
+                for g in gs:
+                    g.step()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            e0, w0 = g.host_enqueue_us, g.host_wait_us
+            e0, w0 = sum(g.host_enqueue_us for g in gs), sum(g.host_wait_us for g in gs)
             pairs = 0
-            for _ in range(args.frames):
-                pairs += len(g.step())
+            for g in gs:
+                g.begin_step()
+            for k in range(args.frames):
+                for g in gs:
+                    pairs += len(g.finish_step())
+                    if k + 1 < args.frames:
+                        g.begin_step()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        out[S] = dict(frames_per_s=pairs / dt, ms_per_step=1e3 * dt / args.frames,
-                      host_enqueue_us_per_step=(g.host_enqueue_us - e0) / args.frames,
-                      host_wait_us_per_step=(g.host_wait_us - w0) / args.frames,
-                      landmarks=int(np.mean([q.num_X[-1] for q in g.seqs])), candidates=int(np.mean([q.num_C[-1] for q in g.seqs])))
+        out[S] = dict(frames_per_s=pairs / dt, ms_per_step=1e3 * dt / args.frames, groups=N,
+                      host_enqueue_us_per_step=(sum(g.host_enqueue_us for g in gs) - e0) / args.frames,
+                      host_wait_us_per_step=(sum(g.host_wait_us for g in gs) - w0) / args.frames,
+                      landmarks=int(np.mean([q.num_X[-1] for g in gs for q in g.seqs])),
+                      candidates=int(np.mean([q.num_C[-1] for g in gs for q in g.seqs])))
         print(S, json.dumps(out[S]), flush=True)
-        g.close()
+        for g in gs:
+            g.close()
     print(json.dumps(out))
 
 

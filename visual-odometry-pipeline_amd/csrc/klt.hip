@@ -172,9 +172,19 @@ __device__ __forceinline__ int bounded_int(double t)
     return min(max(j, -1000000), 1000000);
 }
 
+// Wavefronts per SIMD the 21 x 21 kernel is compiled for (register budget), in two builds.  A launch of a few
+// thousand tracks lasts as long as its slowest track: the build with the most registers is the fastest (3 per
+// SIMD).  A launch that fills the GPU several times over (a group of loops: 16 x 4 000 tracks) is bound by
+// the sum of its wavefronts' stalls -- two round trips to memory and some 900 mostly dependent instructions per
+// level and direction -- and gains from more of them in flight: 3 / 4 / 5 / 6 per SIMD give 13 640 / 14 680 /
+// 15 000 / 14 340 frames/s for a group of 16 (6: 80 registers, 52 bytes of spills per lane), and cost a single loop 1 - 5 %.
 #ifndef KLT_WAVES_21
-#define KLT_WAVES_21 3   // wavefronts per SIMD the 21 x 21 kernel is compiled for (register budget)
+#define KLT_WAVES_21 3
 #endif
+#ifndef KLT_WAVES_21_FULL
+#define KLT_WAVES_21_FULL 5
+#endif
+constexpr long long KLT_FULL_FROM = 8192;   // tracks per launch from which the second build is used
 
 template <int W>
 struct klt_cfg {
@@ -211,12 +221,16 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int A
         const int b0u = __builtin_amdgcn_readfirstlane(b0);   // (the same in every lane: a scalar branch)
         if (b0u >= 0 && b0u + 2 * NLD - 1 <= B - 1) {
             // every row of the patch lies inside the image (nearly always): the rows are a constant stride apart
-            unsigned off = (unsigned)(__mul24(b0u + half, A) + a);
-            const unsigned stride = 2u * (unsigned)A;
+            // (row pair k starts at a wave-uniform address, which the scalar unit advances; the lane's own part
+            // of the address, in bytes, is the same for every row pair: one vector instruction per patch instead
+            // of two per load)
+            const char *rowp = reinterpret_cast<const char *>(img + __mul24(b0u, A));
+            const unsigned lane_bytes = 4u * (unsigned)(__mul24(half, A) + a);
+            const unsigned stride = 8u * (unsigned)A;
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
-                tmp[k] = img[off];
-                off += stride;
+                tmp[k] = *reinterpret_cast<const float *>(rowp + lane_bytes);
+                rowp += stride;
             }
         } else {
 #pragma unroll
@@ -442,8 +456,8 @@ struct klt_sets {
     vohip_klt_set s[3];
 };
 
-template <int W>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(W <= 21 ? KLT_WAVES_21 : 2, W <= 21 ? KLT_WAVES_21 : 2)))
+template <int W, int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
 void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_iter, double max_bidir, double min_lmin,
                       unsigned long long *__restrict__ stats, vohip_seqs SQ)
 {
@@ -734,11 +748,14 @@ int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vo
     // (measurement only: an event pair around the launch, on the stream it runs on)
     const bool timed = ctx->opt_klt_time && ctx->klt_ev && ctx->klt_ev_used < vohip_ctx::KLT_TIME_PAIRS;
     if (timed) VOHIP_HIP(ctx, hipEventRecord(ctx->klt_ev[2 * ctx->klt_ev_used], ctx->stream));
-    if (block_size == 21)
-        hipLaunchKernelGGL(klt_track_kernel<21>, dim3(total, ny), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
-                           max_bidir_error, lmin_threshold(21), d_stats, SQ);
+    if (block_size == 21 && (long long)total * ny >= KLT_FULL_FROM)
+        hipLaunchKernelGGL((klt_track_kernel<21, KLT_WAVES_21_FULL>), dim3(total, ny), dim3(64), 0, ctx->stream, P, Q, S, swap_xy,
+                           max_iter, max_bidir_error, lmin_threshold(21), d_stats, SQ);
+    else if (block_size == 21)
+        hipLaunchKernelGGL((klt_track_kernel<21, KLT_WAVES_21>), dim3(total, ny), dim3(64), 0, ctx->stream, P, Q, S, swap_xy,
+                           max_iter, max_bidir_error, lmin_threshold(21), d_stats, SQ);
     else if (block_size == 31)
-        hipLaunchKernelGGL(klt_track_kernel<31>, dim3(total, ny), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
+        hipLaunchKernelGGL((klt_track_kernel<31, 2>), dim3(total, ny), dim3(64), 0, ctx->stream, P, Q, S, swap_xy, max_iter,
                            max_bidir_error, lmin_threshold(31), d_stats, SQ);
     else
         return vohip_fail(ctx, VOHIP_ERR_INVALID_ARGUMENT, "BlockSize %d not built (21 and 31 are)", block_size);

@@ -428,6 +428,12 @@ class VOGroupDevice:
         """One frame of every active sequence.  Returns {sequence: T_W_C}; a sequence whose frame fails (where
         the reference's script stops with an error, main_demo.m:389-391) records the exception in
         seqs[i].error and takes no further part."""
+        self.begin_step()
+        return self.finish_step()
+
+    def begin_step(self):
+        """The first half of step(): draws the frame's uniforms and enqueues it.  A host that drives several
+        groups (each on a context of its own) begins one group's frame while another's is on the GPU."""
         lib = _lib.load()
         act = self.active()
         if not act:
@@ -445,6 +451,15 @@ class VOGroupDevice:
             states[i] = None if q.rewind else q.rng.bit_generator.state
             u3[i] = q.rng.random((have, 3))                                                 # :387-388
         self.ctx.check(lib.vohip_group_begin(self._h, dptr(u3), have, dptr(u8) if have_map else None))
+        self._begun = (act, have, have_map, states)
+
+    def finish_step(self):
+        """The second half of step(): waits for the frame begin_step() enqueued and books its results."""
+        lib = _lib.load()
+        if getattr(self, "_begun", None) is None:
+            raise RuntimeError("finish_step() without begin_step()")
+        (act, have, have_map, states), self._begun = self._begun, None
+        S = self.n_sequences
         poses = (_lib.FramePose * S)()
         counts = (_lib.FrameCounts * S)()
         status = (C.c_int * S)()
