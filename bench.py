@@ -187,10 +187,13 @@ def kitti_hyper_paras(vo):
     return hp
 
 
-def bench_group(vo, torch, ctx, scene, frames, poses, steps, warmup, n_seq, seed=1000, measure_tracker=False):
+def bench_group(vo, torch, ctx, scene, frames, poses, steps, warmup, n_seq, seed=1000, measure_tracker=False, groups=1):
     """A group of n_seq loops in lockstep (VOGroupDevice: the independent runs of main_eval.m:22-23 sharing every
     launch of a frame) on the headline workload.  Sequence s starts s frames into the rendered corridor (its own
     images, start set and random draws).  One step = one frame of every sequence; returns the aggregate frames/s.
+    groups > 1: the sequences as that many groups, each on a context of its own, driven in turn by this one host
+    thread (a group's frame is begun while the other groups' frames are on the GPU, so one group's localisation
+    chain and tail, which leave the GPU idle, run beside another's trackers).
     measure_tracker: the same run once more with the tracker launches bracketed by timing events and once
     more with the tracker's work counters on (neither while timing) -> the roofline entry of those launches."""
     import ctypes as C
@@ -199,32 +202,47 @@ def bench_group(vo, torch, ctx, scene, frames, poses, steps, warmup, n_seq, seed
     n = warmup + steps + 1
     if len(frames) < n + n_seq - 1:
         raise ValueError("the rendered sequence is too short for %d staggered sequences" % n_seq)
+    if n_seq % groups or (measure_tracker and groups != 1):
+        raise ValueError("bad split of the sequences")
     d_frames = [torch.from_numpy(f).to(dev) for f in frames[:n + n_seq - 1]]
     starts = [init_points(vo, ctx, scene, frames[s], poses[s]) for s in range(n_seq)]
-    g = vo.VOGroupDevice(vo.synth.K_KITTI, tuple(frames[0].shape), n_seq, n, hyper_paras=kitti_hyper_paras(vo), ctx=ctx)
+    per = n_seq // groups
+    ctxs = [ctx] + [vo.Context(torch.cuda.current_device()) for _ in range(groups - 1)]
+    gs = [vo.VOGroupDevice(vo.synth.K_KITTI, tuple(frames[0].shape), per, n, hyper_paras=kitti_hyper_paras(vo), ctx=c)
+          for c in ctxs]
+    g = gs[0]
 
     def run(timed):
         for s in range(n_seq):
-            g.add_sequence(s, d_frames[s:s + n], starts[s][0], starts[s][1], poses[s], rng=np.random.default_rng(seed + s))
+            gs[s // per].add_sequence(s % per, d_frames[s:s + n], starts[s][0], starts[s][1], poses[s],
+                                      rng=np.random.default_rng(seed + s))
         for _ in range(warmup):
-            g.step()
+            for q in gs:
+                q.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        e0, w0 = g.host_enqueue_us, g.host_wait_us
+        e0, w0 = sum(q.host_enqueue_us for q in gs), sum(q.host_wait_us for q in gs)
         pairs = 0
-        for _ in range(steps):
-            pairs += len(g.step())
+        for q in gs:
+            q.begin_step()
+        for k in range(steps):
+            for q in gs:
+                pairs += len(q.finish_step())
+                if k + 1 < steps:
+                    q.begin_step()
         torch.cuda.synchronize()
-        return pairs, time.perf_counter() - t0, g.host_enqueue_us - e0, g.host_wait_us - w0
+        return (pairs, time.perf_counter() - t0, sum(q.host_enqueue_us for q in gs) - e0,
+                sum(q.host_wait_us for q in gs) - w0)
 
     run(False)   # (code objects, staging buffers, the group's first use of its memory)
     pairs, dt, enq, wait = run(True)
-    out = {"sequences": n_seq, "frames_per_s": pairs / dt, "ms_per_step": 1e3 * dt / steps,
+    seqs = [q for grp in gs for q in grp.seqs]
+    out = {"sequences": n_seq, "groups": groups, "frames_per_s": pairs / dt, "ms_per_step": 1e3 * dt / steps,
            "host_enqueue_us_per_step": enq / steps, "host_wait_us_per_step": wait / steps,
-           "tracked_landmarks_per_sequence": int(np.mean([q.num_X[-1] for q in g.seqs])),
-           "candidates_per_sequence": int(np.mean([q.num_C[-1] for q in g.seqs])),
+           "tracked_landmarks_per_sequence": int(np.mean([q.num_X[-1] for q in seqs])),
+           "candidates_per_sequence": int(np.mean([q.num_C[-1] for q in seqs])),
            "final_position_error_m": float(max(np.linalg.norm(q.est_trans[-1] - poses[s + warmup + steps][:3, 3])
-                                               for s, q in enumerate(g.seqs)))}
+                                               for s, q in enumerate(seqs)))}
     if measure_tracker:
         tot, longest, launches = C.c_double(0), C.c_double(0), C.c_int(0)
         ctx.set_option("klt_time", 1)
@@ -239,7 +257,10 @@ def bench_group(vo, torch, ctx, scene, frames, poses, steps, warmup, n_seq, seed
         ctx.set_option("klt_stats", 0)
         out["tracker"] = tracker_roofline(tot.value, longest.value, launches.value, tr.value, it.value,
                                           frames[0].shape, frames_of_run=(warmup + steps) * n_seq)
-    g.close()
+    for q in gs:
+        q.close()
+    for c in ctxs[1:]:
+        c.close()
     return out
 
 
@@ -297,7 +318,8 @@ def bench_main_eval(vo, ctx, frames, poses, concurrent=1, group=0):
     seq = dict(name="kitti", images=frames, K=vo.synth.K_KITTI,
                ground_truth=np.array([[T[0, 3], T[2, 3]] for T in poses[:len(frames)]]))
     short = dict(seq, images=frames[:12])
-    vo.main_eval([short], feats=("Harris", "FAST"), repetition=1, seed=10, ctx=ctx, group=group)   # code objects, staging buffers
+    vo.main_eval([short], feats=("Harris", "FAST"), repetition=2 if group and concurrent > 1 else 1, seed=10, ctx=ctx,
+                 concurrent=concurrent, group=min(group, 2) if concurrent > 1 else group)   # code objects, staging buffers
     t0 = time.perf_counter()
     records = vo.main_eval([seq], feats=("Harris", "MinEigen", "FAST"), repetition=4, seed=10, ctx=ctx, concurrent=concurrent,
                            group=group)
@@ -669,7 +691,7 @@ def main():
         # with the CPU baseline leg the sequence is longer, so that its sample is about 10 s of CPU work; the group
         # legs stagger their sequences by a frame each
         quick = args.only_headline or args.only_group
-        n_seq = n_frames + (max(args.only_group, 1) if quick else 16)
+        n_seq = n_frames + (max(args.only_group, 1) if quick else 32)
         if world > 1:
             n_seq = n_frames + grid_group
         elif not args.no_cpu_baseline and not quick:
@@ -759,6 +781,10 @@ def main():
             for S in (4, 8, 16):
                 extra["frames_per_s_group_of_%d" % S] = bench_group(vo, torch, ctx, scene, frames_all, poses_all, args.steps,
                                                                     args.warmup, S, measure_tracker=S == 16)
+            # ... two such groups on two contexts, begun in turn by the one host thread ...
+            for S in (16, 32):
+                extra["frames_per_s_2_groups_of_%d_in_turn" % (S // 2)] = bench_group(
+                    vo, torch, ctx, scene, frames_all, poses_all, args.steps, args.warmup, S, groups=2)
             # ... and as four loops on four host threads, a context and stream set each (what the group replaces)
             steps_c = min(args.steps, 100)
             extra["frames_per_s_4_sequences_at_once"] = bench_frames_concurrent(vo, torch, scene, frames_all, poses_all,
@@ -770,7 +796,8 @@ def main():
                             "sequence of %d frames, images in host memory; bootstrap + loop + evaluation per run" % len(frames),
                 "one_run_at_a_time": bench_main_eval(vo, ctx, frames, poses),
                 "four_runs_in_flight": bench_main_eval(vo, ctx, frames, poses, concurrent=4),
-                "groups_of_8_loops_in_lockstep": bench_main_eval(vo, ctx, frames, poses, group=8)}
+                "groups_of_8_loops_in_lockstep": bench_main_eval(vo, ctx, frames, poses, group=8),
+                "two_groups_of_6_in_flight": bench_main_eval(vo, ctx, frames, poses, concurrent=2, group=6)}
 
         klt_loop = klt_stress = image_kernels = ba_runs = None
         n, h = args.points, args.hypotheses

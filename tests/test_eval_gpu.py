@@ -132,6 +132,13 @@ def test_main_eval_grid_is_independent_of_world_size(vo, ctx, tmp_path):
             np.testing.assert_array_equal(alone[k][key], grouped[k][key], err_msg="grouped %d %s" % (k, key))
         assert grouped[k]["fps_ct"] > 0 and grouped[k]["toc_ct"] > 0 and grouped[k]["feat"] == feats3[k % 3]
     assert len(glob.glob(str(tmp_path / "w5" / "*_res.mat"))) == 6
+    # ... and of whether the groups run one after the other or two at a time (a thread and a context per group)
+    two = vo.main_eval(sequences, feats=feats3, repetition=1, save_dir=str(tmp_path / "w6"), seed=9, ctx=ctx, group=2,
+                       concurrent=2)
+    for k in range(6):
+        for key in ("est_trans", "est_rot", "num_X", "num_C", "num_new", "errs", "frame_ct", "frame_init"):
+            np.testing.assert_array_equal(alone[k][key], two[k][key], err_msg="two groups in flight %d %s" % (k, key))
+    assert len(glob.glob(str(tmp_path / "w6" / "*_res.mat"))) == 6
     # the two feature variants are different runs
     assert not np.array_equal(whole[0]["num_C"], whole[1]["num_C"])
     for d in ("w1", "w2", "w3"):

@@ -106,6 +106,43 @@ def test_prepared_sequence_changes_nothing(vo, ctx, oracle, sequence, feat, on_d
         np.testing.assert_array_equal(getattr(a[4], key), getattr(b[4], key), err_msg=key)
 
 
+@pytest.mark.parametrize("on_device,ahead", [(False, True), (True, True), (True, False)])
+def test_prepare_in_chunks_and_release_mid_run(vo, ctx, oracle, sequence, on_device, ahead):
+    """A long stored sequence is prepared a chunk at a time, and the prepared data may be released while the loop
+    runs: the pyramid slots of the loop still show pyramids inside the block that a new prepare (or prepare([]))
+    frees, so the library moves those pyramids into the slots' own buffers first.  Bit for bit the unprepared run."""
+    import torch
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    imgs = [torch.from_numpy(f).cuda() for f in frames] if on_device else frames
+    n = len(imgs)
+
+    def run(plan):
+        """plan: {frame index: list of images to prepare right before that frame is begun}"""
+        dev = vo.VOPipelineDevice(K, imgs[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(5), ctx=ctx)
+        Ts = []
+        for i in range(1, n):
+            if i in plan:
+                dev.prepare(plan[i])
+            Ts.append(dev.process_frame(imgs[i], next_image=imgs[i + 1] if ahead and i + 1 < n else None))
+        out = (np.array(Ts), list(dev.num_X), list(dev.num_C), list(dev.num_new), dev.S, dev.rng.bit_generator.state)
+        dev.close()
+        return out
+
+    plain = run({})
+    # two consecutive chunks (the second prepared while the look-ahead of frame 3 already shows image 4 of the
+    # first), then the rest unprepared after a release in the middle of the run
+    chunks = run({1: imgs[1:5], 4: imgs[4:7], 6: []})
+    # released right after the first prepared frames, prepared again later
+    again = run({1: imgs[1:n], 3: [], 5: imgs[5:n]})
+    for other in (chunks, again):
+        np.testing.assert_array_equal(plain[0], other[0])
+        assert plain[1:4] == other[1:4] and plain[5] == other[5]
+        for key in ("P", "X", "C", "F", "T"):
+            np.testing.assert_array_equal(getattr(plain[4], key), getattr(other[4], key), err_msg=key)
+
+
 def test_device_loop_matches_stage_by_stage_loop(vo, ctx, oracle, sequence):
     scene, poses, frames = sequence
     X0, xy = _start(vo, oracle, sequence)

@@ -380,40 +380,53 @@ def main_eval(sequences, feats=("Harris",), repetition=5, save_dir=None, seed=0,
             seq = sequences[item[0]]
             key = (tuple(seq["images"][0].shape), np.asarray(seq["K"], dtype=np.float64).tobytes())
             buckets.setdefault(key, []).append((item_id, item))
+        chunks = []
         for bucket in buckets.values():
             # (longest first, so that the runs of a group end together)
             bucket.sort(key=lambda p: (-len(sequences[p[1][0]]["images"]), p[0]))
-            for c in range(0, len(bucket), int(group)):
-                chunk = bucket[c:c + int(group)]
-                runs = []
-                for item_id, (si, feat, rep) in chunk:
-                    seq = sequences[si]
-                    hp = copy.copy(seq.get("hyper_paras") or default_hyper_paras(seq["name"]))
-                    hp.feature_extract = feat
-                    hp.feature_extract_options = list(EVAL_FEATURE_OPTIONS[feat])
-                    runs.append(dict(images=seq["images"], K=seq["K"], hyper_paras=hp, ground_truth=seq.get("ground_truth"),
-                                     bootstrap_frames=seq.get("bootstrap_frames", (0, 2)), dataset=seq["name"],
-                                     save_dir=save_dir, rng=np.random.default_rng([seed, item_id]),
-                                     now=now + datetime.timedelta(seconds=item_id)))
-                t0 = time.perf_counter()
-                try:
-                    results = run_group(runs, ctx=ctx)
-                except (RuntimeError, _lib.VohipError):   # (a bootstrap that fails: where the reference stops)
+            chunks += [bucket[c:c + int(group)] for c in range(0, len(bucket), int(group))]
+
+        def do_chunk(chunk):
+            runs = []
+            for item_id, (si, feat, rep) in chunk:
+                seq = sequences[si]
+                hp = copy.copy(seq.get("hyper_paras") or default_hyper_paras(seq["name"]))
+                hp.feature_extract = feat
+                hp.feature_extract_options = list(EVAL_FEATURE_OPTIONS[feat])
+                runs.append(dict(images=seq["images"], K=seq["K"], hyper_paras=hp, ground_truth=seq.get("ground_truth"),
+                                 bootstrap_frames=seq.get("bootstrap_frames", (0, 2)), dataset=seq["name"],
+                                 save_dir=save_dir, rng=np.random.default_rng([seed, item_id]),
+                                 now=now + datetime.timedelta(seconds=item_id)))
+            t0 = time.perf_counter()
+            try:
+                results = run_group(runs, ctx=context())
+            except (RuntimeError, _lib.VohipError):   # (a bootstrap that fails: where the reference stops)
+                if on_error != "record":
+                    raise
+                for item_id, item in chunk:   # one by one, so that the others of the group still get their record
+                    out[item_id] = runner(item_id, item)
+                return
+            dt = time.perf_counter() - t0
+            for (item_id, _), res in zip(chunk, results):
+                if res["error"] is not None:
                     if on_error != "record":
-                        raise
-                    for item_id, item in chunk:   # one by one, so that the others of the group still get their record
-                        out[item_id] = runner(item_id, item)
+                        raise res["error"]
+                    out[item_id] = batch.failed_record(item_id, dt / len(chunk))
                     continue
-                dt = time.perf_counter() - t0
-                for (item_id, _), res in zip(chunk, results):
-                    if res["error"] is not None:
-                        if on_error != "record":
-                            raise res["error"]
-                        out[item_id] = batch.failed_record(item_id, dt / len(chunk))
-                        continue
-                    S = res["S"]
-                    out[item_id] = batch.pack_record(item_id, res["total_time"], S.est_trans, S.est_rot, S.num_X, S.num_C,
-                                                     S.num_new, errs=res["errs"], timing=res)
+                S = res["S"]
+                out[item_id] = batch.pack_record(item_id, res["total_time"], S.est_trans, S.est_rot, S.num_X, S.num_C,
+                                                 S.num_new, errs=res["errs"], timing=res)
+
+        if concurrent > 1 and len(chunks) > 1:
+            # groups in flight together, a host thread and a context each: one group's bootstraps, evaluation and
+            # the idle stretches of its frames (localisation chain, tail) beside another group's trackers
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=int(concurrent)) as pool:
+                for f in [pool.submit(do_chunk, c) for c in chunks]:
+                    f.result()
+        else:
+            for c in chunks:
+                do_chunk(c)
         return [out[item_id] for item_id, _ in mine]
 
     costs = [len(sequences[si]["images"]) for si, _, _ in items] if balance else None
