@@ -9,7 +9,7 @@
 //   triangulated with the DLT of linearTriangulation.m and the candidate with the fewest points
 //   behind either camera wins (first minimum).  The result is returned the way the toolbox
 //   returns it: orientation = R_C2_C1, location = -R_C2_C1' t with |t| = 1.
-// One workgroup: lane 0 decomposes, all 256 threads triangulate, ballots count.
+// A workgroup per 64 point pairs: lane 0 decomposes, a wavefront per candidate triangulates, ballots and integer atomics count.
 #include "vohip_internal.h"
 
 #include "geometry_device.h"
@@ -92,20 +92,25 @@ __device__ void decompose_essential(const double *E_cm, pose_candidates &out)
 
 // result[0..8] orientation (column-major), [9..11] location, [12] valid fraction, [13] status
 // (1 = ok, 0 = E has no two non-zero singular values).
+// A workgroup serves 64 point pairs: wavefront k triangulates them under candidate k (one triangulation per
+// thread; a single workgroup walking all pairs four times took 247 us at n = 2 000).  Every workgroup decomposes E
+// itself (one lane, a few microseconds; cheaper than a launch of its own).  cnt[0..3]: points behind a camera per
+// candidate, integer atomics, so the sums do not depend on the order; cnt[4]: tickets -- the workgroup that draws
+// the last one picks the candidate and writes the result.  cnt arrives zeroed.
 __global__ __launch_bounds__(256) void relative_pose_kernel(const double *__restrict__ E_cm,
                                                             const double *__restrict__ K_cm,
                                                             const double *__restrict__ p1,
                                                             const double *__restrict__ p2, int n,
-                                                            double *__restrict__ result)
+                                                            double *__restrict__ result, int *__restrict__ cnt)
 {
     __shared__ pose_candidates cand;
     __shared__ double sM1[12], sM2[4][12], sRt[4][12];
-    __shared__ int sNeg[4][4];
+    __shared__ int sLast;
     const int tid = threadIdx.x;
     if (tid == 0) decompose_essential(E_cm, cand);
     __syncthreads();
     if (!cand.ok) {
-        if (tid < 14) result[tid] = 0.0;
+        if (blockIdx.x == 0 && tid < 14) result[tid] = 0.0;
         return;
     }
     if (tid < 4) {
@@ -127,29 +132,30 @@ __global__ __launch_bounds__(256) void relative_pose_kernel(const double *__rest
                 for (int r = 0; r < 3; ++r) sM1[3 * c + r] = c < 3 ? K_cm[3 * c + r] : 0.0;
     }
     __syncthreads();
-    int neg[4] = {0, 0, 0, 0};
-    for (int base = 0; base < n; base += 256) {
-        const int i = base + tid;
+    {
+        const int k = tid >> 6, i = blockIdx.x * 64 + (tid & 63);
         const bool live = i < n;
         const int ii = live ? i : 0;
         const double a[3] = {p1[2 * ii], p1[2 * ii + 1], 1.0};
         const double b[3] = {p2[2 * ii], p2[2 * ii + 1], 1.0};
-        for (int k = 0; k < 4; ++k) {
-            double P[4];
-            vohip_dev::triangulate_point(a, b, sM1, sM2[k], P);
-            const double *Rt = sRt[k];
-            const double z2 = Rt[2] * P[0] + Rt[5] * P[1] + Rt[8] * P[2] + Rt[11];
-            const bool behind = live && (P[2] < 0.0 || z2 < 0.0);
-            neg[k] += __popcll(__ballot(behind));
-        }
+        double P[4];
+        vohip_dev::triangulate_point(a, b, sM1, sM2[k], P);
+        const double *Rt = sRt[k];
+        const double z2 = Rt[2] * P[0] + Rt[5] * P[1] + Rt[8] * P[2] + Rt[11];
+        const bool behind = live && (P[2] < 0.0 || z2 < 0.0);
+        const int neg = __popcll(__ballot(behind));
+        if ((tid & 63) == 0 && neg) atomicAdd(&cnt[k], neg);
     }
-    if ((tid & 63) == 0)
-        for (int k = 0; k < 4; ++k) sNeg[tid >> 6][k] = neg[k];
+    __threadfence();
     __syncthreads();
+    if (tid == 0) sLast = atomicAdd(&cnt[4], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();
     if (tid == 0) {
         int best = 0, best_neg = 0x7fffffff;
         for (int k = 0; k < 4; ++k) {
-            const int c = sNeg[0][k] + sNeg[1][k] + sNeg[2][k] + sNeg[3][k];
+            const int c = __hip_atomic_load(&cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c < best_neg) {
                 best_neg = c;
                 best = k;
@@ -174,13 +180,17 @@ extern "C" int vohip_relative_pose(vohip_ctx *ctx, const double *E, const double
     VOHIP_REQUIRE(ctx, E && K && p1 && p2 && orientation && location, "NULL argument");
     VOHIP_REQUIRE(ctx, n >= 1, "need at least one point pair");
     void *d_E, *d_K, *d_p1, *d_p2, *d_res;
-    VOHIP_TRY(vohip_upload(ctx, B_STAGE0, E, sizeof(double) * 9, &d_E));
+    double head[13];   // E, then the kernel's five integer counters, zeroed (one copy)
+    for (int q = 0; q < 9; ++q) head[q] = E[q];
+    for (int q = 9; q < 13; ++q) head[q] = 0.0;
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE0, head, sizeof(head), &d_E));
     VOHIP_TRY(vohip_upload(ctx, B_STAGE1, K, sizeof(double) * 9, &d_K));
     VOHIP_TRY(vohip_upload(ctx, B_STAGE2, p1, sizeof(double) * 2 * (size_t)n, &d_p1));
     VOHIP_TRY(vohip_upload(ctx, B_STAGE3, p2, sizeof(double) * 2 * (size_t)n, &d_p2));
     VOHIP_TRY(vohip_upload(ctx, B_STAGE4, nullptr, sizeof(double) * 14, &d_res));
-    hipLaunchKernelGGL(relative_pose_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double *)d_E,
-                       (const double *)d_K, (const double *)d_p1, (const double *)d_p2, n, (double *)d_res);
+    hipLaunchKernelGGL(relative_pose_kernel, dim3((n + 63) / 64), dim3(256), 0, ctx->stream, (const double *)d_E,
+                       (const double *)d_K, (const double *)d_p1, (const double *)d_p2, n, (double *)d_res,
+                       reinterpret_cast<int *>((double *)d_E + 9));
     VOHIP_HIP(ctx, hipGetLastError());
     double res[14];
     VOHIP_TRY(vohip_download(ctx, res, d_res, sizeof(res)));
