@@ -430,98 +430,101 @@ __device__ double fm_trial_budget_dev(int inliers, int n, int num_trials, double
 }
 
 // The sequential part of the fundamental-matrix RANSAC: first trial with the largest count inside
-// the shrinking trial budget.  The budget is a function of the running maximum only, so the
-// workgroup replays FM_DECIDE trials at a time: prefix maximum (within each wavefront, then across
-// them), budget per thread, first trial at which the loop ends.
-constexpr int FM_DECIDE = 512;
-
-__global__ __launch_bounds__(FM_DECIDE) void fm_decide_kernel(const int32_t *__restrict__ counts, int num_trials,
-                                                              double confidence, const double *__restrict__ F_all,
-                                                              int *__restrict__ cnt, double *__restrict__ dv,
-                                                              vohip_seqs SQ)
+// the shrinking trial budget.  The budget is a function of the running maximum only, so a workgroup of NT
+// threads replays NT trials at a time: prefix maximum (within each wavefront, then across them), budget per
+// thread, first trial at which the loop ends.  Every thread returns the outcome.  `sm`: 3 * NT / 64 + 1 ints.
+template <int NT>
+__device__ void fm_decide_block(const int32_t *__restrict__ counts, int num_trials, double confidence, int n, int *sm,
+                                int &best_t, int &run_max, int &trials)
 {
-    constexpr int NW = FM_DECIDE / 64;
-    const int seq__ = vohip_dev::seq_index(SQ);
-    VOHIP_SEQ_STATE(counts);
-    VOHIP_SEQ_STATE(F_all);
-    VOHIP_SEQ_STATE(cnt);
-    VOHIP_SEQ_STATE(dv);
-
-    __shared__ int w_max[NW], w_stop[NW], w_hit[NW], s_mlast;
+    constexpr int NW = NT / 64;
+    int *w_max = sm, *w_stop = sm + NW, *w_hit = sm + 2 * NW, *s_mlast = sm + 3 * NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = cnt[N_CV];
-    int run_max = 0, best_t = -1, trials = 0;
-    if (n >= 8) {
-        bool stopped = false;
-        for (int base = 0; base < num_trials && !stopped; base += FM_DECIDE) {
-            const int t = base + tid;
-            const bool live = t < num_trials;
-            const int c = live ? counts[t] : 0;
-            const int pm = wave_prefix_max(c, lane);
-            if (lane == 63) w_max[wave] = pm;
-            __syncthreads();
-            int m = max(pm, run_max);
-            for (int w = 0; w < wave; ++w) m = max(m, w_max[w]);
-            const double budget = fm_trial_budget_dev(m, n, num_trials, confidence);
-            // after trial t the loop goes on iff t + 1 < budget (and t + 1 < num_trials)
-            const unsigned long long stop = __ballot(live && !((double)(t + 1) < budget));
-            if (lane == 0) w_stop[wave] = stop ? base + 64 * wave + __ffsll((long long)stop) - 1 : 0x7fffffff;
-            __syncthreads();
-            int last = 0x7fffffff;
-            for (int w = 0; w < NW; ++w) last = min(last, w_stop[w]);
-            if (last != 0x7fffffff) stopped = true;
-            else last = min(base + FM_DECIDE, num_trials) - 1;
-            if (t == last) s_mlast = m;
-            __syncthreads();
-            const int m_last = s_mlast;
-            const unsigned long long hit = __ballot(t <= last && c == m_last);
-            if (lane == 0) w_hit[wave] = hit ? base + 64 * wave + __ffsll((long long)hit) - 1 : 0x7fffffff;
-            __syncthreads();
-            if (m_last > run_max) {
-                int first = 0x7fffffff;
-                for (int w = 0; w < NW; ++w) first = min(first, w_hit[w]);
-                best_t = first;
-                run_max = m_last;
-            }
-            trials = last + 1;
-            __syncthreads();   // (the arrays are rewritten by the next round)
+    run_max = 0;
+    best_t = -1;
+    trials = 0;
+    if (n < 8) return;
+    bool stopped = false;
+    for (int base = 0; base < num_trials && !stopped; base += NT) {
+        const int t = base + tid;
+        const bool live = t < num_trials;
+        const int c = live ? counts[t] : 0;
+        const int pm = wave_prefix_max(c, lane);
+        if (lane == 63) w_max[wave] = pm;
+        __syncthreads();
+        int m = max(pm, run_max);
+        for (int w = 0; w < wave; ++w) m = max(m, w_max[w]);
+        const double budget = fm_trial_budget_dev(m, n, num_trials, confidence);
+        // after trial t the loop goes on iff t + 1 < budget (and t + 1 < num_trials)
+        const unsigned long long stop = __ballot(live && !((double)(t + 1) < budget));
+        if (lane == 0) w_stop[wave] = stop ? base + 64 * wave + __ffsll((long long)stop) - 1 : 0x7fffffff;
+        __syncthreads();
+        int last = 0x7fffffff;
+        for (int w = 0; w < NW; ++w) last = min(last, w_stop[w]);
+        if (last != 0x7fffffff) stopped = true;
+        else last = min(base + NT, num_trials) - 1;
+        if (t == last) *s_mlast = m;
+        __syncthreads();
+        const int m_last = *s_mlast;
+        const unsigned long long hit = __ballot(t <= last && c == m_last);
+        if (lane == 0) w_hit[wave] = hit ? base + 64 * wave + __ffsll((long long)hit) - 1 : 0x7fffffff;
+        __syncthreads();
+        if (m_last > run_max) {
+            int first = 0x7fffffff;
+            for (int w = 0; w < NW; ++w) first = min(first, w_hit[w]);
+            best_t = first;
+            run_max = m_last;
         }
+        trials = last + 1;
+        __syncthreads();   // (the arrays are rewritten by the next round)
     }
-    if (tid < 9) dv[D_F + tid] = best_t >= 0 ? F_all[9 * (size_t)best_t + tid] : 0.0;
-    if (tid != 0) return;
-    cnt[F_BEST_T] = best_t;
-    cnt[F_BEST_COUNT] = run_max;
-    cnt[F_TRIALS] = trials;
 }
 
-// update_landmarks.m:15,20-25: the epipolar inliers of the winning matrix (the test the counting kernel
-// applied, evaluated here instead of in a mask kernel of its own).  No model (an all-zero matrix) flags nothing.
+// update_landmarks.m:13-15,20-25: which trial wins (every workgroup replays the trial budget over the trials'
+// counts by itself -- 500 integers, cheaper than a launch of its own; workgroup 0 publishes the outcome), then
+// the epipolar inliers of the winning matrix (the test the counting kernel applied, evaluated here instead of in
+// a mask kernel of its own).  No model flags nothing.
 __global__ __launch_bounds__(256) void select_f_inliers_kernel(const double *__restrict__ p1_rc,
                                                                const double *__restrict__ m_rc,
                                                                const double *__restrict__ F_t,
                                                                const double *__restrict__ T_t,
-                                                               const double *__restrict__ F9, double thr,
+                                                               const int32_t *__restrict__ counts, int num_trials,
+                                                               double confidence, const double *__restrict__ F_all,
+                                                               double *__restrict__ dv, double thr,
                                                                const int32_t *__restrict__ row_t,
                                                                int *__restrict__ cnt, double *__restrict__ m2_rc,
                                                                double *__restrict__ F2, double *__restrict__ T2,
                                                                int32_t *__restrict__ row2, vohip_seqs SQ)
 {
     __shared__ int sh[12];
+    __shared__ int sm[3 * 4 + 1];
     const int seq__ = vohip_dev::seq_index(SQ);
     VOHIP_SEQ_STATE(p1_rc);
     VOHIP_SEQ_STATE(m_rc);
     VOHIP_SEQ_STATE(F_t);
     VOHIP_SEQ_STATE(T_t);
-    VOHIP_SEQ_STATE(F9);
+    VOHIP_SEQ_STATE(counts);
+    VOHIP_SEQ_STATE(F_all);
+    VOHIP_SEQ_STATE(dv);
     VOHIP_SEQ_STATE(row_t);
     VOHIP_SEQ_STATE(cnt);
     VOHIP_SEQ_STATE(m2_rc);
     VOHIP_SEQ_STATE(F2);
     VOHIP_SEQ_STATE(T2);
     VOHIP_SEQ_STATE(row2);
-    const int n = cnt[F_BEST_T] >= 0 ? cnt[N_CV] : 0;
+    int best_t, best_count, trials;
+    fm_decide_block<256>(counts, num_trials, confidence, cnt[N_CV], sm, best_t, best_count, trials);
     double F[9];
-    for (int q = 0; q < 9; ++q) F[q] = F9[q];
+    for (int q = 0; q < 9; ++q) F[q] = best_t >= 0 ? F_all[9 * (size_t)best_t + q] : 0.0;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 9) dv[D_F + threadIdx.x] = F[threadIdx.x];
+        if (threadIdx.x == 0) {
+            cnt[F_BEST_T] = best_t;
+            cnt[F_BEST_COUNT] = best_count;
+            cnt[F_TRIALS] = trials;
+        }
+    }
+    const int n = best_t >= 0 ? cnt[N_CV] : 0;
     auto inlier = [&](int j) {
         return vohip_dev::sampson_inlier(F, p1_rc[2 * j], p1_rc[2 * j + 1], m_rc[2 * j], m_rc[2 * j + 1], thr);
     };
@@ -1064,10 +1067,9 @@ int enqueue_side_filter(vohip_frame *f, const double *u8)
                            f->is_group ? (const int *)(f->cnt + N_C_END) : (const int *)nullptr, f->Q);
         VOHIP_TRY(vohip_fm_enqueue(ctx, f->p1_rc, f->m_rc, f->n_C, f->cnt + N_CV, f->samples8, T, p.fm_threshold,
                                    f->dv + D_NRM, f->fm_F, f->fm_counts, &f->Q));
-        hipLaunchKernelGGL(fm_decide_kernel, dim3(1, ny), dim3(FM_DECIDE), 0, s, f->fm_counts, T, p.fm_confidence, f->fm_F, f->cnt,
-                           f->dv, f->Q);
         hipLaunchKernelGGL(select_f_inliers_kernel, dim3(blocks256(f->n_C), ny), dim3(256), 0, s, f->p1_rc, f->m_rc, f->F_t,
-                           f->T_t, f->dv + D_F, p.fm_threshold, f->row_t, f->cnt, f->m2_rc, f->F2, f->T2, f->row2, f->Q);
+                           f->T_t, (const int32_t *)f->fm_counts, T, p.fm_confidence, (const double *)f->fm_F, f->dv,
+                           p.fm_threshold, f->row_t, f->cnt, f->m2_rc, f->F2, f->T2, f->row2, f->Q);
         VOHIP_HIP(ctx, hipGetLastError());
     }
     VOHIP_HIP(ctx, hipEventRecord(f->ev_side, s));
