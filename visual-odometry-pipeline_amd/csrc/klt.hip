@@ -80,11 +80,50 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__
     const int a0 = max(2 * a - 2, 0), a1 = max(2 * a - 1, 0), a2 = 2 * a, a3 = min(2 * a + 1, A - 1),
               a4 = min(2 * a + 2, A - 1);
     float h[2 * PD_ROWS + 3];
+    if constexpr (PD_ROWS > 1) {
+        // (a batch: every row's five loads are issued before the first value is used -- the loop below, left to the
+        // compiler, waits for memory after every row or two)
+        float t[2 * PD_ROWS + 3][5];
+        // away from the left and right edges a row's five values are neighbours in memory: a 16-byte load (at the
+        // values' own address: 4-byte aligned) and a 4-byte one instead of five
+        const bool inner = 2 * a - 2 >= 0 && 2 * a + 2 <= A - 1;
+        if (__builtin_amdgcn_ballot_w64(!inner) == 0) {
+            typedef float floats4 __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
-    for (int j = 0; j < 2 * PD_ROWS + 3; ++j) {
-        const int bb = min(max(2 * b_first + j - 2, 0), B - 1);
-        const float *row = src + (size_t)bb * A;
-        h[j] = tap5(row[a0], row[a1], row[a2], row[a3], row[a4]);
+            for (int j = 0; j < 2 * PD_ROWS + 3; ++j) {
+                const int bb = min(max(2 * b_first + j - 2, 0), B - 1);
+                const float *row = src + (size_t)bb * A + 2 * a - 2;
+                const floats4 q = *reinterpret_cast<const floats4 *>(row);
+                t[j][0] = q.x;
+                t[j][1] = q.y;
+                t[j][2] = q.z;
+                t[j][3] = q.w;
+                t[j][4] = row[4];
+            }
+        } else {
+            asm volatile("" ::: "memory");   // (keeps these loads on this side of the branch: hoisted above it, both sides' loads would run)
+#pragma unroll
+            for (int j = 0; j < 2 * PD_ROWS + 3; ++j) {
+                const int bb = min(max(2 * b_first + j - 2, 0), B - 1);
+                const float *row = src + (size_t)bb * A;
+                t[j][0] = row[a0];
+                t[j][1] = row[a1];
+                t[j][2] = row[a2];
+                t[j][3] = row[a3];
+                t[j][4] = row[a4];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * PD_ROWS + 3; ++j) asm volatile("" : "+v"(t[j][0]), "+v"(t[j][1]), "+v"(t[j][2]), "+v"(t[j][3]), "+v"(t[j][4]));
+#pragma unroll
+        for (int j = 0; j < 2 * PD_ROWS + 3; ++j) h[j] = tap5(t[j][0], t[j][1], t[j][2], t[j][3], t[j][4]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2 * PD_ROWS + 3; ++j) {
+            const int bb = min(max(2 * b_first + j - 2, 0), B - 1);
+            const float *row = src + (size_t)bb * A;
+            h[j] = tap5(row[a0], row[a1], row[a2], row[a3], row[a4]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < PD_ROWS; ++r) {
@@ -122,6 +161,50 @@ __global__ __launch_bounds__(256) void pyr_first_kernel(const uint8_t *__restric
     const uintptr_t img_begin = (uintptr_t)src, img_end = img_begin + (size_t)A * B;
     // image rows 2 b_first - 2 .. 2 b_first + 2 PF_ROWS: the horizontal pass of each, once
     float h[2 * PF_ROWS + 3];
+    if constexpr (WORDS) {
+        // Every row's pixels as ONE 8-byte load per thread, all eleven issued before the first is used (the per-row
+        // path below waits for memory eleven times in turn, and that wait bounds it).  The window starts at pixel
+        // 2a - 2, moved inside the row at the left and right edges; the five (clamped) pixels are picked out of
+        // it by byte index, so every thread of every wavefront runs the same instructions.  A row's two level-0
+        // floats leave as one 8-byte store.  Same pixels, same taps, same order as below: the same bits.
+        if (A >= 8) {
+            struct __attribute__((packed, aligned(1))) bytes8 { uint32_t lo, hi; };
+            struct __attribute__((packed, aligned(4))) floats2 { float x, y; };
+            const int win = min(max(2 * a - 2, 0), A - 8);
+            // v_perm_b32 selector: byte k of the result = byte (pixel k's column - win) of the window (0..3: lo, 4..7: hi)
+            const uint32_t sel = (uint32_t)(a0 - win) | (uint32_t)(a1 - win) << 8 | (uint32_t)(a2 - win) << 16 | (uint32_t)(a3 - win) << 24;
+            const uint32_t sel4 = (uint32_t)(a4 - win) | 0x0c0c0c00u;   // (0x0c: a zero byte)
+            bytes8 w[2 * PF_ROWS + 3];
+#pragma unroll
+            for (int j = 0; j < 2 * PF_ROWS + 3; ++j) {
+                const int bb = min(max(2 * b_first + j - 2, 0), B - 1);
+                w[j] = *reinterpret_cast<const bytes8 *>(src + (size_t)bb * A + win);
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * PF_ROWS + 3; ++j) {
+                const int y = 2 * b_first + j - 2;
+                const uint32_t q = __builtin_amdgcn_perm(w[j].hi, w[j].lo, sel);
+                const float t0 = (float)(q & 0xffu), t1 = (float)((q >> 8) & 0xffu), t2 = (float)((q >> 16) & 0xffu),
+                            t3 = (float)(q >> 24), t4 = (float)__builtin_amdgcn_perm(w[j].hi, w[j].lo, sel4);
+                h[j] = tap5(t0, t1, t2, t3, t4);
+                if (j >= 2 && j < 2 * PF_ROWS + 2 && y < B) {
+                    float *o = lvl0 + (size_t)y * A + 2 * a;
+                    if (right) {
+                        typedef float pair4 __attribute__((ext_vector_type(2), aligned(4)));
+                        __builtin_nontemporal_store((pair4){t2, t3}, reinterpret_cast<pair4 *>(o));
+                    } else {
+                        o[0] = t2;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < PF_ROWS; ++r) {
+                const int b = b_first + r;
+                if (b < B2) lvl1[(size_t)b * A2 + a] = tap5(h[2 * r], h[2 * r + 1], h[2 * r + 2], h[2 * r + 3], h[2 * r + 4]);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2 * PF_ROWS + 3; ++j) {
         const int y = 2 * b_first + j - 2;
