@@ -29,6 +29,10 @@ bool mxIsComplex(const mxArray *a);
 bool mxIsChar(const mxArray *a);
 bool mxIsStruct(const mxArray *a);
 bool mxIsEmpty(const mxArray *a);
+bool mxIsCell(const mxArray *a);
+mxArray *mxGetCell(const mxArray *a, size_t index);
+mwSize mxGetNumberOfDimensions(const mxArray *a);
+const mwSize *mxGetDimensions(const mxArray *a);
 size_t mxGetNumberOfElements(const mxArray *a);
 size_t mxGetM(const mxArray *a);
 size_t mxGetN(const mxArray *a);
@@ -46,6 +50,7 @@ mxArray *mxCreateDoubleScalar(double v);
 mxArray *mxCreateLogicalMatrix(mwSize m, mwSize n);
 mxArray *mxCreateLogicalScalar(bool v);
 mxArray *mxCreateNumericMatrix(mwSize m, mwSize n, mxClassID cls, mxComplexity flag);
+mxArray *mxCreateNumericArray(mwSize ndim, const mwSize *dims, mxClassID cls, mxComplexity flag);
 mxArray *mxCreateStructMatrix(mwSize m, mwSize n, int nfields, const char **names);
 mxArray *mxDuplicateArray(const mxArray *a);
 void mxDestroyArray(mxArray *a);

@@ -24,11 +24,15 @@
 static vohip_ctx *g_ctx = nullptr;
 static vohip_frame *g_frame = nullptr;   // the device-resident loop state ('frame_*' opcodes)
 static vohip_window *g_window = nullptr; // the bundle-adjustment window ('window_*' opcodes)
+static vohip_group *g_group = nullptr;   // a group of loops advanced in lockstep ('group_*' opcodes)
+static int g_group_n = 0;                // its number of sequences
 
 static void at_exit()
 {
     if (g_window) vohip_window_destroy(g_window);
     g_window = nullptr;
+    if (g_group) vohip_group_destroy(g_group);
+    g_group = nullptr;
     if (g_frame) vohip_frame_destroy(g_frame);
     g_frame = nullptr;
     if (g_ctx) vohip_destroy(g_ctx);
@@ -105,6 +109,40 @@ static void frame_outputs(int nlhs, mxArray *plhs[], const vohip_frame_pose &pos
         for (int k = 0; k < 9; ++k) mxSetField(plhs[1], 0, names[k], mxCreateDoubleScalar(values[k]));
     }
     if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(status);
+}
+
+// fields of a 'frame_create' / 'group_create' parameter struct over the library's defaults
+static void frame_params_from_struct(const mxArray *st, vohip_frame_params &p)
+{
+    auto field = [&](const char *name, double dflt) {
+        const mxArray *f = mxGetField(st, 0, name);
+        return f ? mxGetScalar(f) : dflt;
+    };
+    p.r_discard_redundant = field("r_discard_redundant", p.r_discard_redundant);
+    p.angle_threshold_deg = field("angle_threshold_deg", p.angle_threshold_deg);
+    p.min_depth = field("min_depth", p.min_depth);
+    p.max_depth = field("max_depth", p.max_depth);
+    p.min_quality = field("min_quality", p.min_quality);
+    p.filter_size = (int)field("filter_size", p.filter_size);
+    p.detector = (int)field("detector", p.detector);
+    p.refine_pose = (int)field("refine_pose", p.refine_pose);
+    p.is_BA = (int)field("is_BA", p.is_BA);
+    p.min_contrast = field("min_contrast", p.min_contrast);
+}
+
+// info struct array (1 x n) of the 'group_step' opcode, same fields as frame_outputs'
+static mxArray *group_info(const vohip_frame_pose *pose, const vohip_frame_counts *counts, int n)
+{
+    const char *names[] = {"n_tracked", "n_inliers", "n_iter", "num_iterations", "n_landmarks", "n_candidates",
+                           "num_new", "n_detected", "n_kept"};
+    mxArray *info = mxCreateStructMatrix(1, n, 9, names);
+    for (int s = 0; s < n; ++s) {
+        const double values[] = {(double)pose[s].n_tracked, (double)pose[s].n_inliers, (double)pose[s].n_iter,
+                                 pose[s].num_iterations, (double)counts[s].n_landmarks, (double)counts[s].n_candidates,
+                                 (double)counts[s].num_new, (double)counts[s].n_detected, (double)counts[s].n_kept};
+        for (int k = 0; k < 9; ++k) mxSetField(info, s, names[k], mxCreateDoubleScalar(values[k]));
+    }
+    return info;
 }
 
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
@@ -302,22 +340,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         if (g_frame) { vohip_frame_destroy(g_frame); g_frame = nullptr; }
         vohip_frame_params p;
         vohip_frame_default_params(&p);
-        if (nrhs > 4 && mxIsStruct(in[3])) {
-            auto field = [&](const char *name, double dflt) {
-                const mxArray *f = mxGetField(in[3], 0, name);
-                return f ? mxGetScalar(f) : dflt;
-            };
-            p.r_discard_redundant = field("r_discard_redundant", p.r_discard_redundant);
-            p.angle_threshold_deg = field("angle_threshold_deg", p.angle_threshold_deg);
-            p.min_depth = field("min_depth", p.min_depth);
-            p.max_depth = field("max_depth", p.max_depth);
-            p.min_quality = field("min_quality", p.min_quality);
-            p.filter_size = (int)field("filter_size", p.filter_size);
-            p.detector = (int)field("detector", p.detector);
-            p.refine_pose = (int)field("refine_pose", p.refine_pose);
-            p.is_BA = (int)field("is_BA", p.is_BA);
-            p.min_contrast = field("min_contrast", p.min_contrast);
-        }
+        if (nrhs > 4 && mxIsStruct(in[3])) frame_params_from_struct(in[3], p);
         check(vohip_frame_create(c, dbl(in[0], "K"), (int)mxGetScalar(in[1]), (int)mxGetScalar(in[2]), 1, &p, &g_frame));
     } else if (is("frame_reset")) {
         // vohip_mex('frame_reset', image uint8, X 3xn, P_rc 2xn, T_W_C 4x4)   (main_demo.m:268-303, 342-344)
@@ -437,6 +460,98 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
             check(vohip_window_state(g_window, &num_key, nullptr, nullptr, nullptr));
             plhs[out + 3] = mxCreateDoubleScalar(num_key);
         }
+    } else if (is("group_create")) {
+        // vohip_mex('group_create', K, rows, cols, params struct, n_sequences, max_frames): n_sequences loops of one
+        // image size, camera and parameter set that advance together, one launch sequence per frame for all of them
+        // (the independent runs of main_eval.m:20-23); params as for 'frame_create' (is_BA must be 0).
+        if (g_group) { vohip_group_destroy(g_group); g_group = nullptr; }
+        vohip_frame_params p;
+        vohip_frame_default_params(&p);
+        if (mxIsStruct(in[3])) frame_params_from_struct(in[3], p);
+        g_group_n = (int)mxGetScalar(in[4]);
+        check(vohip_group_create(c, dbl(in[0], "K"), (int)mxGetScalar(in[1]), (int)mxGetScalar(in[2]), 1, &p, g_group_n,
+                                 (int)mxGetScalar(in[5]), &g_group));
+    } else if (is("group_prepare")) {
+        // vohip_mex('group_prepare', seq (1-based), images (cell array of uint8; the first is the image the loop is
+        // reset on, main_demo.m:342-344), detector (-1: the group's, 0 Harris, 1 MinEigen, 2 FAST), min_quality, min_contrast)
+        // vohip_mex('group_prepare', seq, from_seq (a sequence that holds the same images), detector, min_quality, min_contrast)
+        if (!g_group) mexErrMsgIdAndTxt("vohip:usage", "group_create first");
+        const int seq = (int)mxGetScalar(in[0]) - 1;
+        if (mxIsCell(in[1])) {
+            const int n = numel(in[1]);
+            const uint8_t **imgs = scratch<const uint8_t *>((size_t)n);
+            for (int k = 0; k < n; ++k) {
+                const mxArray *im = mxGetCell(in[1], k);
+                if (!im || !mxIsUint8(im)) mexErrMsgIdAndTxt("vohip:type", "images must be uint8");
+                imgs[k] = mxGetUint8s(im);
+            }
+            check(vohip_group_prepare(g_group, seq, imgs, n, 0, (int)mxGetScalar(in[2]), mxGetScalar(in[3]), mxGetScalar(in[4])));
+        } else {
+            check(vohip_group_prepare_like(g_group, seq, (int)mxGetScalar(in[1]) - 1, (int)mxGetScalar(in[2]), mxGetScalar(in[3]),
+                                           mxGetScalar(in[4])));
+        }
+    } else if (is("group_reset")) {
+        // vohip_mex('group_reset', seq, X 3xn, P_rc 2xn, T_W_C 4x4)   (the state after the bootstrap, main_demo.m:268-303)
+        if (!g_group) mexErrMsgIdAndTxt("vohip:usage", "group_create first");
+        check(vohip_group_reset(g_group, (int)mxGetScalar(in[0]) - 1, dbl(in[1], "X"), nullptr, dbl(in[2], "P"), cols(in[1]),
+                                dbl(in[3], "T_W_C")));
+    } else if (is("group_step")) {
+        // [T_W_C 4x4xS, info 1xS, status 1xS] = vohip_mex('group_step', u3 3 x h x S, u8 8 x trials x S or [])
+        // One frame of every sequence that has one left; status(k): 0 done, VOHIP_SAMPLES_EXHAUSTED -> 'group_retry'
+        // for that sequence, VOHIP_SEQUENCE_IDLE the sequence took no part, else it stopped (as the reference's
+        // script does at main_demo.m:389-391) and stays idle.
+        if (!g_group) mexErrMsgIdAndTxt("vohip:usage", "group_create first");
+        const int S = g_group_n;
+        const mwSize *d3 = mxGetDimensions(in[0]);
+        const int h = mxGetNumberOfDimensions(in[0]) >= 2 ? (int)d3[1] : 0;
+        if (rows(in[0]) != 3 || numel(in[0]) != 3 * h * S) mexErrMsgIdAndTxt("vohip:usage", "u3 must be 3 x h x n_sequences");
+        const bool have_u8 = nrhs > 2 && !mxIsEmpty(in[1]);
+        check(vohip_group_begin(g_group, dbl(in[0], "u3"), h, have_u8 ? dbl(in[1], "u8") : nullptr));
+        vohip_frame_pose *pose = scratch<vohip_frame_pose>((size_t)S);
+        vohip_frame_counts *counts = scratch<vohip_frame_counts>((size_t)S);
+        int *status = scratch<int>((size_t)S);
+        check(vohip_group_finish(g_group, pose, counts, status));
+        const mwSize dims[3] = {4, 4, (mwSize)S};
+        plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxREAL);
+        for (int s = 0; s < S; ++s) std::memcpy(mxGetDoubles(plhs[0]) + 16 * (size_t)s, pose[s].T_W_C, sizeof(double) * 16);
+        if (nlhs > 1) plhs[1] = group_info(pose, counts, S);
+        if (nlhs > 2) {
+            plhs[2] = mxCreateDoubleMatrix(1, S, mxREAL);
+            for (int s = 0; s < S; ++s) mxGetDoubles(plhs[2])[s] = status[s];
+        }
+    } else if (is("group_retry")) {
+        // [T_W_C, info, status] = vohip_mex('group_retry', seq, u3 3xh): more hypotheses for one sequence
+        if (!g_group) mexErrMsgIdAndTxt("vohip:usage", "group_create first");
+        vohip_frame_pose pose;
+        vohip_frame_counts counts;
+        const int st = vohip_group_retry(g_group, (int)mxGetScalar(in[0]) - 1, dbl(in[1], "u3"), cols(in[1]), &pose, &counts);
+        if (st != VOHIP_OK && st != VOHIP_SAMPLES_EXHAUSTED) check(st);
+        frame_outputs(nlhs, plhs, pose, counts, st);
+    } else if (is("group_state")) {
+        // [P, X, C, F, T] = vohip_mex('group_state', seq): as 'frame_state', of one sequence
+        if (!g_group) mexErrMsgIdAndTxt("vohip:usage", "group_create first");
+        const int seq = (int)mxGetScalar(in[0]) - 1;
+        int nL = 0, nC = 0;
+        check(vohip_group_sizes(g_group, seq, &nL, &nC, nullptr));
+        plhs[0] = mxCreateDoubleMatrix(2, nL, mxREAL);
+        mxArray *X3 = mxCreateDoubleMatrix(3, nL, mxREAL), *ids = mxCreateDoubleMatrix(1, nL, mxREAL);
+        mxArray *C = mxCreateDoubleMatrix(2, nC, mxREAL), *Fm = mxCreateDoubleMatrix(2, nC, mxREAL);
+        mxArray *T = mxCreateDoubleMatrix(12, nC, mxREAL);
+        check(vohip_group_state(g_group, seq, mxGetDoubles(plhs[0]), mxGetDoubles(X3), mxGetDoubles(ids), mxGetDoubles(C),
+                                mxGetDoubles(Fm), mxGetDoubles(T)));
+        plhs[1] = mxCreateDoubleMatrix(4, nL, mxREAL);
+        for (int k = 0; k < nL; ++k) {
+            std::memcpy(mxGetDoubles(plhs[1]) + 4 * (size_t)k, mxGetDoubles(X3) + 3 * (size_t)k, sizeof(double) * 3);
+            mxGetDoubles(plhs[1])[4 * (size_t)k + 3] = mxGetDoubles(ids)[k];
+        }
+        mxDestroyArray(X3);
+        mxDestroyArray(ids);
+        plhs[2] = C;
+        plhs[3] = Fm;
+        plhs[4] = T;
+    } else if (is("group_destroy")) {
+        if (g_group) vohip_group_destroy(g_group);
+        g_group = nullptr;
     } else if (is("window_destroy")) {
         if (g_window) vohip_window_destroy(g_window);
         g_window = nullptr;
