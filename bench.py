@@ -256,7 +256,7 @@ def bench_group(vo, torch, ctx, scene, frames, poses, steps, warmup, n_seq, seed
         ctx.check(lib.vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1))
         ctx.set_option("klt_stats", 0)
         out["tracker"] = tracker_roofline(tot.value, longest.value, launches.value, tr.value, it.value,
-                                          frames[0].shape, frames_of_run=(warmup + steps) * n_seq)
+                                          frames[0].shape, frames_of_run=(warmup + steps) * n_seq, group=n_seq > 1)
     for q in gs:
         q.close()
     for c in ctxs[1:]:
@@ -264,7 +264,7 @@ def bench_group(vo, torch, ctx, scene, frames, poses, steps, warmup, n_seq, seed
     return out
 
 
-def tracker_roofline(total_ms, longest_ms, launches, tracks, iterations, shape, frames_of_run):
+def tracker_roofline(total_ms, longest_ms, launches, tracks, iterations, shape, frames_of_run, group=False):
     """Roofline entry of the tracker launches of a loop (or group of loops): the launches' own durations (event pairs
     on their streams) against the work their tracks did (the kernel's counters, same run repeated)."""
     passes = tracks * 5 * 2                             # (track, level, direction) triples
@@ -273,8 +273,8 @@ def tracker_roofline(total_ms, longest_ms, launches, tracks, iterations, shape, 
     rows, cols = shape
     pyr = 4.0 * rows * cols * sum(0.25 ** l for l in range(5))
     s = total_ms * 1e-3
-    # (the library launches the build for 5 wavefronts per SIMD from 8 192 tracks per launch on, the one for 3 below)
-    name = "klt_track_kernel<21, 5>" if tracks / max(launches, 1) >= 8192 else "klt_track_kernel<21, 3>"
+    # (the library launches the build for 5 wavefronts per SIMD for a group of loops, the one for 3 for a single loop)
+    name = "klt_track_kernel<21, 5>" if group else "klt_track_kernel<21, 3>"
     return {"kernel": name, "launches": launches, "tracks": tracks, "tracks_per_launch": tracks / max(launches, 1),
             "kernel_ms_total": total_ms, "kernel_ms_mean": total_ms / max(launches, 1), "kernel_ms_longest": longest_ms,
             "tracker_us_per_frame": 1e3 * total_ms / max(frames_of_run, 1),

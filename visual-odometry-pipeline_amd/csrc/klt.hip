@@ -381,8 +381,11 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, size_t seq_float
         stage_patch<C::SI>(Pl, A, B, ia - C::HALF - 1, ib - C::HALF - 1, sI);
         __syncthreads();
 
-        float T[C::RPL], GX[C::RPL], GY[C::RPL];
+        float GX[C::RPL], GY[C::RPL];
         double gxx = 0.0, gxy = 0.0, gyy = 0.0;
+        // sum (T - J) G = sum T G - sum J G: the first sum does not change during the iterations, so the
+        // lane keeps its part of it (fp32, rows in increasing order) and an iteration only forms sum J G
+        float ctx_ = 0.f, cty_ = 0.f;
         {
             // S(q, j): the previous image sampled at window row wb0 + q, column wa - 1 + j.  Tap rows are
             // interpolated along a first (h; tap row r serves the samples of rows r - 1 and r), so
@@ -409,13 +412,14 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, size_t seq_float
                         GY[k] = gy;
                         gyy += (double)gy * (double)gy;
                         gxy += (double)GX[k] * (double)gy;
+                        cty_ = __builtin_fmaf(s_cur, gy, cty_);   // (s_cur: pixel k's own value, the sample of row r - 2)
                     }
                     if (r >= 1 && r <= C::RPL) {
                         const int k = r - 1;
                         const float gx = live[k] ? (sp - sm) * 0.5f : 0.f;
-                        T[k] = s_next;   // (a masked pixel's gradients are zero: its template value never counts)
-                        GX[k] = gx;
+                        GX[k] = gx;   // (a masked pixel's gradients are zero: its template value never counts)
                         gxx += (double)gx * (double)gx;
+                        ctx_ = __builtin_fmaf(s_next, gx, ctx_);
                     }
                     s_prev = s_cur;
                     s_cur = s_next;
@@ -426,14 +430,6 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, size_t seq_float
             }
         }
         vohip_dev::wave_sum3_f64(gxx, gxy, gyy);
-        // sum (T - J) G = sum T G - sum J G: the first sum does not change during the iterations, so the
-        // lane keeps its part of it (fp32, rows in increasing order) and an iteration only forms sum J G
-        float ctx_ = 0.f, cty_ = 0.f;
-#pragma unroll
-        for (int k = 0; k < C::RPL; ++k) {
-            ctx_ = __builtin_fmaf(T[k], GX[k], ctx_);
-            cty_ = __builtin_fmaf(T[k], GY[k], cty_);
-        }
         const double det = gxx * gyy - gxy * gxy;
         const double lmin = 0.5 * ((gxx + gyy) - sqrt((gxx - gyy) * (gxx - gyy) + 4.0 * gxy * gxy));
         // lambda_min / W^2 >= KLT_MIN_EIG, without the division: min_lmin is the smallest double whose
@@ -831,7 +827,12 @@ int vohip_klt_enqueue_sets(vohip_ctx *ctx, int slot_prev, int slot_cur, const vo
     // (measurement only: an event pair around the launch, on the stream it runs on)
     const bool timed = ctx->opt_klt_time && ctx->klt_ev && ctx->klt_ev_used < vohip_ctx::KLT_TIME_PAIRS;
     if (timed) VOHIP_HIP(ctx, hipEventRecord(ctx->klt_ev[2 * ctx->klt_ev_used], ctx->stream));
-    if (block_size == 21 && (long long)total * ny >= KLT_FULL_FROM)
+    // (sets whose counts live on the device are sized by an upper bound: how many tracks a single loop's launch
+    // really carries -- a few thousand -- is not known here, a group's launches carry thousands per sequence)
+    bool bound_only = false;
+    for (int q = 0; q < nsets; ++q) bound_only = bound_only || sets[q].n_dev != nullptr;
+    const bool full = bound_only ? ny >= 2 : (long long)total * ny >= KLT_FULL_FROM;
+    if (block_size == 21 && full)
         hipLaunchKernelGGL((klt_track_kernel<21, KLT_WAVES_21_FULL>), dim3(total, ny), dim3(64), 0, ctx->stream, P, Q, S, swap_xy,
                            max_iter, max_bidir_error, lmin_threshold(21), d_stats, SQ);
     else if (block_size == 21)
