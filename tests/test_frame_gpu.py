@@ -143,6 +143,38 @@ def test_prepare_in_chunks_and_release_mid_run(vo, ctx, oracle, sequence, on_dev
             np.testing.assert_array_equal(getattr(plain[4], key), getattr(other[4], key), err_msg=key)
 
 
+def test_prepare_finds_images_it_had_to_convert_and_warns_when_it_is_never_hit(vo, ctx, oracle, sequence):
+    """The library recognises a prepared image by its address.  Images in the other memory order are copied by
+    prepare(): later calls with the caller's own objects must find those copies (same results as the unprepared
+    loop).  A loop that is fed copies of the prepared images never hits them: that earns a warning."""
+    import warnings
+    scene, poses, frames = sequence
+    X0, xy = _start(vo, oracle, sequence)
+    hp = vo.default_hyper_paras("kitti")
+    fortran = [np.asfortranarray(f) for f in frames]      # (the loop below is row-major: every one is converted)
+
+    def run(images, prepared, feed):
+        dev = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(5), ctx=ctx)
+        if prepared:
+            dev.prepare(images[1:])
+        fed = [feed(im) for im in images]
+        Ts = [dev.process_frame(fed[i], next_image=fed[i + 1] if i + 1 < len(fed) else None) for i in range(1, 6)]
+        hits = getattr(dev, "_prepared_hits", 0)
+        dev.close()
+        return np.array(Ts), hits
+
+    plain, _ = run(frames, False, lambda im: im)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        conv, hits = run(fortran, True, lambda im: im)
+    np.testing.assert_array_equal(plain, conv)
+    assert hits >= 5
+    with pytest.warns(RuntimeWarning, match="none of the"):
+        copies, hits = run(frames, True, lambda im: im.copy())
+    np.testing.assert_array_equal(plain, copies)
+    assert hits == 0
+
+
 def test_device_loop_matches_stage_by_stage_loop(vo, ctx, oracle, sequence):
     scene, poses, frames = sequence
     X0, xy = _start(vo, oracle, sequence)

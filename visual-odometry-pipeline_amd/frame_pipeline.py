@@ -110,6 +110,11 @@ class VOPipelineDevice:
         self.last_counts = None
 
     def _image_ptr(self, image):
+        # an image that prepare() had to copy (wrong memory order, not an ndarray): the library knows the copy
+        hit = getattr(self, "_prepared_as", {}).get(id(image))
+        if hit is not None and hit[0] is image:
+            self._prepared_hits += 1
+            return C.c_void_p(hit[1].ctypes.data), 0, hit[1]
         if hasattr(image, "data_ptr"):                      # uint8 image already on the GPU (torch tensor)
             if tuple(image.shape) != self._shape:
                 raise ValueError("image shape changed")
@@ -127,7 +132,9 @@ class VOPipelineDevice:
         made by batched launches (vohip_frame_prepare).  Frames later passed to process_frame / begin_frame as
         the same objects then cost no transfer, no pyramid and no detection of their own; results do not change.
         Pass an empty list to release the prepared data."""
-        ptrs, keep, on_dev = [], [], None
+        self._warn_unused_prepare()
+        self._prepared_as = {}
+        ptrs, keep, on_dev, copies = [], [], None, {}
         for im in images:
             ptr, dev, k = self._image_ptr(im)
             if on_dev is None:
@@ -136,9 +143,26 @@ class VOPipelineDevice:
                 raise ValueError("host and device images cannot be mixed in one prepared sequence")
             ptrs.append(ptr.value)
             keep.append(k)
+            if k is not im:   # converted: later calls with `im` must find this very copy, not make another
+                copies[id(im)] = (im, k)
         arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
         self.ctx.check(_lib.load().vohip_frame_prepare(self._h, arr, len(ptrs), int(on_dev or 0)))
-        self._prepared = keep   # (the pointers are the library's keys: the arrays must stay alive and in place)
+        # (the pointers are the library's keys: the arrays must stay alive, in place and unchanged)
+        self._prepared = keep
+        self._prepared_as = copies
+        self._prepared_hits = 0
+        self._prepared_ptrs = set(ptrs)
+
+    def _warn_unused_prepare(self):
+        """A prepared sequence none of whose images was ever passed to the loop holds GPU memory for nothing: the
+        images were probably copied or reallocated between prepare() and the loop (the library recognises a
+        prepared image by its address)."""
+        done = len(self.num_X) - 1
+        if getattr(self, "_prepared", None) and getattr(self, "_prepared_hits", 0) == 0 and done > getattr(self, "_prepared_at", 0):
+            import warnings
+            warnings.warn("VOPipelineDevice.prepare(): none of the %d prepared images was passed to the loop since "
+                          "(pass the same objects that were prepared)" % len(self._prepared), RuntimeWarning, stacklevel=3)
+        self._prepared_at = done
 
     def process_frame(self, image, next_image=None):
         """One frame of the loop (main_demo.m:377-427).  next_image: the frame after this one, when the
@@ -162,6 +186,8 @@ class VOPipelineDevice:
             ptr, on_dev, keep = self._image_ptr(image)
         nptr, non_dev, nkeep = self._image_ptr(next_image) if next_image is not None else (None, 0, None)
         self._next_image = (next_image, (nptr, non_dev, nkeep)) if next_image is not None else None
+        if getattr(ptr, "value", None) in getattr(self, "_prepared_ptrs", ()):
+            self._prepared_hits += 1
         have_map = self.num_C[-1] > 0                                                       # :406
         u8 = None
         if have_map:                                                                        # update_landmarks.m:13
@@ -279,6 +305,8 @@ class VOPipelineDevice:
                                num_new=list(self.num_new))
 
     def close(self):
+        if getattr(self, "_h", None) is not None and getattr(self, "num_X", None):
+            self._warn_unused_prepare()
         if getattr(self, "_window", None) is not None:
             _lib.load().vohip_window_destroy(self._window)
             self._window = None
