@@ -154,3 +154,27 @@ def test_group_feature_variants_and_a_sequence_that_stops(vo, ctx, oracle, world
         assert group.seqs[s].error is None
         _compare(group, s, refs[s])
     group.close()
+
+
+def test_group_slots_across_the_64_bit_mask(vo, ctx, oracle, worlds):
+    """A group of 40 slots of which only slots 0, 31, 32 and 39 hold a sequence: a launch serves the set bits of
+    a 64-bit mask, and a workgroup finds its sequence as the position of the blockIdx.y-th set bit -- bits on both
+    sides of the 32-bit boundary, idle slots in between.  Every sequence as its own single loop, bit for bit."""
+    hp = vo.default_hyper_paras("kitti")
+    used = (0, 31, 32, 39)
+    specs = {}
+    for k, slot in enumerate(used):
+        scene, poses, frames = worlds[k % 3]
+        frames = frames[:5 + (k % 2)]
+        X0, xy = _start(oracle, scene, poses, frames, thin=350, seed=30 + k)
+        specs[slot] = (frames, X0, xy, poses[0], 80 + k)
+    refs = {slot: _single(vo, ctx, hp, *sp) for slot, sp in specs.items()}
+    group = vo.VOGroupDevice(K, (H, W), 40, 6, hyper_paras=hp, ctx=ctx)
+    for slot, (frames, X0, xy, T0, seed) in specs.items():
+        group.add_sequence(slot, frames, X0, xy, T0, rng=np.random.default_rng(seed))
+    group.run()
+    for slot in used:
+        assert group.seqs[slot].error is None
+        _compare(group, slot, refs[slot])
+    assert all(group.seqs[s] is None for s in range(40) if s not in used)
+    group.close()
