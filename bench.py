@@ -875,6 +875,13 @@ def main():
                          "compulsory_hbm_bytes_per_frame": klt_loop["compulsory_hbm_bytes_per_frame"],
                          "stress_config_8192_tracks": klt_stress},
         }
+        g16 = extra.get("frames_per_s_group_of_16", {}).get("tracker") if isinstance(extra.get("frames_per_s_group_of_16"), dict) else None
+        out["roofline"]["frac_note"] = (
+            "frac prices the single loop's own launches (about 2 000 tracks each), which last as long as their slowest "
+            "track; the same kernel in launches that fill the GPU: %s of the LDS peak at 8 192 tracks (stress_config_8192_tracks), "
+            "%s in a group of 16 loops (frames_per_s_group_of_16.tracker), where it issues at 0.60 of the vector issue rate "
+            "(counter pass of profiles/r03b_group16)"
+            % ("%.3f" % klt_stress["frac_lds"] if klt_stress else "n/a", "%.3f" % g16["frac_lds"] if g16 else "n/a"))
         if hyps_per_s is not None:
             out.update({
                 "ransac_hypotheses_per_s": hyps_per_s,

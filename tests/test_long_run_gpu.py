@@ -90,3 +90,41 @@ def test_540_frames_through_main_eval(vo, ctx, long_sequence, tmp_path):
             np.testing.assert_array_equal(a[key], g[key], err_msg=key)
     back = vo.load_results(os.path.join(tmp_path / "a", sorted(os.listdir(tmp_path / "a"))[0]))
     assert back["S"]["est_trans"].shape == (3, N_FRAMES - 2) and back["errs"].shape == (3, 6)
+
+
+def test_a_group_of_loops_over_200_frames_is_its_single_loops(vo, ctx, long_sequence):
+    """Five sequences of 120-200 frames each (windows of the long sequence starting 0, 40, ... frames into it,
+    own start sets and seeds) as one group of loops in lockstep against their own single loops: poses, counts, ids,
+    final state and generator positions bit for bit, through hundreds of frames in which the landmark and
+    candidate counts of every sequence move independently across the kernels' block sizes and the shorter
+    sequences drop out of the group."""
+    bench, scene, frames, poses = long_sequence
+    hp = bench.kitti_hyper_paras(vo)
+    K = vo.synth.K_KITTI
+    specs = []
+    for s, (first, length) in enumerate(((0, 200), (40, 160), (80, 200), (120, 120), (160, 180))):
+        fr = frames[first:first + length + 1]
+        X0, xy0 = bench.init_points(vo, ctx, scene, fr[0], poses[first])
+        specs.append((fr, X0, xy0, poses[first], 500 + s))
+    refs = []
+    for fr, X0, xy0, T0, seed in specs:
+        dev = vo.VOPipelineDevice(K, fr[0], X0, xy0, T0, hyper_paras=hp, rng=np.random.default_rng(seed), ctx=ctx)
+        Ts = [dev.process_frame(fr[i], next_image=fr[i + 1] if i + 1 < len(fr) else None) for i in range(1, len(fr))]
+        refs.append((np.array(Ts), list(dev.num_X), list(dev.num_C), list(dev.num_new), dev.S, dev.rng.bit_generator.state))
+        dev.close()
+    group = vo.VOGroupDevice(K, frames[0].shape, len(specs), max(len(sp[0]) for sp in specs), hyper_paras=hp, ctx=ctx)
+    for s, (fr, X0, xy0, T0, seed) in enumerate(specs):
+        group.add_sequence(s, fr, X0, xy0, T0, rng=np.random.default_rng(seed))
+    assert group.run() == sum(len(sp[0]) - 1 for sp in specs)
+    for s, (T, nX, nC, nN, S, state) in enumerate(refs):
+        q = group.seqs[s]
+        assert q.error is None, s
+        et, er = group.trajectory(s)
+        np.testing.assert_array_equal(et[:, 1:], T[:, :3, 3].T, err_msg="translations of sequence %d" % s)
+        np.testing.assert_array_equal(er[:, 1:], np.array([t[:3, :3].reshape(-1, order="F") for t in T]).T)
+        assert (q.num_X, q.num_C, q.num_new) == (nX, nC, nN), s
+        assert q.rng.bit_generator.state == state, s
+        Sg = group.S(s)
+        for key in ("P", "X", "C", "F", "T"):
+            np.testing.assert_array_equal(getattr(Sg, key), getattr(S, key), err_msg="%s of sequence %d" % (key, s))
+    group.close()
