@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64) void dlt_solve_kernel(const double *__restrict_
     }
 }
 
-constexpr int RF_THREADS = 256;
+constexpr int RF_THREADS = 512;
 
 // Sums over the workgroup of the NS values every thread holds, left in sOut (two barriers + one).
 template <int NS>
