@@ -247,14 +247,21 @@ def matching_init(img0, img_seqs, hp):
     return init_points_[alive], pts[alive]                                                 # :23-24
 
 
-def pose_estimation_init(init_points, matched_points, K, draw_octets, rng):
-    """Initialization/pose_estimation_init.m:1-37, 'fundamental' branch."""
+def pose_estimation_init(init_points, matched_points, K, draw_octets, rng, sfm_pose="fundamental"):
+    """Initialization/pose_estimation_init.m:1-37.  'essential' (:19): the toolbox's estimateEssentialMatrix is
+    closed source; it is defined here as the same RANSAC with that function's default settings (500 trials, Sampson
+    distance 0.1 px^2) followed by the nearest essential matrix to K' F K."""
     K = np.asarray(K, dtype=np.float64)
     p1 = np.asarray(init_points, dtype=np.float64)
     p2 = np.asarray(matched_points, dtype=np.float64)
-    res = orc.fmatrix_ransac(p1.T, p2.T, draw_octets(rng, p1.shape[0], 2000), 1e-2, 99.9)  # :7-12
+    if sfm_pose == "fundamental":
+        res = orc.fmatrix_ransac(p1.T, p2.T, draw_octets(rng, p1.shape[0], 2000), 1e-2, 99.9)  # :7-12
+        essMat = K.T @ res["F"] @ K                                                        # :15
+    else:
+        res = orc.fmatrix_ransac(p1.T, p2.T, draw_octets(rng, p1.shape[0], 500), 0.1, 99.9)    # :19
+        U, _, Vt = np.linalg.svd(K.T @ res["F"] @ K)
+        essMat = U @ np.diag([1.0, 1.0, 0.0]) @ Vt
     inl = res["mask"]
-    essMat = K.T @ res["F"] @ K                                                            # :15
     init_valid, matched_valid = np.asarray(init_points)[inl], np.asarray(matched_points)[inl]   # :25-26
     R, loc, _ = orc.relative_pose(essMat, K, p1[inl].T, p2[inl].T)                         # :29-33
     T_W_C = np.eye(4)
@@ -282,7 +289,8 @@ def triangulation_init(init_valid, matched_valid, T_init_WC, K, hp):
 def bootstrap(img0, img_seqs, K, hp, draw_octets, rng):
     """main_demo.m:252-264."""
     init_points, matched_points = matching_init(img0, img_seqs, hp)
-    T_init_WC, init_valid, matched_valid = pose_estimation_init(init_points, matched_points, K, draw_octets, rng)
+    T_init_WC, init_valid, matched_valid = pose_estimation_init(init_points, matched_points, K, draw_octets, rng,
+                                                                getattr(hp, "sfm_pose", "fundamental"))
     pts3d, matched_valid = triangulation_init(init_valid, matched_valid, T_init_WC, K, hp)
     p_W_landmarks = np.asarray(pts3d, dtype=np.float64)
     keypoints = np.asarray(matched_valid, dtype=np.float64)

@@ -98,3 +98,41 @@ def test_bootstrap_matches_cpu_restatement(vo, ctx, oracle):
     # moving forward by about half a unit per frame
     steps = np.diff(et, axis=1)
     assert np.all(steps[2] > 0.3) and np.all(steps[2] < 0.7), steps[2]
+
+
+def test_essential_branch_of_the_bootstrap(vo, ctx, oracle):
+    """sfm_pose = 'essential' (pose_estimation_init.m:19).  The toolbox's estimateEssentialMatrix is closed source;
+    the branch is this project's stated definition (the same RANSAC with that function's default trial count and
+    Sampson distance, then the nearest essential matrix): parity unpinned against MATLAB.  Here: device against
+    the CPU restatement of that definition, the essential matrix's singular values, and the pose it yields against
+    the 'fundamental' branch's and the truth."""
+    import copy
+    from oracle import pipeline_oracle as po
+    K = np.array([[400.0, 0, 320], [0, 400.0, 120], [0, 0, 1]])
+    scene = vo.synth.CorridorScene(K=K, width=640, height=240)
+    poses = vo.synth.corridor_trajectory(4, step=0.5)
+    frames = [scene.render(T) for T in poses]
+    hp = copy.copy(vo.default_hyper_paras("kitti"))
+    hp.sfm_pose = "essential"
+    ip, mp = vo.matching_init(frames[0], frames[1:3], hp, ctx=ctx)
+    E, inl = vo.estimateEssentialMatrix(ip, mp, K, Confidence=99.9, rng=np.random.default_rng(3), ctx=ctx)
+    sv = np.linalg.svd(E, compute_uv=False)
+    np.testing.assert_allclose(sv, [1.0, 1.0, 0.0], atol=1e-12)
+    assert inl.mean() > 0.6      # (Sampson distance 0.1 px^2: a third of a pixel)
+    x1 = np.linalg.solve(K, np.vstack([ip[inl].T, np.ones(inl.sum())]))
+    x2 = np.linalg.solve(K, np.vstack([mp[inl].T, np.ones(inl.sum())]))
+    assert np.abs(np.einsum("in,ij,jn->n", x2, E, x1)).max() < 5e-3       # the epipolar constraint of the inliers
+    T_r, iv_r, _ = po.pose_estimation_init(ip, mp, K, vo.draw_octets, np.random.default_rng(3), "essential")
+    T_g, iv_g, _ = vo.pose_estimation_init(ip, mp, K, hp, rng=np.random.default_rng(3), ctx=ctx)
+    assert iv_g.shape == iv_r.shape
+    np.testing.assert_allclose(T_g, T_r, rtol=0, atol=1e-7)
+    hp_f = copy.copy(hp)
+    hp_f.sfm_pose = "fundamental"
+    T_f, _, _ = vo.pose_estimation_init(ip, mp, K, hp_f, rng=np.random.default_rng(3), ctx=ctx)
+    np.testing.assert_allclose(T_g[:3, :3], T_f[:3, :3], atol=5e-3)       # the two branches see the same motion
+    assert abs(float(T_g[:3, 3] @ T_f[:3, 3])) > 0.999                    # (unit baselines, same direction)
+    X, kp, T0 = vo.bootstrap(frames[0], frames[1:3], K, hp, rng=np.random.default_rng(3), ctx=ctx)
+    assert X.shape[0] == kp.shape[0] > 500
+    hp.sfm_pose = "five_point"
+    with pytest.raises(NotImplementedError):
+        vo.pose_estimation_init(ip, mp, K, hp, rng=np.random.default_rng(3), ctx=ctx)

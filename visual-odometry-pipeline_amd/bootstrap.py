@@ -59,6 +59,26 @@ def matching_init(img0, img_seqs, hyper_paras, ctx=None):
     return init_points_[validity_img1], matched_points1_[validity_img1]                    # :23-24
 
 
+def estimateEssentialMatrix(matchedPoints1, matchedPoints2, K, MaxNumTrials=500, MaxDistance=0.1, Confidence=99.0,
+                            samples=None, rng=None, ctx=None):
+    """[E, inliersIndex] = estimateEssentialMatrix(matchedPoints1, matchedPoints2, cameraParams, 'Confidence', c)
+    (pose_estimation_init.m:19; MaxNumTrials 500 and MaxDistance 0.1 px^2 Sampson are the toolbox function's
+    documented defaults).
+
+    The toolbox function is closed source (a five-point minimal solver inside M-estimator sample consensus).  This
+    project's definition, stated in full: the fundamental-matrix RANSAC of estimateFundamentalMatrix (normalised
+    eight-point hypotheses, Sampson distance in pixels^2, adaptive trial budget) with those trial / distance /
+    confidence settings, then E = K' F K moved to the nearest essential matrix (singular values (1, 1, 0)).  The
+    inlier test is the toolbox's (Sampson distance against MaxDistance); the hypothesis generator is not, so the
+    inlier SETS agree with MATLAB's only in kind."""
+    K = np.asarray(K, dtype=np.float64)
+    F, inliers = estimateFundamentalMatrix(matchedPoints1, matchedPoints2, Method="RANSAC", NumTrials=MaxNumTrials,
+                                           DistanceThreshold=MaxDistance, Confidence=Confidence, samples=samples, rng=rng,
+                                           ctx=ctx)
+    U, _, Vt = np.linalg.svd(K.T @ F @ K)
+    return U @ np.diag([1.0, 1.0, 0.0]) @ Vt, inliers
+
+
 def pose_estimation_init(init_points, matched_points, K, hyper_paras, rng=None, ctx=None):
     """[T_W_C, init_points_valid, matched_points_valid] =
     pose_estimation_init(init_points, matched_points, K, hyper_paras)
@@ -67,12 +87,15 @@ def pose_estimation_init(init_points, matched_points, K, hyper_paras, rng=None, 
     side by side without conversion (:35), so the rotation block of the returned matrix is the
     toolbox orientation (R_C2_C1), not its transpose."""
     method = getattr(hyper_paras, "sfm_pose", "fundamental")
-    if method != "fundamental":
-        raise NotImplementedError("sfm_pose '%s' is not built (only 'fundamental')" % method)
     K = np.asarray(K, dtype=np.float64)
-    fRANSAC, inliers = estimateFundamentalMatrix(init_points, matched_points, Method="RANSAC", NumTrials=2000,
-                                                 DistanceThreshold=1e-2, Confidence=99.9, rng=rng, ctx=ctx)   # :7-12
-    essMat = K.T @ fRANSAC @ K                                                             # :15
+    if method == "fundamental":
+        fRANSAC, inliers = estimateFundamentalMatrix(init_points, matched_points, Method="RANSAC", NumTrials=2000,
+                                                     DistanceThreshold=1e-2, Confidence=99.9, rng=rng, ctx=ctx)   # :7-12
+        essMat = K.T @ fRANSAC @ K                                                         # :15
+    elif method == "essential":
+        essMat, inliers = estimateEssentialMatrix(init_points, matched_points, K, Confidence=99.9, rng=rng, ctx=ctx)   # :19
+    else:
+        raise NotImplementedError("sfm_pose '%s' is not built ('fundamental' and 'essential' are)" % method)
     init_points_valid = np.asarray(init_points)[inliers]                                   # :25-26
     matched_points_valid = np.asarray(matched_points)[inliers]
     R_W_C, t_W_C, _ = relativeCameraPose(essMat, K, init_points_valid, matched_points_valid, ctx=ctx)   # :29-33
