@@ -1,5 +1,5 @@
 #!/bin/bash
-# The rocprofv3 evidence of round 3 on the GPU box, one command per profile directory:
+# The rocprofv3 evidence of the bench lines on the GPU box, one command per profile directory:
 #   prof_<tag>_headline   bench.py --only-headline   (the headline loop and the replays that price its tracker launches)
 #   prof_<tag>_group16    bench.py --only-group 16   (... and a group of 16 loops in lockstep)
 # each with kernel-time statistics + trace, then HBM traffic and SQ counters in separate counter passes.
