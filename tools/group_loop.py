@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--seqs", default="1,2,4,8,16")
     ap.add_argument("--distinct", action="store_true", help="every sequence its own rendered corridor")
     ap.add_argument("--split", type=int, default=1)
+    ap.add_argument("--probe", action="store_true", help="call vohip_klt_stats after every configuration (a measuring build prints its phase clocks there)")
     args = ap.parse_args()
     import torch
     vo = importlib.import_module("visual_odometry_pipeline_amd")
@@ -74,6 +75,10 @@ def main():
                       landmarks=int(np.mean([q.num_X[-1] for g in gs for q in g.seqs])),
                       candidates=int(np.mean([q.num_C[-1] for g in gs for q in g.seqs])))
         print(S, json.dumps(out[S]), flush=True)
+        if args.probe:
+            import ctypes as C
+            tr, it = C.c_longlong(0), C.c_longlong(0)
+            vo._lib.load().vohip_klt_stats(ctx.handle, C.byref(tr), C.byref(it), 1)
         for g in gs:
             g.close()
     print(json.dumps(out))

@@ -348,11 +348,26 @@ __device__ __forceinline__ void stage_patch(const float *__restrict__ img, int A
     }
 }
 
+#ifdef KLT_PHASE_PROBE
+// (a measuring build only: shader clock ticks per phase, summed over all tracks of all launches)
+// (a track's ticks are collected in its workgroup's LDS and added to one of 256 rows at the end of the track: the probe
+// must not serialise the wavefronts it measures)
+__device__ unsigned long long g_klt_probe[256][8];
+#define KLT_PROBE_NOW() clock64()
+#define KLT_PROBE_ADD(slot, ticks) do { if (threadIdx.x == 0) s_klt_probe[slot] += (unsigned long long)(ticks); } while (0)
+#else
+#define KLT_PROBE_NOW() 0ll
+#define KLT_PROBE_ADD(slot, ticks) do { } while (0)
+#endif
+
 // Tracks (pa, pb) from pyramid P to pyramid Q.  sI / sJ: this wavefront's LDS.
 template <int W>
 __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, size_t seq_floats, int max_iter, double min_lmin, double pa,
                           double pb, double &qa, double &qb, float *sI, float *sJ, int &iters)
 {
+#ifdef KLT_PHASE_PROBE
+    unsigned long long *s_klt_probe = reinterpret_cast<unsigned long long *>(sJ + klt_cfg<W>::SJ * klt_cfg<W>::SJ + 3);
+#endif
     using C = klt_cfg<W>;
     const int lane = threadIdx.x;
     double da = 0.0, db = 0.0;
@@ -377,9 +392,13 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, size_t seq_float
         const float fa = (float)(ca - fca), fb = (float)(cb - fcb);
 
         // stage the template neighbourhood: raw pixels at offsets -(HALF+1) .. HALF+2
+        [[maybe_unused]] const long long probe0 = KLT_PROBE_NOW();
         __syncthreads();
         stage_patch<C::SI>(Pl, A, B, ia - C::HALF - 1, ib - C::HALF - 1, sI);
         __syncthreads();
+        [[maybe_unused]] const long long probe1 = KLT_PROBE_NOW();
+        [[maybe_unused]] long long probe_stage = 0;
+        KLT_PROBE_ADD(0, probe1 - probe0);
 
         float GX[C::RPL], GY[C::RPL];
         double gxx = 0.0, gxy = 0.0, gyy = 0.0;
@@ -441,6 +460,8 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, size_t seq_float
         // fused multiply-adds
         const double iaa = gyy * inv_det, iab = gxy * inv_det, ibb = gxx * inv_det;
         if (l == 0) ok0 = good;
+        [[maybe_unused]] const long long probe2 = KLT_PROBE_NOW();
+        KLT_PROBE_ADD(1, probe2 - probe1);
         if (good) {
             int cja = 0, cjb = 0;
             bool staged = false;
@@ -468,9 +489,11 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, size_t seq_float
                         cja = ja + la;
                         cjb = jb + lb;
                         staged = true;
+                        [[maybe_unused]] const long long ps = KLT_PROBE_NOW();
                         __syncthreads();
                         stage_patch<C::SJ>(Ql, A, B, cja - C::HALF - C::MARG, cjb - C::HALF - C::MARG, sJ);
                         __syncthreads();
+                        probe_stage += KLT_PROBE_NOW() - ps;
                     }
                     const float *org = sJ + __mul24(jb - cjb + C::MARG, C::SJ) + (ja - cja + C::MARG) + offJ;
                     float t1[C::RPL + 1];
@@ -516,6 +539,13 @@ __device__ bool track_dir(const pyr_desc &P, const pyr_desc &Q, size_t seq_float
                 pb_prev = sb;
             }
         }
+        {
+            [[maybe_unused]] const long long probe3 = KLT_PROBE_NOW();
+            KLT_PROBE_ADD(2, probe_stage);
+            KLT_PROBE_ADD(3, probe3 - probe2 - probe_stage);
+            KLT_PROBE_ADD(4, 1);
+            (void)probe3;
+        }
         if (l > 0) {
             da *= 2.0;
             db *= 2.0;
@@ -544,7 +574,16 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
     const size_t seq_floats = (size_t)(SQ.stride_prep * (unsigned long long)seq__) / sizeof(float);
     using C = klt_cfg<W>;
     __shared__ float sI[C::SI_ROWS * C::SI + 8];
+#ifdef KLT_PHASE_PROBE
+    __shared__ __align__(8) float sJ[C::SJ * C::SJ + 3 + 16];   // (+ the probe's five 64-bit sums behind the region)
+    {
+        unsigned long long *pr = reinterpret_cast<unsigned long long *>(sJ + C::SJ * C::SJ + 3);
+        if (threadIdx.x < 8) pr[threadIdx.x] = 0;
+        __syncthreads();
+    }
+#else
     __shared__ float sJ[C::SJ * C::SJ];
+#endif
     int i = blockIdx.x, k = 0;
     if (i >= S.s[0].n) {
         i -= S.s[0].n;
@@ -610,6 +649,12 @@ void klt_track_kernel(pyr_desc P, pyr_desc Q, klt_sets S, int swap_xy, int max_i
         out_xy[ld + o] = (swap_xy ? qa : qb) + 1.0;
         valid[o] = (ok_f && ok_b && inside && err <= max_bidir) ? 1 : 0;
         if (fb_err) fb_err[o] = err;
+#ifdef KLT_PHASE_PROBE
+        {
+            const unsigned long long *pr = reinterpret_cast<const unsigned long long *>(sJ + C::SJ * C::SJ + 3);
+            for (int q = 0; q < 5; ++q) atomicAdd(&g_klt_probe[blockIdx.x & 255][q], pr[q]);
+        }
+#endif
         if (stats) {   // work counters: tracks, Gauss-Newton iterations (both directions, all levels)
             atomicAdd(stats, 1ull);
             atomicAdd(stats + 1, (unsigned long long)iters);
@@ -867,6 +912,22 @@ int vohip_klt_stats(vohip_ctx *ctx, long long *tracks, long long *iterations, in
         }
     }
     if (std::getenv("VOHIP_KLT_CYCLES")) std::fprintf(stderr, "vohip klt: longest track %llu ticks\n", h[2]);
+#ifdef KLT_PHASE_PROBE
+    {
+        static unsigned long long rows[256][8];
+        unsigned long long pr[8] = {0};
+        (void)hipMemcpyFromSymbol(rows, HIP_SYMBOL(g_klt_probe), sizeof(rows));
+        for (int r = 0; r < 256; ++r)
+            for (int q = 0; q < 8; ++q) pr[q] += rows[r][q];
+        const double n = pr[4] ? (double)pr[4] : 1.0;
+        std::fprintf(stderr, "vohip klt probe: %llu passes; ticks per pass: template staging %.0f, template + G %.0f, "
+                     "region staging %.0f, iterations %.0f\n", pr[4], pr[0] / n, pr[1] / n, pr[2] / n, pr[3] / n);
+        if (reset) {
+            std::memset(rows, 0, sizeof(rows));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_klt_probe), rows, sizeof(rows));
+        }
+    }
+#endif
     if (tracks) *tracks = (long long)h[0];
     if (iterations) *iterations = (long long)h[1];
     return VOHIP_OK;
