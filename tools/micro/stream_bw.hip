@@ -32,6 +32,26 @@ __global__ __launch_bounds__(256) void widen_kernel(const uint16_t *src, float2 
     if (i < n) { const uint16_t v = src[i]; dst[i] = make_float2((float)(v & 0xff), (float)(v >> 8)); }
 }
 
+__global__ __launch_bounds__(256) void widen_nt_kernel(const uint16_t *src, float2 *dst, size_t n)
+{
+    typedef float pair __attribute__((ext_vector_type(2)));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const uint16_t v = src[i];
+        __builtin_nontemporal_store((pair){(float)(v & 0xff), (float)(v >> 8)}, reinterpret_cast<pair *>(dst) + i);
+    }
+}
+__global__ __launch_bounds__(256) void widen4_nt_kernel(const uint32_t *src, float4 *dst, size_t n)
+{
+    typedef float quad __attribute__((ext_vector_type(4)));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const uint32_t v = src[i];
+        __builtin_nontemporal_store((quad){(float)(v & 0xff), (float)((v >> 8) & 0xff), (float)((v >> 16) & 0xff), (float)(v >> 24)},
+                                    reinterpret_cast<quad *>(dst) + i);
+    }
+}
+
 int main()
 {
     const size_t n = (size_t)60 << 20;   // float2 elements: 480 MB written, as one batch of 256 level-0 images
@@ -52,6 +72,10 @@ int main()
     time([&] { hipLaunchKernelGGL(read_kernel, dim3(blocks), dim3(256), 0, 0, a, n, sink); }, n * 8.0, "read 8 B per lane");
     time([&] { hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, 0, a, b, n); }, n * 16.0, "copy (bytes read + written)");
     time([&] { hipLaunchKernelGGL(widen_kernel, dim3(blocks), dim3(256), 0, 0, u, b, n); }, n * 10.0, "2 B in, 8 B out per lane");
+    time([&] { hipLaunchKernelGGL(widen_nt_kernel, dim3(blocks), dim3(256), 0, 0, u, b, n); }, n * 10.0, "2 B in, 8 B out, non-temporal");
+    const unsigned blocks4 = (unsigned)((n / 2 + 255) / 256);
+    time([&] { hipLaunchKernelGGL(widen4_nt_kernel, dim3(blocks4), dim3(256), 0, 0, (const uint32_t *)u, (float4 *)b, n / 2); }, n * 10.0,
+         "4 B in, 16 B out, non-temporal");
     CK(hipDeviceSynchronize());
     return 0;
 }

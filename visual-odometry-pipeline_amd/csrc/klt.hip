@@ -137,13 +137,10 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__
 // float level -- and the 2 x 2 block of level-0 floats at (2a, 2b) lies inside that window, so the float
 // image is written here and never read back: level 0 costs its write only.  A thread makes PF_ROWS
 // vertically adjacent samples: their windows share three of five image rows, so it reads 2 PF_ROWS + 3 rows
-// of five pixels instead of 5 PF_ROWS, each row's five pixels as two aligned 32-bit loads where that is possible
-// (the byte loads, not the memory behind them, bound this kernel).
-// (blockIdx.z: image of a batch.)
-// WORDS: the two-word loads, for batches (256 pyramids 0.47 -> 0.40 ms); a single image, whose pyramid is a matter
-// of latency, is a microsecond faster with the byte loads and their fewer instructions.
+// of five pixels instead of 5 PF_ROWS.
+// This kernel serves a single image, whose pyramid is a matter of latency (byte loads row by row: the fewest
+// instructions); batches take pyr_first_pairs_kernel below.  (blockIdx.z: image of a batch.)
 constexpr int PF_ROWS = 4;
-template <bool WORDS>
 __global__ __launch_bounds__(256) void pyr_first_kernel(const uint8_t *__restrict__ src, int A, int B,
                                                         float *__restrict__ lvl0, float *__restrict__ lvl1, int A2, int B2,
                                                         size_t src_stride, size_t dst_stride)
@@ -157,79 +154,14 @@ __global__ __launch_bounds__(256) void pyr_first_kernel(const uint8_t *__restric
     const int a0 = max(2 * a - 2, 0), a1 = max(2 * a - 1, 0), a2 = 2 * a, a3 = min(2 * a + 1, A - 1),
               a4 = min(2 * a + 2, A - 1);
     const bool right = 2 * a + 1 < A;
-    const bool interior = 2 * a - 2 >= 0 && 2 * a + 2 <= A - 1;
-    const uintptr_t img_begin = (uintptr_t)src, img_end = img_begin + (size_t)A * B;
     // image rows 2 b_first - 2 .. 2 b_first + 2 PF_ROWS: the horizontal pass of each, once
     float h[2 * PF_ROWS + 3];
-    if constexpr (WORDS) {
-        // Every row's pixels as ONE 8-byte load per thread, all eleven issued before the first is used (the per-row
-        // path below waits for memory eleven times in turn, and that wait bounds it).  The window starts at pixel
-        // 2a - 2, moved inside the row at the left and right edges; the five (clamped) pixels are picked out of
-        // it by byte index, so every thread of every wavefront runs the same instructions.  A row's two level-0
-        // floats leave as one 8-byte store.  Same pixels, same taps, same order as below: the same bits.
-        if (A >= 8) {
-            struct __attribute__((packed, aligned(1))) bytes8 { uint32_t lo, hi; };
-            struct __attribute__((packed, aligned(4))) floats2 { float x, y; };
-            const int win = min(max(2 * a - 2, 0), A - 8);
-            // v_perm_b32 selector: byte k of the result = byte (pixel k's column - win) of the window (0..3: lo, 4..7: hi)
-            const uint32_t sel = (uint32_t)(a0 - win) | (uint32_t)(a1 - win) << 8 | (uint32_t)(a2 - win) << 16 | (uint32_t)(a3 - win) << 24;
-            const uint32_t sel4 = (uint32_t)(a4 - win) | 0x0c0c0c00u;   // (0x0c: a zero byte)
-            bytes8 w[2 * PF_ROWS + 3];
-#pragma unroll
-            for (int j = 0; j < 2 * PF_ROWS + 3; ++j) {
-                const int bb = min(max(2 * b_first + j - 2, 0), B - 1);
-                w[j] = *reinterpret_cast<const bytes8 *>(src + (size_t)bb * A + win);
-            }
-#pragma unroll
-            for (int j = 0; j < 2 * PF_ROWS + 3; ++j) {
-                const int y = 2 * b_first + j - 2;
-                const uint32_t q = __builtin_amdgcn_perm(w[j].hi, w[j].lo, sel);
-                const float t0 = (float)(q & 0xffu), t1 = (float)((q >> 8) & 0xffu), t2 = (float)((q >> 16) & 0xffu),
-                            t3 = (float)(q >> 24), t4 = (float)__builtin_amdgcn_perm(w[j].hi, w[j].lo, sel4);
-                h[j] = tap5(t0, t1, t2, t3, t4);
-                if (j >= 2 && j < 2 * PF_ROWS + 2 && y < B) {
-                    float *o = lvl0 + (size_t)y * A + 2 * a;
-                    if (right) {
-                        typedef float pair4 __attribute__((ext_vector_type(2), aligned(4)));
-                        __builtin_nontemporal_store((pair4){t2, t3}, reinterpret_cast<pair4 *>(o));
-                    } else {
-                        o[0] = t2;
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < PF_ROWS; ++r) {
-                const int b = b_first + r;
-                if (b < B2) lvl1[(size_t)b * A2 + a] = tap5(h[2 * r], h[2 * r + 1], h[2 * r + 2], h[2 * r + 3], h[2 * r + 4]);
-            }
-            return;
-        }
-    }
 #pragma unroll
     for (int j = 0; j < 2 * PF_ROWS + 3; ++j) {
         const int y = 2 * b_first + j - 2;
         const int bb = min(max(y, 0), B - 1);
         const uint8_t *row = src + (size_t)bb * A;
-        float t0, t1, t2, t3, t4;
-        // the five pixels 2a - 2 .. 2a + 2 lie in two aligned 32-bit words; away from the image's left and right
-        // edges, and when those two words lie inside the image's own bytes, two loads replace five
-        const uintptr_t first = (uintptr_t)(row + 2 * a - 2), word = first & ~(uintptr_t)3;
-        if (WORDS && interior && word >= img_begin && word + 8 <= img_end) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(word);
-            const uint32_t lo = q[0], hi = q[1], sh = (uint32_t)(first & 3) * 8u;
-            const uint32_t w = __builtin_amdgcn_alignbit(hi, lo, sh);
-            t0 = (float)(w & 0xffu);
-            t1 = (float)((w >> 8) & 0xffu);
-            t2 = (float)((w >> 16) & 0xffu);
-            t3 = (float)(w >> 24);
-            t4 = (float)((hi >> sh) & 0xffu);
-        } else {
-            t0 = (float)row[a0];
-            t1 = (float)row[a1];
-            t2 = (float)row[a2];
-            t3 = (float)row[a3];
-            t4 = (float)row[a4];
-        }
+        const float t0 = (float)row[a0], t1 = (float)row[a1], t2 = (float)row[a2], t3 = (float)row[a3], t4 = (float)row[a4];
         h[j] = tap5(t0, t1, t2, t3, t4);
         if (j >= 2 && j < 2 * PF_ROWS + 2 && y < B) {   // (y >= 0 here) an image row of this thread's blocks: its two pixels
             float *o = lvl0 + (size_t)y * A + 2 * a;
@@ -241,6 +173,80 @@ __global__ __launch_bounds__(256) void pyr_first_kernel(const uint8_t *__restric
     for (int r = 0; r < PF_ROWS; ++r) {
         const int b = b_first + r;
         if (b < B2) lvl1[(size_t)b * A2 + a] = tap5(h[2 * r], h[2 * r + 1], h[2 * r + 2], h[2 * r + 3], h[2 * r + 4]);
+    }
+}
+
+// The same two levels for a batch of images (A >= 8), where the bytes moved count: a thread makes the level-1
+// samples 2p and 2p + 1 of PF_ROWS rows.  Their two 5-pixel windows lie in the seven pixels 4p - 2 .. 4p + 4,
+// read as ONE 8-byte load per image row at the pixels' own address -- the window is moved inside the row at the
+// left and right edges and the seven (clamped) pixels are picked out of it by byte index (v_perm_b32), so every
+// thread runs the same instructions and all eleven loads are in flight before the first is used -- and the row's
+// four level-0 floats leave as one non-temporal 16-byte store (level 0 is 2/3 of the bytes this kernel moves and
+// is not read again before the trackers: written through the caches it held the kernel at 3.9 TB/s where the
+// same pattern reaches 7 with non-temporal 16-byte stores).  Same pixels, same taps, same order as pyr_first_kernel:
+// the same bits.  Workgroup: 64 sample pairs x 4 groups of PF_ROWS rows.
+__global__ __launch_bounds__(256) void pyr_first_pairs_kernel(const uint8_t *__restrict__ src, int A, int B,
+                                                              float *__restrict__ lvl0, float *__restrict__ lvl1, int A2,
+                                                              int B2, size_t src_stride, size_t dst_stride)
+{
+    typedef float quad __attribute__((ext_vector_type(4), aligned(4)));
+    typedef float pair __attribute__((ext_vector_type(2), aligned(4)));
+    struct __attribute__((packed, aligned(1))) bytes8 { uint32_t lo, hi; };
+    const int p = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int b_first = (blockIdx.y * 4 + (threadIdx.x >> 6)) * PF_ROWS;
+    if (2 * p >= A2 || b_first >= B2) return;
+    src += blockIdx.z * src_stride;
+    lvl0 += blockIdx.z * dst_stride;
+    lvl1 += blockIdx.z * dst_stride;
+    const int c0 = 4 * p - 2;                       // column of the first of the seven pixels
+    const int win = min(max(c0, 0), A - 8);         // first column of the 8-byte window
+    // selectors: byte k of the result = byte (column of pixel k, clamped to the row, - win) of the window
+    uint32_t sel_lo = 0, sel_hi = 0x0c000000u;      // (0x0c: a zero byte)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const uint32_t byte = (uint32_t)(min(max(c0 + k, 0), A - 1) - win);
+        if (k < 4) sel_lo |= byte << (8 * k);
+        else sel_hi |= byte << (8 * (k - 4));
+    }
+    const int n0 = min(4, A - 4 * p);               // level-0 floats of a row that exist (columns 4p .. 4p + 3)
+    const bool second = 2 * p + 1 < A2;             // the thread's second level-1 sample exists
+    bytes8 w[2 * PF_ROWS + 3];
+#pragma unroll
+    for (int j = 0; j < 2 * PF_ROWS + 3; ++j) {
+        const int bb = min(max(2 * b_first + j - 2, 0), B - 1);
+        w[j] = *reinterpret_cast<const bytes8 *>(src + (size_t)bb * A + win);
+    }
+    float hA[2 * PF_ROWS + 3], hB[2 * PF_ROWS + 3];
+#pragma unroll
+    for (int j = 0; j < 2 * PF_ROWS + 3; ++j) {
+        const int y = 2 * b_first + j - 2;
+        const uint32_t q0 = __builtin_amdgcn_perm(w[j].hi, w[j].lo, sel_lo), q1 = __builtin_amdgcn_perm(w[j].hi, w[j].lo, sel_hi);
+        const float p0 = (float)(q0 & 0xffu), p1 = (float)((q0 >> 8) & 0xffu), p2 = (float)((q0 >> 16) & 0xffu),
+                    p3 = (float)(q0 >> 24), p4 = (float)(q1 & 0xffu), p5 = (float)((q1 >> 8) & 0xffu),
+                    p6 = (float)((q1 >> 16) & 0xffu);
+        hA[j] = tap5(p0, p1, p2, p3, p4);
+        hB[j] = tap5(p2, p3, p4, p5, p6);
+        if (j >= 2 && j < 2 * PF_ROWS + 2 && y < B) {   // an image row of this thread's blocks: pixels 4p .. 4p + 3
+            float *o = lvl0 + (size_t)y * A + 4 * p;
+            if (n0 == 4) {
+                __builtin_nontemporal_store((quad){p2, p3, p4, p5}, reinterpret_cast<quad *>(o));
+            } else {
+                o[0] = p2;
+                if (n0 > 1) o[1] = p3;
+                if (n0 > 2) o[2] = p4;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < PF_ROWS; ++r) {
+        const int b = b_first + r;
+        if (b < B2) {
+            const float sA = tap5(hA[2 * r], hA[2 * r + 1], hA[2 * r + 2], hA[2 * r + 3], hA[2 * r + 4]);
+            const float sB = tap5(hB[2 * r], hB[2 * r + 1], hB[2 * r + 2], hB[2 * r + 3], hB[2 * r + 4]);
+            float *o = lvl1 + (size_t)b * A2 + 2 * p;
+            if (second) *reinterpret_cast<pair *>(o) = (pair){sA, sB};
+            else o[0] = sA;
+        }
     }
 }
 
@@ -755,7 +761,7 @@ int vohip_pyramid_build_dev(vohip_ctx *ctx, int slot, const uint8_t *d_img, int 
         hipLaunchKernelGGL(u8_to_float_kernel, dim3((n0 + 255) / 256), dim3(256), 0, ctx->stream, d_img, n0, base, (size_t)0,
                            (size_t)0);
     else   // levels 0 and 1 in one pass over the image
-        hipLaunchKernelGGL(pyr_first_kernel<false>, dim3((p.A[1] + 255) / 256, (p.B[1] + PF_ROWS - 1) / PF_ROWS), dim3(256), 0, ctx->stream, d_img,
+        hipLaunchKernelGGL(pyr_first_kernel, dim3((p.A[1] + 255) / 256, (p.B[1] + PF_ROWS - 1) / PF_ROWS), dim3(256), 0, ctx->stream, d_img,
                            p.A[0], p.B[0], base, base + p.offset[1], p.A[1], p.B[1], (size_t)0, (size_t)0);
     for (int l = 2; l < levels; ++l)
         hipLaunchKernelGGL(pyr_down_kernel<1>, dim3((p.A[l] + 63) / 64, (p.B[l] + 3) / 4), dim3(256), 0, ctx->stream,
@@ -793,8 +799,11 @@ int vohip_pyramid_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int ro
     if (levels == 1)
         hipLaunchKernelGGL(u8_to_float_kernel, dim3((n0 + 255) / 256, n), dim3(256), 0, ctx->stream, d_imgs, n0, d_pyramids,
                            (size_t)n0, total);
+    else if (A[0] >= 8)
+        hipLaunchKernelGGL(pyr_first_pairs_kernel, dim3(((A[1] + 1) / 2 + 63) / 64, (B[1] + 4 * PF_ROWS - 1) / (4 * PF_ROWS), n), dim3(256), 0,
+                           ctx->stream, d_imgs, A[0], B[0], d_pyramids, d_pyramids + off[1], A[1], B[1], (size_t)n0, total);
     else
-        hipLaunchKernelGGL(pyr_first_kernel<true>, dim3((A[1] + 255) / 256, (B[1] + PF_ROWS - 1) / PF_ROWS, n), dim3(256), 0, ctx->stream, d_imgs,
+        hipLaunchKernelGGL(pyr_first_kernel, dim3((A[1] + 255) / 256, (B[1] + PF_ROWS - 1) / PF_ROWS, n), dim3(256), 0, ctx->stream, d_imgs,
                            A[0], B[0], d_pyramids, d_pyramids + off[1], A[1], B[1], (size_t)n0, total);
     for (int l = 2; l < levels; ++l)
         hipLaunchKernelGGL(pyr_down_kernel<4>, dim3((A[l] + 63) / 64, (B[l] + 15) / 16, n), dim3(256), 0, ctx->stream,
