@@ -608,11 +608,13 @@ def traffic_from_profile(kernel, prefer=None):
     return None
 
 
-def cpu_baseline_frames(vo, scene, frames, poses, X0, xy0, budget_s=12.0):
-    """The CPU restatement of the same loop on the first frames of the same sequence."""
+def cpu_baseline_frames(vo, scene, frames, poses, X0, xy0, budget_s=12.0, threads=0):
+    """The CPU restatement of the same loop on the first frames of the same sequence.  threads: for the tracker's
+    loop over the points, the one parallel part (0: all cores)."""
     from oracle import pipeline_oracle as po
     from oracle import vo_oracle
     vo_oracle.build()
+    vo_oracle.set_threads(threads)
     hp = vo.default_hyper_paras("kitti", is_BA=False)
     hp.r_discard_redundant = KITTI_EXCLUSION_RADIUS
     pipe = po.OraclePipeline(vo.synth.K_KITTI, frames[0], X0, xy0, poses[0], hp, 3, 2, np.random.default_rng(0),
@@ -902,10 +904,14 @@ def main():
         out.update(extra)
         if not args.no_cpu_baseline and world == 1 and not quick:
             X0, xy0 = init_points(vo, ctx, scene, frames_all[0], poses_all[0])
-            v, done, dt = cpu_baseline_frames(vo, scene, frames_all, poses_all, X0, xy0)
-            out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), "kind": "port",
+            cores = int(os.environ.get("OMP_NUM_THREADS", min(os.cpu_count() or 1, 16)))
+            v, done, dt = cpu_baseline_frames(vo, scene, frames_all, poses_all, X0, xy0, threads=cores)
+            out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": cores, "kind": "port",
                                    "sample": "%d frames of the same sequence through the CPU restatement of the loop "
                                              "(OpenMP in the tracker, scalar elsewhere), %.1f s" % (done, dt)}
+            v1, done1, dt1 = cpu_baseline_frames(vo, scene, frames_all, poses_all, X0, xy0, budget_s=5.0, threads=1)
+            out["cpu_baseline"]["single_thread"] = {"value": v1, "unit": "frames/s", "cores": 1,
+                                                    "sample": "%d frames, %.1f s" % (done1, dt1)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -39,6 +39,9 @@
 #include "vo_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -225,6 +228,20 @@ static int track_one(float **P, float **Q, const int *As, const int *Bs, int lev
     *qa = pa + da;
     *qb = pb + db;
     return ok0;
+}
+
+/* Threads the tracker's loop over the points may use from now on (n < 1: as many as OpenMP finds); returns the
+ * number in force.  For the benchmark's CPU baseline, which is quoted single-threaded and on all cores. */
+int vo_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+    else omp_set_num_threads(omp_get_num_procs());
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 /* pts / out: n x 2 column-major (first n values = a coordinate, next n = b coordinate), 0-based.

@@ -111,6 +111,7 @@ void vo_candidate_triangulate(const double *cur_rc, const double *first_rc, cons
  * a = row, b = column.  Coordinates are 0-based. */
 void vo_pyr_down(const float *src, int A, int B, float *dst);
 void vo_pyramid_level(const uint8_t *img, int A, int B, int level, float *out, int *Aout, int *Bout);
+int vo_set_threads(int n);
 void vo_klt_track(const uint8_t *prev, const uint8_t *cur, int A, int B, const double *pts, int n, int W,
                   int levels, int max_iter, double max_bidir_error, double *out, uint8_t *valid,
                   double *fb_err);

@@ -245,6 +245,13 @@ def pyramid_level(img_ab, level):
     return out[:Ao.value * Bo.value].reshape(Bo.value, Ao.value).copy()
 
 
+def set_threads(n=0):
+    """Threads the tracker's loop over the points uses from now on (0: all the cores OpenMP finds); returns the number in force."""
+    f = lib().vo_set_threads
+    f.restype = C.c_int
+    return int(f(C.c_int(int(n))))
+
+
 def klt_track(prev_ab, cur_ab, pts_ab, block=21, levels=5, max_iter=20, max_bidir_error=6.0):
     """prev_ab, cur_ab uint8 (B, A); pts_ab (n, 2) 0-based (a, b) coordinates.
     Returns (out (n, 2), valid bool (n,), fb_err (n,))."""
