@@ -382,8 +382,8 @@ def bench_ransac(vo, torch, ctx, n, h, steps, warmup, seed):
 
     # The clocks need a few milliseconds of load to settle (a 2 ms burst of fp64 FMAs runs at ~50-60
     # TFLOP/s, a sustained one at ~72), so both measurements run long enough to be steady-state.
-    steps = max(steps, 200)
-    for _ in range(max(warmup, 50)):
+    steps = max(steps, 200) if h <= 4096 else steps
+    for _ in range(max(warmup, 50) if h <= 4096 else warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -816,6 +816,18 @@ def main():
             del d_many
             ba_runs = bench_ba(vo, ctx, with_cpu=not args.no_cpu_baseline and world == 1)
             hyps_per_s, score_ms = bench_ransac(vo, torch, ctx, n, h, max(args.steps, 20), args.warmup, 100)
+            # the other sizes of the micro-benchmark: correspondences x hypotheses per call, solve + score
+            sweep = {}
+            for nn in (2000, 8192):
+                for hh in (128, 1024, 4096, 65536):
+                    if (nn, hh) == (n, h):
+                        sweep["n=%d,h=%d" % (nn, hh)] = {"hypotheses_per_s": hyps_per_s, "score_kernel_ms": score_ms,
+                                                         "score_kernel_frac_fp64_valu": 116.0 * nn * hh / (score_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+                        continue
+                    hs, ms = bench_ransac(vo, torch, ctx, nn, hh, 200 if hh <= 4096 else 50, 50 if hh <= 4096 else 10, 100)
+                    sweep["n=%d,h=%d" % (nn, hh)] = {"hypotheses_per_s": hs, "score_kernel_ms": ms,
+                                                     "score_kernel_frac_fp64_valu": 116.0 * nn * hh / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
+            extra["ransac_sweep"] = sweep
             achieved = 116.0 * n * h / (score_ms * 1e-3) / 1e12
 
     if rank == 0:
