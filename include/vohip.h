@@ -607,6 +607,25 @@ int vohip_detect_fast(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, in
 int vohip_detect_fast_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, double min_contrast,
                           double min_quality, int border, float *d_xy, float *d_metric, int cap, int *d_count);
 
+/* Stands in for genKeypoints.m:1-33 with method 'SURF', the reference's default detector (dispatch table
+ * genKeypoints.m:16; main_demo.m:25; main_eval.m:151,167 pass {'MetricThreshold', 10 / 200}):
+ * detectSURFFeatures(image, 'MetricThreshold', t) with the toolbox defaults NumOctaves 3, NumScaleLevels 4.
+ * Fast-Hessian detector of Bay et al. (CVIU 2008): box-filter second derivatives of side 9 15 21 27 |
+ * 15 27 39 51 | 27 51 75 99 sampled every 1 | 2 | 4 pixels from an integral image, Metric = Dxx Dyy - 0.81 Dxy^2
+ * on the 0..255 intensity scale with every box normalised by its area, strict maxima of the 3 x 3 x 3 sample
+ * blocks of the two middle levels of every octave above MetricThreshold, refined by the quadratic through the
+ * block (dropped when an offset exceeds one sample).  Only the positions are used by the pipeline
+ * (genKeypoints.m:32 returns valid_points; the loop reads .Location); scale_out / d_scale (may be NULL)
+ * receives SURFPoints' Scale.  Points closer than `border` pixels to an edge are dropped as for the other
+ * detectors.  Output layout as vohip_detect_corners; order: octave, level, then pixel order.  At most 2^24
+ * pixels.  The batch call serves n images stored one after the other (lists of n single calls, bit for bit). */
+int vohip_detect_surf(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double metric_threshold,
+                      int border, float *xy_out, float *metric_out, float *scale_out, int cap, int *n_out);
+int vohip_detect_surf_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, double metric_threshold,
+                          int border, float *d_xy, float *d_metric, float *d_scale, int cap, int *d_count);
+int vohip_detect_surf_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                                double metric_threshold, int border, float *d_xy, float *d_metric, int cap, int *d_counts);
+
 #ifdef __cplusplus
 }
 #endif

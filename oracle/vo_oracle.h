@@ -172,6 +172,14 @@ void vo_fast_score(const uint8_t *img, int A, int B, int threshold, int *S);
 int vo_detect_fast(const uint8_t *img, int A, int B, double min_contrast, double min_quality, int border,
                    float *ab_out, float *metric_out, int cap);
 
+/* ---- surf_oracle.c --------------------------------------------------------------------- */
+
+/* This project's definition of the SURF detector that stands in for detectSURFFeatures (genKeypoints.m:16);
+ * see surf_oracle.c.  R: the response map of (octave 0..2, level 0..3), ceil(A / 2^octave) x ceil(B / 2^octave). */
+void vo_surf_response(const uint8_t *img, int A, int B, int octave, int level, float *R);
+int vo_detect_surf(const uint8_t *img, int A, int B, double metric_threshold, int border, float *ab_out,
+                   float *metric_out, float *scale_out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -322,8 +322,41 @@ def detect_fast(img_ab, min_contrast=0.2, min_quality=0.1, border=16, cap=16384)
     return np.stack([ab[:n], ab[cap:cap + n]], axis=1).copy(), metric[:n].copy(), total
 
 
+SURF_SIZES = ((9, 15, 21, 27), (15, 27, 39, 51), (27, 51, 75, 99))
+
+
+def surf_response(img_ab, octave, level):
+    """Determinant-of-Hessian map of (octave, level): float32 (ceil(B / s), ceil(A / s)), s = 2**octave."""
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    s = 1 << octave
+    R = np.zeros(((B + s - 1) // s, (A + s - 1) // s), dtype=np.float32)
+    lib().vo_surf_response(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_int(octave), C.c_int(level),
+                           R.ctypes.data_as(C.POINTER(C.c_float)))
+    return R
+
+
+def detect_surf(img_ab, metric_threshold=1000.0, border=16, cap=16384):
+    """img_ab uint8 (B, A).  Returns ab (n, 2) float32 0-based (a, b), metric (n,), scale (n,), total found."""
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    ab = np.zeros(2 * cap, dtype=np.float32)
+    metric = np.zeros(cap, dtype=np.float32)
+    scale = np.zeros(cap, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    lib().vo_detect_surf.restype = C.c_int
+    total = lib().vo_detect_surf(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_double(metric_threshold),
+                                 C.c_int(border), ab.ctypes.data_as(fp), metric.ctypes.data_as(fp),
+                                 scale.ctypes.data_as(fp), C.c_int(cap))
+    n = min(total, cap)
+    return np.stack([ab[:n], ab[cap:cap + n]], axis=1).copy(), metric[:n].copy(), scale[:n].copy(), total
+
+
 def detect(img_ab, method, options, border=16):
-    """genKeypoints.m:1-33 for the three detectors: options as the name-value dict of the reference."""
+    """genKeypoints.m:1-33 for the detectors: options as the name-value dict of the reference."""
+    if method == "SURF":
+        ab, metric, _, total = detect_surf(img_ab, options.get("MetricThreshold", 1000.0), border)
+        return ab, metric, total
     if method == "FAST":
         return detect_fast(img_ab, options.get("MinContrast", 0.2), options.get("MinQuality", 0.1), border)
     return detect_corners(img_ab, min_quality=options.get("MinQuality", 0.01), filter_size=5, border=border,

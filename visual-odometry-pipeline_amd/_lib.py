@@ -186,6 +186,12 @@ SIGNATURES = {
                                      c_float_p, c_float_p, C.c_int, c_int_p]),
     "vohip_detect_fast_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_detect_surf": (C.c_int, [C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, c_float_p,
+                                     c_float_p, c_float_p, C.c_int, c_int_p]),
+    "vohip_detect_surf_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_detect_surf_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_pyramid_build": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vohip_pyramid_build_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vohip_pyramid_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

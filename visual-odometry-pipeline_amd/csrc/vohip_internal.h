@@ -33,6 +33,7 @@ enum vohip_buf_id {
     B_IMG_STAGE,
     B_HARRIS_SCRATCH,
     B_HARRIS_BATCH,
+    B_SURF_SCRATCH, B_SURF_BATCH,
     B_FM_NRM, B_FM_F, B_FM_COUNTS, H_FM_COUNTS,
     B_BA_INDEX, B_BA_FRAME, B_BA_LM, B_BA_UV, B_BA_COUNT, B_BA_STATE, B_BA_TRIAL, B_BA_SPART, B_BA_GPART,
     B_BA_E, B_BA_GL, B_BA_W, B_BA_DP, B_BA_PART, B_BA_STATUS, H_BA_STATUS, B_BA_SRED, B_BA_GRED,
@@ -206,6 +207,14 @@ int vohip_pyramid_attach(vohip_ctx *ctx, int slot, const float *d_pyr, int rows,
 int vohip_detect_corners_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
                                        double min_quality, int filter_size, int border, int method, float *d_xy,
                                        float *d_metric, int cap, int *d_counts, double min_contrast = 0.2);
+// SURF (detector 3): scratch of a single image; detection on `st` with caller-owned scratch; a stored sequence.
+size_t vohip_surf_scratch_bytes(int rows, int cols);
+int vohip_detect_surf_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, const uint8_t *d_img, int rows, int cols,
+                              int colmajor, double metric_threshold, int border, float *d_xy, float *d_metric,
+                              float *d_scale, int cap, int *d_count);
+int vohip_detect_surf_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                                    double metric_threshold, int border, float *d_xy, float *d_metric, int cap,
+                                    int *d_counts);
 int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, const double *d_X, int n,
                               const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
                               double *d_stats, const vohip_seqs *seqs = nullptr);
