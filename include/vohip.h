@@ -230,7 +230,7 @@ typedef struct vohip_frame vohip_frame;
 typedef struct vohip_frame_params {
     int klt_block, klt_levels, klt_max_iter;   /* vision.PointTracker arguments, main_demo.m:342-343 */
     double klt_max_bidir_error;
-    int detector;                              /* 0 Harris, 1 MinEigen, 2 FAST (genKeypoints.m:16-19,31-32) */
+    int detector;                              /* 0 Harris, 1 MinEigen, 2 FAST, 3 SURF (genKeypoints.m:16-19,31-32) */
     double min_quality;
     int filter_size, border;
     double r_discard_redundant;                /* hyper_paras, main_demo.m:36-43, 72-75 */
@@ -244,6 +244,7 @@ typedef struct vohip_frame_params {
     int is_BA;                                 /* hyper_paras.is_BA: update_landmarks.m:78-88 then also asks for
                                                   reprojection errors below 100 px in both views */
     double min_contrast;                       /* detector 2: detectFASTFeatures' 'MinContrast' (main_eval.m:172-173) */
+    double metric_threshold;                   /* detector 3: detectSURFFeatures' 'MetricThreshold' (main_eval.m:151,167) */
 } vohip_frame_params;
 
 typedef struct vohip_frame_pose {
@@ -336,9 +337,10 @@ int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, doub
  * The sequences are stored ones: vohip_group_prepare copies sequence `seq`'s n images (n <= max_frames;
  * image 0 is the one the loop is reset on, main_demo.m:342-344, images 1.. are the loop's frames) to the
  * device and makes all their pyramids and corner lists by batched launches, as vohip_frame_prepare does
- * (detector < 0: the group's detector and thresholds; else 0 Harris / 1 MinEigen / 2 FAST with min_quality
- * and, for FAST, min_contrast: the feature variants of main_eval.m:165-174 may share a group, the loop only
- * reads the corner lists).
+ * (detector < 0: the group's detector and thresholds; else 0 Harris / 1 MinEigen / 2 FAST / 3 SURF with
+ * min_quality and the detector's other threshold in the last argument -- FAST's 'MinContrast', SURF's
+ * 'MetricThreshold': the feature variants of main_eval.m:165-174 may share a group, the loop only reads the
+ * corner lists).
  * vohip_group_reset gives sequence `seq` its initial state (as vohip_frame_reset; the image is prepared
  * image 0).  The first reset after a frame was processed starts a new run of the group: sequences that
  * are not reset again stay idle in it.
@@ -357,13 +359,13 @@ int vohip_group_create(vohip_ctx *ctx, const double K[9], int rows, int cols, in
                        const vohip_frame_params *params, int n_sequences, int max_frames, vohip_group **out);
 int vohip_group_destroy(vohip_group *g);
 int vohip_group_prepare(vohip_group *g, int seq, const uint8_t *const *images, int n, int on_device, int detector,
-                        double min_quality, double min_contrast);
+                        double min_quality, double min_contrast_or_metric_threshold);
 /* vohip_group_prepare for a sequence that holds the same images as the prepared sequence from_seq (the
  * repetitions and feature variants of main_eval.m:22-23 run over one image sequence): images and pyramids
  * are copied on the device instead of being uploaded and built again; detector -2 copies the corner lists
  * too, otherwise they are detected as vohip_group_prepare would. */
 int vohip_group_prepare_like(vohip_group *g, int seq, int from_seq, int detector, double min_quality,
-                             double min_contrast);
+                             double min_contrast_or_metric_threshold);
 int vohip_group_reset(vohip_group *g, int seq, const double *X, const double *ids, const double *P_rc, int n,
                       const double T_W_C[16]);
 int vohip_group_begin(vohip_group *g, const double *u3, int h, const double *u8);

@@ -256,7 +256,8 @@ def run_group(runs, ctx=None, group=None, n_slots=None, max_frames=None):
             # then the frames of :351
             group.add_sequence(s, list(r["images"][b["b2"]:]), b["p_W"], b["kp"], b["T0"], rng=r["rng"],
                                feature_extract=hp.feature_extract, min_quality=fo.get("MinQuality"),
-                               min_contrast=fo.get("MinContrast"), same_images_as=uploaded.get(key))
+                               min_contrast=fo.get("MinContrast"), same_images_as=uploaded.get(key),
+                               metric_threshold=fo.get("MetricThreshold"))
             uploaded.setdefault(key, s)
         group.run()
         loop_s = time.perf_counter() - t_ct                                 # :446
@@ -287,7 +288,8 @@ def run_group(runs, ctx=None, group=None, n_slots=None, max_frames=None):
     return outs
 
 
-EVAL_FEATURE_OPTIONS = {"Harris": ["MinQuality", 2e-4],      # main_eval.m:168-169
+EVAL_FEATURE_OPTIONS = {"SURF": ["MetricThreshold", 200],     # main_eval.m:166-167
+                        "Harris": ["MinQuality", 2e-4],      # main_eval.m:168-169
                         "MinEigen": ["MinQuality", 1e-2],    # genKeypoints.m:18 (no entry in main_eval's switch)
                         "FAST": ["MinContrast", 0.11]}       # main_eval.m:172-173
 

@@ -52,6 +52,7 @@ class VOPipelineDevice:
         prm.detector = DETECTORS[self.hp.feature_extract]
         prm.min_quality = float(fo.get("MinQuality", DEFAULT_MIN_QUALITY[self.hp.feature_extract]))
         prm.min_contrast = float(fo.get("MinContrast", 0.2))
+        prm.metric_threshold = float(fo.get("MetricThreshold", 1000.0))
         prm.filter_size = int(fo.get("FilterSize", 5))
         prm.r_discard_redundant = float(self.hp.r_discard_redundant)
         prm.angle_threshold_deg = float(self.hp.angle_threshold)
@@ -359,6 +360,7 @@ class VOGroupDevice:
         prm.detector = DETECTORS[self.hp.feature_extract]
         prm.min_quality = float(fo.get("MinQuality", DEFAULT_MIN_QUALITY[self.hp.feature_extract]))
         prm.min_contrast = float(fo.get("MinContrast", 0.2))
+        prm.metric_threshold = float(fo.get("MetricThreshold", 1000.0))
         prm.filter_size = int(fo.get("FilterSize", 5))
         prm.r_discard_redundant = float(self.hp.r_discard_redundant)
         prm.angle_threshold_deg = float(self.hp.angle_threshold)
@@ -389,10 +391,11 @@ class VOGroupDevice:
         self.host_wait_us = 0.0
 
     def add_sequence(self, seq, images, p_W_landmarks, keypoints_xy, T_init_WC, rng=None, rng_map=None,
-                     feature_extract=None, min_quality=None, min_contrast=None, same_images_as=None):
+                     feature_extract=None, min_quality=None, min_contrast=None, same_images_as=None,
+                     metric_threshold=None):
         """Sequence `seq` of the group: its stored images, the state its loop starts from (as VOPipelineDevice's
-        constructor takes it) and its generators.  feature_extract / min_quality / min_contrast: this sequence's
-        detector when it differs from the group's (the feature variants of main_eval.m:165-174).
+        constructor takes it) and its generators.  feature_extract / min_quality / min_contrast / metric_threshold:
+        this sequence's detector when it differs from the group's (the feature variants of main_eval.m:165-174).
         same_images_as: a sequence of this run of the group that was added with these very images (repetitions and
         feature variants run over one image sequence): they are copied on the GPU instead of uploaded again."""
         if self.frames:
@@ -406,6 +409,8 @@ class VOGroupDevice:
         mq = float(min_quality) if min_quality is not None else (
             DEFAULT_MIN_QUALITY[feature_extract] if feature_extract is not None else 0.0)
         mc = float(min_contrast) if min_contrast is not None else 0.2     # detectFASTFeatures' default
+        if feature_extract == "SURF":   # (the library takes the detector's one other threshold in the same argument)
+            mc = float(metric_threshold) if metric_threshold is not None else 1000.0   # detectSURFFeatures' default
         ptrs, keep, on_dev = [], [], None
         other = self.seqs[same_images_as] if same_images_as is not None else None
         if other is not None:

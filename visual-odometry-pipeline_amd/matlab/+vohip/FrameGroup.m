@@ -49,10 +49,12 @@ classdef FrameGroup < handle
                     case 'Harris',   det = 0; mq = 0.01;
                     case 'MinEigen', det = 1; mq = 0.01;
                     case 'FAST',     det = 2; mq = 0.1;
+                    case 'SURF',     det = 3; mq = 0; mc = 1000;   % (the last argument then carries MetricThreshold)
                     otherwise, error('vohip:FrameGroup', 'detector %s is not built natively', feature_extract);
                 end
                 if nargin > 7 && isfield(feature_params, 'MinQuality'), mq = feature_params.MinQuality; end
                 if nargin > 7 && isfield(feature_params, 'MinContrast'), mc = feature_params.MinContrast; end
+                if nargin > 7 && det == 3 && isfield(feature_params, 'MetricThreshold'), mc = feature_params.MetricThreshold; end
             end
             vohip_mex('group_prepare', k, images, det, mq, mc);
             vohip_mex('group_reset', k, double(X), double(P), double(T_W_C));

@@ -32,12 +32,14 @@ classdef FrameLoop < handle
             if nargin > 3 && isfield(feature_params, 'MinQuality'), p.min_quality = feature_params.MinQuality; end
             if nargin > 3 && isfield(feature_params, 'FilterSize'), p.filter_size = feature_params.FilterSize; end
             if nargin > 3 && isfield(feature_params, 'MinContrast'), p.min_contrast = feature_params.MinContrast; end
+            if nargin > 3 && isfield(feature_params, 'MetricThreshold'), p.metric_threshold = feature_params.MetricThreshold; end
             if isfield(hyper_paras, 'feature_extract')   % genKeypoints.m:17-19
                 switch hyper_paras.feature_extract
                     case 'Harris',   p.detector = 0;
                     case 'MinEigen', p.detector = 1;
                     case 'FAST',     p.detector = 2;
                         if ~isfield(p, 'min_quality'), p.min_quality = 0.1; end   % detectFASTFeatures' default
+                    case 'SURF',     p.detector = 3;                              % genKeypoints.m:16
                     otherwise, error('vohip:FrameLoop', 'detector %s is not built natively', hyper_paras.feature_extract);
                 end
             end

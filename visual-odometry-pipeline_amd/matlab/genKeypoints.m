@@ -1,13 +1,20 @@
 function [features, valid_key_points] = genKeypoints(image, method, options)
-% Drop-in for utils/genKeypoints.m for the natively built detectors ('Harris', 'MinEigen', 'FAST').
-% features is [] (the continuous-operation loop discards it); valid_key_points is a cornerPoints
-% object, so .Location / .Metric / indexing behave as before.
-opts = struct('MinQuality', 0.01, 'FilterSize', 5, 'MinContrast', 0.2);
+% Drop-in for utils/genKeypoints.m for the natively built detectors ('SURF', 'Harris', 'MinEigen', 'FAST').
+% features is [] (the continuous-operation loop discards it); valid_key_points is a cornerPoints (SURF:
+% SURFPoints) object, so .Location / .Metric / indexing behave as before.
+if nargin == 1, method = 'SURF'; end          % the reference's default
+if nargin < 3, options = {}; end
+opts = struct('MinQuality', 0.01, 'FilterSize', 5, 'MinContrast', 0.2, 'MetricThreshold', 1000);
 if strcmp(method, 'FAST'), opts.MinQuality = 0.1; end   % detectFASTFeatures' own default
 for k = 1:2:numel(options)
     opts.(options{k}) = options{k + 1};
 end
 switch method
+    case 'SURF'
+        [loc, metric, scale] = vohip_mex('detect_surf', image, opts.MetricThreshold, 16);
+        features = [];
+        valid_key_points = SURFPoints(loc, 'Metric', metric, 'Scale', scale);
+        return
     case 'Harris'
         [loc, metric] = vohip_mex('detect_corners', image, opts.MinQuality, opts.FilterSize, 16, 0);
     case 'MinEigen'

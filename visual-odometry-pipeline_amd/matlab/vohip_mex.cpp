@@ -128,6 +128,7 @@ static void frame_params_from_struct(const mxArray *st, vohip_frame_params &p)
     p.refine_pose = (int)field("refine_pose", p.refine_pose);
     p.is_BA = (int)field("is_BA", p.is_BA);
     p.min_contrast = field("min_contrast", p.min_contrast);
+    p.metric_threshold = field("metric_threshold", p.metric_threshold);
 }
 
 // info struct array (1 x n) of the 'group_step' opcode, same fields as frame_outputs'
@@ -318,6 +319,25 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         std::memcpy(mxGetSingles(plhs[1]), metric, sizeof(float) * n);
         mxFree(xy);
         mxFree(metric);
+    } else if (is("detect_surf")) {
+        // [Location, Metric, Scale] = vohip_mex('detect_surf', image uint8, metric_threshold, border)
+        if (!mxIsUint8(in[0])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
+        const int cap = 16384;
+        float *xy = scratch<float>((size_t)2 * cap), *metric = scratch<float>((size_t)cap), *scale = scratch<float>((size_t)cap);
+        int n = 0;
+        check(vohip_detect_surf(c, mxGetUint8s(in[0]), rows(in[0]), cols(in[0]), 1, mxGetScalar(in[1]), (int)mxGetScalar(in[2]),
+                                xy, metric, scale, cap, &n));
+        plhs[0] = mxCreateNumericMatrix(n, 2, mxSINGLE_CLASS, mxREAL);
+        plhs[1] = mxCreateNumericMatrix(n, 1, mxSINGLE_CLASS, mxREAL);
+        std::memcpy(mxGetSingles(plhs[0]), xy, sizeof(float) * 2 * n);   // n x 2, x column then y column
+        std::memcpy(mxGetSingles(plhs[1]), metric, sizeof(float) * n);
+        if (nlhs > 2) {
+            plhs[2] = mxCreateNumericMatrix(n, 1, mxSINGLE_CLASS, mxREAL);
+            std::memcpy(mxGetSingles(plhs[2]), scale, sizeof(float) * n);
+        }
+        mxFree(xy);
+        mxFree(metric);
+        mxFree(scale);
     } else if (is("pyramid_build")) {
         // vohip_mex('pyramid_build', slot, image uint8, levels)
         if (!mxIsUint8(in[1])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
@@ -336,7 +356,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         // vohip_mex('frame_create', K, rows, cols, params struct): the loop body of main_demo.m:377-427 as
         // one call per frame, state resident on the GPU (one loop per MATLAB session).  params fields
         // (all optional): r_discard_redundant, angle_threshold_deg, min_depth, max_depth, min_quality,
-        // filter_size, detector, min_contrast, refine_pose, is_BA.
+        // filter_size, detector, min_contrast, metric_threshold, refine_pose, is_BA.
         if (g_frame) { vohip_frame_destroy(g_frame); g_frame = nullptr; }
         vohip_frame_params p;
         vohip_frame_default_params(&p);
@@ -473,7 +493,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                                  (int)mxGetScalar(in[5]), &g_group));
     } else if (is("group_prepare")) {
         // vohip_mex('group_prepare', seq (1-based), images (cell array of uint8; the first is the image the loop is
-        // reset on, main_demo.m:342-344), detector (-1: the group's, 0 Harris, 1 MinEigen, 2 FAST), min_quality, min_contrast)
+        // reset on, main_demo.m:342-344), detector (-1: the group's, 0 Harris, 1 MinEigen, 2 FAST, 3 SURF), min_quality, min_contrast (SURF: metric_threshold))
         // vohip_mex('group_prepare', seq, from_seq (a sequence that holds the same images), detector, min_quality, min_contrast)
         if (!g_group) mexErrMsgIdAndTxt("vohip:usage", "group_create first");
         const int seq = (int)mxGetScalar(in[0]) - 1;
