@@ -73,8 +73,8 @@ def make_sequence(vo, n_frames, item=0):
     return scene, frames, poses
 
 
-def init_points(vo, ctx, scene, frame0, pose0, thin=True, min_quality=2e-4, limit=None):
-    _, kp = vo.genKeypoints(frame0, "Harris", ["MinQuality", min_quality], ctx=ctx)
+def init_points(vo, ctx, scene, frame0, pose0, thin=True, min_quality=2e-4, limit=None, feature=None):
+    _, kp = vo.genKeypoints(frame0, *(feature or ("Harris", ["MinQuality", min_quality])), ctx=ctx)
     xy = kp.Location.astype(np.float64)
     if thin:
         xy = xy[thin_by_grid(xy, kp.Metric)]
@@ -84,14 +84,15 @@ def init_points(vo, ctx, scene, frame0, pose0, thin=True, min_quality=2e-4, limi
 
 
 def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barrier, gather, resident=True, ahead=True,
-                 stress_hypotheses=0, bundle_adjust=False):
+                 stress_hypotheses=0, bundle_adjust=False, feature=None):
     """ahead: every call also hands over the following frame of the stored sequence, whose pyramid and corners
     are then prepared beside the localisation of the current one (same results; the sequence holds one frame
     more than is processed).
     stress_hypotheses > 0: the stress configuration -- every corner of the first frame starts as a landmark
     (about 6k, no thinning) and that many P3P hypotheses are solved and scored in every frame (the adaptive
     rule still picks the winner among the iterations it would have executed).
-    bundle_adjust: main_BA.m's configuration (is_BA, window of 5 keyframes, every 2nd frame a keyframe)."""
+    bundle_adjust: main_BA.m's configuration (is_BA, window of 5 keyframes, every 2nd frame a keyframe).
+    feature: (method, options) of genKeypoints.m:16-19 when not Harris with main_eval.m:169's MinQuality."""
     dev = torch.device("cuda", torch.cuda.current_device())
     if resident:
         d_frames = [torch.from_numpy(f).to(dev) for f in frames[:warmup + steps + 2]]
@@ -107,8 +108,11 @@ def bench_frames(vo, torch, ctx, scene, frames, poses, steps, warmup, seed, barr
     if stress_hypotheses:   # every corner of the frames and a narrow exclusion radius: about 12k points tracked per frame
         hp.feature_extract_options = ["MinQuality", STRESS_MIN_QUALITY]
         hp.r_discard_redundant = STRESS_EXCLUSION_RADIUS
+    if feature:
+        hp.feature_extract, hp.feature_extract_options = feature[0], list(feature[1])
     X0, xy0 = init_points(vo, ctx, scene, frames[0], poses[0], thin=not stress_hypotheses,
-                          min_quality=STRESS_MIN_QUALITY if stress_hypotheses else 2e-4, limit=STRESS_CAPACITY)
+                          min_quality=STRESS_MIN_QUALITY if stress_hypotheses else 2e-4, limit=STRESS_CAPACITY,
+                          feature=feature)
     cap = STRESS_CAPACITY if stress_hypotheses else 8192
     pipe = vo.VOPipelineDevice(vo.synth.K_KITTI, d_frames[0], X0, xy0, poses[0], hyper_paras=hp,
                                rng=np.random.default_rng(seed), ctx=ctx, cap_landmarks=cap, cap_candidates=cap,
@@ -481,8 +485,13 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
         ctx.check(lib.vohip_detect_fast_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 0.11, 0.1, 16,
                                             d_xy.data_ptr(), d_metric.data_ptr(), cap, d_count.data_ptr()))
 
+    def detect_surf():   # main_eval.m:166-167
+        ctx.check(lib.vohip_detect_surf_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 200.0, 16, d_xy.data_ptr(),
+                                            d_metric.data_ptr(), None, cap, d_count.data_ptr()))
+
     out = {}
-    for name, fn in (("pyramid_build", build), ("fast_detection", detect_fast), ("corner_detection", detect)):
+    for name, fn in (("pyramid_build", build), ("fast_detection", detect_fast), ("surf_detection", detect_surf),
+                     ("corner_detection", detect)):
         fn()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -494,6 +503,8 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
         out[name] = ev0.elapsed_time(ev1) / reps
         if name == "fast_detection":
             n_fast = min(int(d_count.item()), cap)
+        if name == "surf_detection":
+            n_surf = min(int(d_count.item()), cap)
     px = float(rows * cols)
     levels = sum(0.25 ** l for l in range(5))
     n_corners = min(int(d_count.item()), cap)
@@ -518,8 +529,12 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
         ctx.check(lib.vohip_detect_corners_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 2e-4, 5, 16, 0,
                                                      b_xy.data_ptr(), b_metric.data_ptr(), cap, b_counts.data_ptr()))
 
+    def detect_surf_batch():
+        ctx.check(lib.vohip_detect_surf_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 200.0, 16,
+                                                  b_xy.data_ptr(), b_metric.data_ptr(), cap, b_counts.data_ptr()))
+
     batched = {}
-    for name, fn in (("pyramid_build", build_batch), ("corner_detection", detect_batch)):
+    for name, fn in (("pyramid_build", build_batch), ("surf_detection", detect_surf_batch), ("corner_detection", detect_batch)):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -530,9 +545,25 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
         ev1.record()
         torch.cuda.synchronize()
         batched[name] = ev0.elapsed_time(ev1) / 5
+        if name == "surf_detection":
+            surf_b = float(torch.clamp(b_counts, max=cap).sum().item())
     corners_b = float(torch.clamp(b_counts, max=cap).sum().item())
     bytes_det_b = px * nb + 8.0 * corners_b
+    # SURF per image: the image in, the integral image (4 bytes per pixel) written by the row pass, read and
+    # written by the column pass and read by the response pass (32 lookups per response come out of L2), the 12
+    # response maps (4 (1 + 1/4 + 1/16) floats per pixel) written once and read once, 16 bytes per point out
+    maps_px = 4.0 * (1.0 + 0.25 + 0.0625)
+    bytes_surf = px * (1.0 + 4.0 * 4.0 + 2.0 * 4.0 * maps_px)
     batch_out = {"frames": nb,
+                 "surf_detection": {"ms": batched["surf_detection"], "points": surf_b,
+                                    "algorithmic_bytes": bytes_surf * nb + 16.0 * surf_b,
+                                    "achieved_gbs": (bytes_surf * nb + 16.0 * surf_b) / (batched["surf_detection"] * 1e-3) / 1e9,
+                                    "peak_gbs": 8000.0,
+                                    "frac": (bytes_surf * nb + 16.0 * surf_b) / (batched["surf_detection"] * 1e-3) / 1e9 / 8000.0,
+                                    "lookups_per_s": 32.0 * maps_px * px * nb / (batched["surf_detection"] * 1e-3),
+                                    "note": "six launches serve the batch; the response pass makes 32 four-byte lookups of the "
+                                            "integral image per response (1.9 MB per image, L2-resident), which is what it "
+                                            "is bound by"},
                  "pyramid_build": {"ms": batched["pyramid_build"], "algorithmic_bytes": bytes_pyr * nb,
                                    "achieved_gbs": bytes_pyr * nb / (batched["pyramid_build"] * 1e-3) / 1e9, "peak_gbs": 8000.0,
                                    "frac": bytes_pyr * nb / (batched["pyramid_build"] * 1e-3) / 1e9 / 8000.0,
@@ -556,6 +587,9 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
             "corner_detection": {"ms": out["corner_detection"], "corners": n_corners, "algorithmic_bytes": bytes_det,
                                  "achieved_gbs": bytes_det / (out["corner_detection"] * 1e-3) / 1e9,
                                  "peak_gbs": 8000.0},
+            "surf_detection": {"ms": out["surf_detection"], "points": n_surf, "algorithmic_bytes": bytes_surf + 16.0 * n_surf,
+                               "achieved_gbs": (bytes_surf + 16.0 * n_surf) / (out["surf_detection"] * 1e-3) / 1e9,
+                               "peak_gbs": 8000.0},
             "fast_detection": {"ms": out["fast_detection"], "corners": n_fast, "algorithmic_bytes": px + 8.0 * n_fast,
                                "achieved_gbs": (px + 8.0 * n_fast) / (out["fast_detection"] * 1e-3) / 1e9,
                                "peak_gbs": 8000.0}}
@@ -747,6 +781,16 @@ def main():
             el, _ = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync, nogather,
                                  ahead=False)
             extra["frames_per_s_without_lookahead"] = args.steps / el
+            # the headline loop with the other detectors of main_eval.m:165-174 (SURF is the reference's default,
+            # main_demo.m:25): only the detection on the side stream and the candidates it feeds differ
+            variants = {}
+            for feat in (("SURF", ["MetricThreshold", 200]), ("FAST", ["MinContrast", 0.11])):
+                el, inf = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync, nogather,
+                                       feature=feat)
+                variants[feat[0]] = {"frames_per_s": args.steps / el, "options": feat[1],
+                                     "tracked_landmarks": inf["n_landmarks"], "candidates": inf["n_candidates"],
+                                     "final_position_error_m": inf["final_position_error_m"]}
+            extra["frames_per_s_feature_variants"] = variants
             # main_BA.m's configuration on the same KITTI-shape sequence: bundle adjustment over a window of 5
             # keyframes, every 2nd frame a keyframe (runBA and the normal-frame re-refinements on the GPU, the
             # window bookkeeping on the host, one copy of the landmarks each way)

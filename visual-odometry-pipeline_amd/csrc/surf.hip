@@ -19,20 +19,27 @@
 //        position (sample + x) s, Scale = (1.2 / 9)(L_m + x_level (L_m - L_m-1)), Metric = det;
 //   output order: octave, level, b, a ascending.
 // Kernels:
-//   surf_integral_rows_kernel      one wavefront per image row: running sums along the fast axis (wavefront
-//                                  scans with a carry) into the integral image's rows (uint32, a zero first row
-//                                  and column so that box sums need no edge cases).
+//   surf_integral_rows_kernel      one wavefront per image row: running sums along the fast axis (four pixels per
+//                                  lane, a wavefront scan of the lanes' sums, a carry from one 256-pixel span to
+//                                  the next) into the integral image's rows (uint32, a zero first row and column
+//                                  so that box sums need no edge cases).
 //   surf_integral_colsum_kernel /  the slow axis in chunks of 32 rows: per-chunk column sums, then every
 //   surf_integral_colscan_kernel   chunk adds the chunks before it and runs down its own rows (all 32 loads
 //                                  of a thread in flight together); consecutive threads = consecutive columns.
 //   surf_response_kernel           all 12 (octave, level) maps in one launch, a thread per sample: 32 lookups
 //                                  of the integral image (which stays in L2: 1.9 MB for 1241 x 376), exact
 //                                  integer box sums, fp64 determinant.
-//   surf_count_kernel /            one wavefront per (octave, level, sample row) cell: tests its samples,
-//   surf_emit_kernel               counts the points; the second pass ranks every cell behind the cells
-//                                  before it and writes the points in order.  No atomics; deterministic.
+//   surf_extrema_kernel            a workgroup per tile of 64 x 4 samples of an octave: the four levels of the tile
+//                                  and a one-sample ring go to LDS once (6.3 KB), every thread tests its sample
+//                                  on both middle levels from there and refines the hits; a wavefront = one row
+//                                  of 64 samples = one (octave, level, row, span) sub-cell, whose points become
+//                                  records in sample order (ballot ranks) and whose count is added to its
+//                                  (octave, level, row) cell (integer atomics: the sums do not depend on order).
+//   surf_emit_kernel               one wavefront per sub-cell that holds points: ranks it behind the cells before
+//                                  its own and the spans before it in its cell, and writes its records there.
+//                                  Ordered and deterministic.
 // Per image: the uint8 image read once, the integral image written twice and read ~3 times, 2.45 M
-// responses (9.8 MB for 1241 x 376) written once and read ~twice.
+// responses (9.8 MB for 1241 x 376) written once and read once, 16 bytes per point written twice.
 #include "vohip_internal.h"
 
 #include <cmath>
@@ -42,6 +49,11 @@ namespace {
 constexpr int SURF_OCT = 3, SURF_LEV = 4, SURF_MAPS = SURF_OCT * SURF_LEV, SURF_MID = 2 * SURF_OCT;
 constexpr int SURF_CH = 32;   // rows of the integral image per chunk of the slow-axis pass
 constexpr int SURF_BATCH_BYTES_MAX = 1 << 30;   // scratch of one pass over a batch of images
+constexpr int SURF_SUB_CAP = 32;   // points of a span of 64 samples of one row: strict maxima are never neighbours
+
+struct surf_point {   // 16 bytes
+    float pa, pb, metric, scale;
+};
 
 struct surf_geom {
     int A, B, A1;                        // image axes; row length of the integral image
@@ -51,9 +63,11 @@ struct surf_geom {
     int tile_first[SURF_MAPS + 1];       // workgroups of the response launch before map k
     int tiles_a[SURF_OCT];
     int cell_first[SURF_MID + 1];        // cells before (octave, middle level) pair k = 2 o + (m - 1)
+    int sub_first[SURF_MID + 1];         // sub-cells (a cell's spans of 64 samples) before pair k
+    int otile_first[SURF_OCT + 1];       // workgroups of the extrema launch before octave o
     int nch;                             // chunks of the slow-axis pass
     // per image of a batch
-    size_t img_stride, t_stride, p_stride, r_stride, cell_stride;
+    size_t img_stride, t_stride, p_stride, r_stride, cell_stride, sub_stride, rec_stride;
     int xy_stride, metric_stride, count_stride;
 };
 
@@ -66,7 +80,7 @@ surf_geom make_geom(int A, int B)
     g.B = B;
     g.A1 = A + 1;
     unsigned off = 0;
-    int tiles = 0, cells = 0;
+    int tiles = 0, cells = 0, subs = 0, otiles = 0;
     for (int o = 0; o < SURF_OCT; ++o) {
         const int s = 1 << o;
         g.GA[o] = (A + s - 1) / s;
@@ -82,10 +96,16 @@ surf_geom make_geom(int A, int B)
         for (int m = 0; m < 2; ++m) {
             g.cell_first[2 * o + m] = cells;
             cells += g.GB[o];
+            g.sub_first[2 * o + m] = subs;
+            subs += g.GB[o] * g.tiles_a[o];
         }
+        g.otile_first[o] = otiles;
+        otiles += g.tiles_a[o] * ((g.GB[o] + 3) / 4);
     }
     g.tile_first[SURF_MAPS] = tiles;
     g.cell_first[SURF_MID] = cells;
+    g.sub_first[SURF_MID] = subs;
+    g.otile_first[SURF_OCT] = otiles;
     g.nch = (B + SURF_CH - 1) / SURF_CH;
     auto r256 = [](size_t v) { return (v + 255) / 256 * 256; };
     g.img_stride = (size_t)A * B;
@@ -93,35 +113,59 @@ surf_geom make_geom(int A, int B)
     g.p_stride = r256(sizeof(uint32_t) * (size_t)g.nch * A) / sizeof(uint32_t);
     g.r_stride = r256(sizeof(float) * (size_t)off) / sizeof(float);
     g.cell_stride = r256(sizeof(int) * (size_t)cells) / sizeof(int);
+    g.sub_stride = r256(sizeof(int) * (size_t)subs) / sizeof(int);
+    g.rec_stride = (size_t)subs * SURF_SUB_CAP;
     return g;
 }
 
 size_t image_scratch_bytes(const surf_geom &g)
 {
-    return sizeof(uint32_t) * (g.t_stride + g.p_stride) + sizeof(float) * g.r_stride + sizeof(int) * g.cell_stride;
+    return sizeof(uint32_t) * (g.t_stride + g.p_stride) + sizeof(float) * g.r_stride +
+           sizeof(int) * (g.cell_stride + g.sub_stride) + sizeof(surf_point) * g.rec_stride;
 }
 
+// (also clears the per-cell point counts the extrema kernel adds to)
 __global__ __launch_bounds__(256) void surf_integral_rows_kernel(const uint8_t *__restrict__ img, uint32_t *__restrict__ T,
-                                                                 surf_geom g)
+                                                                 int *__restrict__ cells, surf_geom g)
 {
     img += blockIdx.y * g.img_stride;
     T += blockIdx.y * g.t_stride;
+    cells += blockIdx.y * g.cell_stride;
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0) {
         for (int a = threadIdx.x; a < g.A1; a += 256) T[a] = 0u;
+        for (int q = threadIdx.x; q < g.cell_first[SURF_MID]; q += 256) cells[q] = 0;
+    }
     if (b >= g.B) return;
     uint32_t carry = 0u;
     uint32_t *row = T + (size_t)(b + 1) * g.A1;
+    const uint8_t *src = img + (size_t)b * g.A;
     if (lane == 0) row[0] = 0u;
-    for (int c = 0; c < g.A; c += 64) {
-        const int a = c + lane;
-        uint32_t v = a < g.A ? (uint32_t)img[(size_t)b * g.A + a] : 0u;
+    for (int c = 0; c < g.A; c += 256) {
+        const int a = c + 4 * lane;
+        uint32_t x[4];
+        if (a + 3 < g.A) {
+            uint32_t w;
+            __builtin_memcpy(&w, src + a, 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = (w >> (8 * k)) & 0xffu;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = a + k < g.A ? (uint32_t)src[a + k] : 0u;
+        }
+        x[1] += x[0];
+        x[2] += x[1];
+        x[3] += x[2];
+        uint32_t v = x[3];   // inclusive scan of the lanes' sums
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
             if (lane >= d) v += t;
         }
-        if (a < g.A) row[a + 1] = v + carry;
+        const uint32_t before = carry + (v - x[3]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (a + k < g.A) row[a + k + 1] = before + x[k];
         carry += (uint32_t)__shfl((int)v, 63, 64);
     }
 }
@@ -209,19 +253,14 @@ __global__ __launch_bounds__(256) void surf_response_kernel(const uint32_t *__re
     R[g.map_off[map] + (size_t)gb * g.GA[o] + ga] = r;
 }
 
-struct surf_point {
-    float pa, pb, metric, scale;
-};
-
-// The sample (ga, gb) of the middle level whose map is R1 (R0 below, R2 above): an interest point?
-__device__ __forceinline__ bool surf_test(const float *__restrict__ R0, const float *__restrict__ R1,
-                                          const float *__restrict__ R2, int GA, int ga, int gb, float thr, int s, int Lm,
-                                          int dL, surf_point *out)
+// The sample (ga, gb) of a middle level: an interest point?  p0, p1, p2 point at the sample in the level below, its
+// own and the level above; consecutive rows of samples lie GA floats apart.
+__device__ __forceinline__ bool surf_test(const float *p0, const float *p1, const float *p2, int GA, int ga, int gb, float thr,
+                                          int s, int Lm, int dL, surf_point *out)
 {
-    const size_t c = (size_t)gb * GA + ga;
-    const float v = R1[c];
+    const float v = p1[0];
     if (!(v > thr)) return false;
-    const float *lv[3] = {R0 + c, R1 + c, R2 + c};
+    const float *lv[3] = {p0, p1, p2};
     bool is_max = true;
 #pragma unroll
     for (int di = 0; di < 3; ++di)
@@ -263,95 +302,116 @@ __device__ __forceinline__ bool surf_test(const float *__restrict__ R0, const fl
     return true;
 }
 
-// The cell of wavefront `cell`: its maps, its row of samples and the range of samples that may hold a point.
-struct surf_cell {
-    const float *R0, *R1, *R2;
-    int GA, gb, s, Lm, dL, first, last;   // samples first..last (empty when first > last)
-};
-
-__device__ __forceinline__ surf_cell cell_of(const surf_geom &g, const float *__restrict__ R, int cell, int lo)
+// The samples of row gb of (octave o, middle level m) that may hold a point: first..last (empty when first > last).
+// Those at which the filter of level m + 1 lies inside the image, less one sample for the block; then the border.
+__device__ __forceinline__ void candidate_range(const surf_geom &g, int o, int m, int gb, int lo, int *first, int *last)
 {
-    int pair = 0;
-#pragma unroll
-    for (int k = 1; k < SURF_MID; ++k) pair += cell >= g.cell_first[k] ? 1 : 0;
-    const int o = pair >> 1, m = 1 + (pair & 1), s = 1 << o;
-    surf_cell c;
-    c.GA = g.GA[o];
-    c.gb = cell - g.cell_first[pair];
-    c.s = s;
-    c.Lm = g.L[4 * o + m];
-    c.dL = c.Lm - g.L[4 * o + m - 1];
-    c.R0 = R + g.map_off[4 * o + m - 1];
-    c.R1 = R + g.map_off[4 * o + m];
-    c.R2 = R + g.map_off[4 * o + m + 1];
-    // samples at which the filter of level m + 1 lies inside the image, less one sample for the block; then the border
-    const int htop = (g.L[4 * o + m + 1] - 1) / 2;
+    const int s = 1 << o, htop = (g.L[4 * o + m + 1] - 1) / 2;
     const int lo_g = (htop + s - 1) / s + 1;
     const int hi_a = (g.A - 1 - htop >= 0 ? (g.A - 1 - htop) / s : -1) - 1;
     const int hi_b = (g.B - 1 - htop >= 0 ? (g.B - 1 - htop) / s : -1) - 1;
-    const int b = c.gb * s;
-    const bool row_ok = c.gb >= lo_g && c.gb <= hi_b && b >= lo && b < g.B - lo;
-    c.first = max(lo_g, (lo + s - 1) / s);
-    c.last = min(hi_a, (g.A - lo - 1) / s);   // a = ga s <= A - lo - 1
-    if (!row_ok) c.last = c.first - 1;
-    return c;
+    const int b = gb * s;
+    const bool row_ok = gb >= lo_g && gb <= hi_b && b >= lo && b < g.B - lo;
+    *first = max(lo_g, (lo + s - 1) / s);
+    *last = min(hi_a, (g.A - lo - 1) / s);   // a = ga s <= A - lo - 1
+    if (!row_ok) *last = *first - 1;
 }
 
-__global__ __launch_bounds__(256) void surf_count_kernel(const float *__restrict__ R, int *__restrict__ cells, surf_geom g,
-                                                         float thr, int lo)
+constexpr int XT_A = 64, XT_B = 4, XS_A = XT_A + 2, XS_B = XT_B + 2;   // tile of samples; staged with a ring of one
+
+__global__ __launch_bounds__(256) void surf_extrema_kernel(const float *__restrict__ R, int *__restrict__ cells,
+                                                           int *__restrict__ subs, surf_point *__restrict__ recs, surf_geom g,
+                                                           float thr, int lo)
 {
     R += blockIdx.y * g.r_stride;
     cells += blockIdx.y * g.cell_stride;
-    const int lane = threadIdx.x & 63, cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cell >= g.cell_first[SURF_MID]) return;
-    const surf_cell c = cell_of(g, R, cell, lo);
-    int n = 0;
-    for (int ga0 = c.first; ga0 <= c.last; ga0 += 64) {
-        const int ga = ga0 + lane;
-        surf_point pt;
-        const bool hit = ga <= c.last && surf_test(c.R0, c.R1, c.R2, c.GA, ga, c.gb, thr, c.s, c.Lm, c.dL, &pt);
-        n += __popcll(__ballot(hit));
+    subs += blockIdx.y * g.sub_stride;
+    recs += blockIdx.y * g.rec_stride;
+    __shared__ float sR[SURF_LEV][XS_B * XS_A];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int o = 0;
+#pragma unroll
+    for (int k = 1; k < SURF_OCT; ++k) o += (int)blockIdx.x >= g.otile_first[k] ? 1 : 0;
+    const int t = (int)blockIdx.x - g.otile_first[o];
+    const int ta = t % g.tiles_a[o], tb = t / g.tiles_a[o];
+    const int ga0 = ta * XT_A, gb0 = tb * XT_B, GA = g.GA[o], GB = g.GB[o];
+    // (every load of the thread issued before the first one is waited for)
+    constexpr int N = SURF_LEV * XS_B * XS_A, ROUNDS = (N + 255) / 256;
+    float v[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int q = tid + 256 * k;
+        const int lev = q / (XS_B * XS_A), r = q - lev * (XS_B * XS_A);
+        const int rb = r / XS_A, ra = r - rb * XS_A;
+        const int ga = ga0 - 1 + ra, gb = gb0 - 1 + rb;
+        v[k] = q < N && ga >= 0 && ga < GA && gb >= 0 && gb < GB ? R[g.map_off[4 * o + lev] + (size_t)gb * GA + ga] : 0.0f;
     }
-    if (lane == 0) cells[cell] = n;
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) {
+        const int q = tid + 256 * k;
+        if (q < N) (&sR[0][0])[q] = v[k];
+    }
+    __syncthreads();
+    const int ga = ga0 + lane, gb = gb0 + wave;
+    if (gb >= GB) return;   // (a whole wavefront)
+    const int c = (wave + 1) * XS_A + (lane + 1);
+#pragma unroll
+    for (int m = 1; m <= 2; ++m) {
+        int first, last;
+        candidate_range(g, o, m, gb, lo, &first, &last);
+        surf_point pt;
+        const bool hit = ga >= first && ga <= last &&
+                         surf_test(&sR[m - 1][c], &sR[m][c], &sR[m + 1][c], XS_A, ga, gb, thr, 1 << o, g.L[4 * o + m],
+                                   g.L[4 * o + m] - g.L[4 * o + m - 1], &pt);
+        const unsigned long long bal = __ballot(hit);
+        const int n = __popcll(bal), pair = 2 * o + (m - 1);
+        const int sub = g.sub_first[pair] + gb * g.tiles_a[o] + ta;
+        if (hit) recs[(size_t)sub * SURF_SUB_CAP + __popcll(bal & ((1ull << lane) - 1ull))] = pt;
+        if (lane == 0) {
+            subs[sub] = n;
+            if (n) atomicAdd(&cells[g.cell_first[pair] + gb], n);
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void surf_emit_kernel(const float *__restrict__ R, const int *__restrict__ cells, surf_geom g,
-                                                        float thr, int lo, int cap, int swap_xy, float *__restrict__ xy_out,
-                                                        float *__restrict__ metric_out, float *__restrict__ scale_out,
-                                                        int *__restrict__ count)
+// One wavefront per sub-cell, in the order of the output: (octave, level) pair, row of samples, span.
+__global__ __launch_bounds__(256) void surf_emit_kernel(const int *__restrict__ cells, const int *__restrict__ subs,
+                                                        const surf_point *__restrict__ recs, surf_geom g, int cap, int swap_xy,
+                                                        float *__restrict__ xy_out, float *__restrict__ metric_out,
+                                                        float *__restrict__ scale_out, int *__restrict__ count)
 {
-    R += blockIdx.y * g.r_stride;
     cells += blockIdx.y * g.cell_stride;
+    subs += blockIdx.y * g.sub_stride;
+    recs += blockIdx.y * g.rec_stride;
     xy_out += blockIdx.y * (size_t)g.xy_stride;
     metric_out += blockIdx.y * (size_t)g.metric_stride;
     if (scale_out) scale_out += blockIdx.y * (size_t)g.metric_stride;
     count += blockIdx.y * (size_t)g.count_stride;
-    const int lane = threadIdx.x & 63, cell = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int ncells = g.cell_first[SURF_MID];
-    if (cell >= ncells) return;
-    int base = 0;   // points in the cells before this one
+    const int lane = threadIdx.x & 63, sub = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nsubs = g.sub_first[SURF_MID];
+    if (sub >= nsubs) return;
+    const int n = subs[sub];
+    if (n == 0 && sub != nsubs - 1) return;
+    int pair = 0;
+#pragma unroll
+    for (int k = 1; k < SURF_MID; ++k) pair += sub >= g.sub_first[k] ? 1 : 0;
+    const int o = pair >> 1, spans = g.tiles_a[o];
+    const int row = (sub - g.sub_first[pair]) / spans, span = (sub - g.sub_first[pair]) - row * spans;
+    const int cell = g.cell_first[pair] + row;
+    int base = 0;   // points in the cells before this one and in the spans of this cell before this one
     for (int q = lane; q < cell; q += 64) base += cells[q];
+    for (int q = lane; q < span; q += 64) base += subs[sub - span + q];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) base += __shfl_xor(base, m, 64);
-    const int mine = cells[cell];
-    if (cell == ncells - 1 && lane == 0) *count = base + mine;
-    if (mine == 0) return;
-    const surf_cell c = cell_of(g, R, cell, lo);
-    int run = 0;
-    for (int ga0 = c.first; ga0 <= c.last; ga0 += 64) {
-        const int ga = ga0 + lane;
-        surf_point pt;
-        const bool hit = ga <= c.last && surf_test(c.R0, c.R1, c.R2, c.GA, ga, c.gb, thr, c.s, c.Lm, c.dL, &pt);
-        const unsigned long long bal = __ballot(hit);
-        const int pos = base + run + __popcll(bal & ((1ull << lane) - 1ull));
-        run += __popcll(bal);
-        if (hit && pos < cap) {
-            const float pa = pt.pa + 1.0f, pb = pt.pb + 1.0f;
-            xy_out[pos] = swap_xy ? pb : pa;
-            xy_out[cap + pos] = swap_xy ? pa : pb;
-            metric_out[pos] = pt.metric;
-            if (scale_out) scale_out[pos] = pt.scale;
-        }
+    if (sub == nsubs - 1 && lane == 0) *count = base + n;   // (the last sub-cell is the last span of the last cell)
+    const int pos = base + lane;
+    if (lane < n && pos < cap) {
+        const surf_point pt = recs[(size_t)sub * SURF_SUB_CAP + lane];
+        const float pa = pt.pa + 1.0f, pb = pt.pb + 1.0f;
+        xy_out[pos] = swap_xy ? pb : pa;
+        xy_out[cap + pos] = swap_xy ? pa : pb;
+        metric_out[pos] = pt.metric;
+        if (scale_out) scale_out[pos] = pt.scale;
     }
 }
 
@@ -380,20 +440,24 @@ int enqueue_images(vohip_ctx *ctx, hipStream_t st, void *scratch, surf_geom g, c
     float *R = (float *)p;
     p += sizeof(float) * g.r_stride * n;
     int *cells = (int *)p;
+    p += sizeof(int) * g.cell_stride * n;
+    int *subs = (int *)p;
+    p += sizeof(int) * g.sub_stride * n;
+    surf_point *recs = (surf_point *)p;
     g.xy_stride = 2 * cap;
     g.metric_stride = cap;
     g.count_stride = 1;
-    const int lo = border < 1 ? 1 : border, ncells = g.cell_first[SURF_MID];
-    hipLaunchKernelGGL(surf_integral_rows_kernel, dim3((g.B + 3) / 4, n), dim3(256), 0, st, d_imgs, T, g);
+    const int lo = border < 1 ? 1 : border, nsubs = g.sub_first[SURF_MID];
+    hipLaunchKernelGGL(surf_integral_rows_kernel, dim3((g.B + 3) / 4, n), dim3(256), 0, st, d_imgs, T, cells, g);
     const dim3 cgrid((g.A + 63) / 64, (g.nch + 3) / 4, n);
     hipLaunchKernelGGL(surf_integral_colsum_kernel, cgrid, dim3(64, 4), 0, st, (const uint32_t *)T, P, g);
     hipLaunchKernelGGL(surf_integral_colscan_kernel, cgrid, dim3(64, 4), 0, st, T, (const uint32_t *)P, g);
     hipLaunchKernelGGL(surf_response_kernel, dim3(g.tile_first[SURF_MAPS], n), dim3(256), 0, st, (const uint32_t *)T, R, g,
                        make_norms(g));
-    hipLaunchKernelGGL(surf_count_kernel, dim3((ncells + 3) / 4, n), dim3(256), 0, st, (const float *)R, cells, g,
-                       (float)metric_threshold, lo);
-    hipLaunchKernelGGL(surf_emit_kernel, dim3((ncells + 3) / 4, n), dim3(256), 0, st, (const float *)R, (const int *)cells, g,
-                       (float)metric_threshold, lo, cap, colmajor ? 1 : 0, d_xy, d_metric, d_scale, d_counts);
+    hipLaunchKernelGGL(surf_extrema_kernel, dim3(g.otile_first[SURF_OCT], n), dim3(256), 0, st, (const float *)R, cells, subs,
+                       recs, g, (float)metric_threshold, lo);
+    hipLaunchKernelGGL(surf_emit_kernel, dim3((nsubs + 3) / 4, n), dim3(256), 0, st, (const int *)cells, (const int *)subs,
+                       (const surf_point *)recs, g, cap, colmajor ? 1 : 0, d_xy, d_metric, d_scale, d_counts);
     VOHIP_HIP(ctx, hipGetLastError());
     return VOHIP_OK;
 }
