@@ -26,9 +26,11 @@
 //   surf_integral_colsum_kernel /  the slow axis in chunks of 32 rows: per-chunk column sums, then every
 //   surf_integral_colscan_kernel   chunk adds the chunks before it and runs down its own rows (all 32 loads
 //                                  of a thread in flight together); consecutive threads = consecutive columns.
-//   surf_response_kernel           all 12 (octave, level) maps in one launch, a thread per sample: 32 lookups
-//                                  of the integral image (which stays in L2: 1.9 MB for 1241 x 376), exact
-//                                  integer box sums, fp64 determinant.
+//   surf_response_kernel           all 12 (octave, level) maps in one launch: 32 lookups of the integral image
+//                                  per response (exact integer box sums, fp64 determinant).  Octave 0 from an
+//                                  LDS tile of the integral image (64 x 8 samples, four levels, 12.7 KB), octaves
+//                                  1 and 2 a thread per sample through the caches (the integral image stays in L2:
+//                                  1.9 MB for 1241 x 376).
 //   surf_extrema_kernel            a workgroup per tile of 64 x 4 samples of an octave: the four levels of the tile
 //                                  and a one-sample ring go to LDS once (6.3 KB), every thread tests its sample
 //                                  on both middle levels from there and refines the hits; a wavefront = one row
@@ -65,6 +67,7 @@ struct surf_geom {
     int cell_first[SURF_MID + 1];        // cells before (octave, middle level) pair k = 2 o + (m - 1)
     int sub_first[SURF_MID + 1];         // sub-cells (a cell's spans of 64 samples) before pair k
     int otile_first[SURF_OCT + 1];       // workgroups of the extrema launch before octave o
+    int resp0_tiles;                     // workgroups of the response launch that make octave 0 (64 x 8 samples, all levels)
     int nch;                             // chunks of the slow-axis pass
     // per image of a batch
     size_t img_stride, t_stride, p_stride, r_stride, cell_stride, sub_stride, rec_stride;
@@ -106,6 +109,7 @@ surf_geom make_geom(int A, int B)
     g.cell_first[SURF_MID] = cells;
     g.sub_first[SURF_MID] = subs;
     g.otile_first[SURF_OCT] = otiles;
+    g.resp0_tiles = g.tiles_a[0] * ((B + 7) / 8);
     g.nch = (B + SURF_CH - 1) / SURF_CH;
     auto r256 = [](size_t v) { return (v + 255) / 256 * 256; };
     g.img_stride = (size_t)A * B;
@@ -223,32 +227,90 @@ struct surf_norms {
     double inv_lobe[SURF_MAPS], inv_sq[SURF_MAPS];   // 1 / (l (2l - 1)), 1 / l^2, divided on the host
 };
 
+// The determinant of one sample from box sums: `sum(a0, b0, a1, b1)` = the image summed over [a0, a1) x [b0, b1).
+template <class BOX>
+__device__ __forceinline__ float surf_det(BOX sum, int a, int b, int L, double inv_lobe, double inv_sq)
+{
+    const int l = L / 3, h = (L - 1) / 2;
+    const int nxx = sum(a - h, b - l + 1, a + h + 1, b + l) - 3 * sum(a - h + l, b - l + 1, a - h + 2 * l, b + l);
+    const int nyy = sum(a - l + 1, b - h, a + l, b + h + 1) - 3 * sum(a - l + 1, b - h + l, a + l, b - h + 2 * l);
+    const int nxy = sum(a - l, b - l, a, b) + sum(a + 1, b + 1, a + 1 + l, b + 1 + l) - sum(a + 1, b - l, a + 1 + l, b) -
+                    sum(a - l, b + 1, a, b + 1 + l);
+    const double dxx = (double)nxx * inv_lobe, dyy = (double)nyy * inv_lobe, dxy = (double)nxy * inv_sq;
+    const double t1 = dxx * dyy, t2 = dxy * dxy, t3 = 0.81 * t2;
+    return (float)(t1 - t3);
+}
+
+// Octave 0 (three quarters of all responses) from LDS: a workgroup stages the integral image under a tile of
+// 64 x 8 pixels and the reach of the largest filter of the octave (13 before, 14 after: 91 x 35 words, 12.7 KB) once
+// and makes the four levels of its 512 samples from there (128 LDS lookups per thread and row instead of 128
+// cache lookups; consecutive lanes read consecutive words).  The other two octaves, whose filters reach up to 50
+// pixels, read the integral image through the caches.
+constexpr int RT_A = 64, RT_B = 8, RT_H = 13, RS_A = RT_A + 2 * RT_H + 1, RS_B = RT_B + 2 * RT_H + 1;
+
 __global__ __launch_bounds__(256) void surf_response_kernel(const uint32_t *__restrict__ T, float *__restrict__ R, surf_geom g,
                                                             surf_norms nm)
 {
     T += blockIdx.y * g.t_stride;
     R += blockIdx.y * g.r_stride;
-    int map = 0;
+    const int A1 = g.A1;
+    if ((int)blockIdx.x < g.resp0_tiles) {
+        static_assert(SIZES[0][SURF_LEV - 1] == 2 * RT_H + 1, "the staged reach is that of octave 0's largest filter");
+        __shared__ uint32_t sT[RS_B * RS_A];
+        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+        const int a0 = ((int)blockIdx.x % g.tiles_a[0]) * RT_A, b0 = ((int)blockIdx.x / g.tiles_a[0]) * RT_B;
+        constexpr int N = RS_A * RS_B, ROUNDS = (N + 255) / 256;
+        uint32_t v[ROUNDS];   // (all loads of the thread in flight together)
 #pragma unroll
-    for (int k = 1; k < SURF_MAPS; ++k) map += (int)blockIdx.x >= g.tile_first[k] ? 1 : 0;
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int q = min(tid + 256 * k, N - 1);
+            const int rb = q / RS_A, ra = q - rb * RS_A;
+            // (entries outside the integral image are only reached from samples whose filter does not fit)
+            const int ia = min(max(a0 - RT_H + ra, 0), g.A), ib = min(max(b0 - RT_H + rb, 0), g.B);
+            v[k] = T[(size_t)ib * A1 + ia];
+        }
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int q = tid + 256 * k;
+            if (q < N) sT[q] = v[k];
+        }
+        __syncthreads();
+        const int a = a0 + lane;
+        if (a >= g.A) return;
+        auto sum = [&](int x0, int y0, int x1, int y1) {
+            const int r0 = (y0 - (b0 - RT_H)) * RS_A - (a0 - RT_H), r1 = (y1 - (b0 - RT_H)) * RS_A - (a0 - RT_H);
+            return (int)((sT[r1 + x1] - sT[r0 + x1]) - (sT[r1 + x0] - sT[r0 + x0]));
+        };
+#pragma unroll
+        for (int half = 0; half < RT_B / 4; ++half) {
+            const int b = b0 + wave + 4 * half;
+            if (b >= g.B) break;
+#pragma unroll
+            for (int i = 0; i < SURF_LEV; ++i) {
+                constexpr int Ls[SURF_LEV] = {SIZES[0][0], SIZES[0][1], SIZES[0][2], SIZES[0][3]};
+                const int h = (Ls[i] - 1) / 2;
+                float r = 0.0f;
+                if (a - h >= 0 && a + h <= g.A - 1 && b - h >= 0 && b + h <= g.B - 1)
+                    r = surf_det(sum, a, b, Ls[i], nm.inv_lobe[i], nm.inv_sq[i]);
+                R[g.map_off[i] + (size_t)b * g.A + a] = r;
+            }
+        }
+        return;
+    }
+    const int bx = (int)blockIdx.x - g.resp0_tiles + g.tile_first[SURF_LEV];
+    int map = SURF_LEV;
+#pragma unroll
+    for (int k = SURF_LEV + 1; k < SURF_MAPS; ++k) map += bx >= g.tile_first[k] ? 1 : 0;
     const int o = map >> 2, s = 1 << o;
-    const int t = (int)blockIdx.x - g.tile_first[map];
+    const int t = bx - g.tile_first[map];
     const int ga = (t % g.tiles_a[o]) * 64 + (threadIdx.x & 63), gb = (t / g.tiles_a[o]) * 4 + (threadIdx.x >> 6);
     if (ga >= g.GA[o] || gb >= g.GB[o]) return;
-    const int L = g.L[map], l = L / 3, h = (L - 1) / 2;
-    const int a = ga * s, b = gb * s, A1 = g.A1;
+    const int L = g.L[map], h = (L - 1) / 2;
+    const int a = ga * s, b = gb * s;
     float r = 0.0f;
     if (a - h >= 0 && a + h <= g.A - 1 && b - h >= 0 && b + h <= g.B - 1) {
-        const int nxx = box_sum(T, A1, a - h, b - l + 1, a + h + 1, b + l) -
-                        3 * box_sum(T, A1, a - h + l, b - l + 1, a - h + 2 * l, b + l);
-        const int nyy = box_sum(T, A1, a - l + 1, b - h, a + l, b + h + 1) -
-                        3 * box_sum(T, A1, a - l + 1, b - h + l, a + l, b - h + 2 * l);
-        const int nxy = box_sum(T, A1, a - l, b - l, a, b) + box_sum(T, A1, a + 1, b + 1, a + 1 + l, b + 1 + l) -
-                        box_sum(T, A1, a + 1, b - l, a + 1 + l, b) - box_sum(T, A1, a - l, b + 1, a, b + 1 + l);
-        const double dxx = (double)nxx * nm.inv_lobe[map], dyy = (double)nyy * nm.inv_lobe[map];
-        const double dxy = (double)nxy * nm.inv_sq[map];
-        const double t1 = dxx * dyy, t2 = dxy * dxy, t3 = 0.81 * t2;
-        r = (float)(t1 - t3);
+        auto sum = [&](int x0, int y0, int x1, int y1) { return box_sum(T, A1, x0, y0, x1, y1); };
+        r = surf_det(sum, a, b, L, nm.inv_lobe[map], nm.inv_sq[map]);
     }
     R[g.map_off[map] + (size_t)gb * g.GA[o] + ga] = r;
 }
@@ -452,8 +514,8 @@ int enqueue_images(vohip_ctx *ctx, hipStream_t st, void *scratch, surf_geom g, c
     const dim3 cgrid((g.A + 63) / 64, (g.nch + 3) / 4, n);
     hipLaunchKernelGGL(surf_integral_colsum_kernel, cgrid, dim3(64, 4), 0, st, (const uint32_t *)T, P, g);
     hipLaunchKernelGGL(surf_integral_colscan_kernel, cgrid, dim3(64, 4), 0, st, T, (const uint32_t *)P, g);
-    hipLaunchKernelGGL(surf_response_kernel, dim3(g.tile_first[SURF_MAPS], n), dim3(256), 0, st, (const uint32_t *)T, R, g,
-                       make_norms(g));
+    hipLaunchKernelGGL(surf_response_kernel, dim3(g.resp0_tiles + g.tile_first[SURF_MAPS] - g.tile_first[SURF_LEV], n),
+                       dim3(256), 0, st, (const uint32_t *)T, R, g, make_norms(g));
     hipLaunchKernelGGL(surf_extrema_kernel, dim3(g.otile_first[SURF_OCT], n), dim3(256), 0, st, (const float *)R, cells, subs,
                        recs, g, (float)metric_threshold, lo);
     hipLaunchKernelGGL(surf_emit_kernel, dim3((nsubs + 3) / 4, n), dim3(256), 0, st, (const int *)cells, (const int *)subs,
