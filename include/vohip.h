@@ -628,6 +628,36 @@ int vohip_detect_surf_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int co
 int vohip_detect_surf_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
                                 double metric_threshold, int border, float *d_xy, float *d_metric, int cap, int *d_counts);
 
+/* Stands in for extractFeatures(image, SURFPoints) as genKeypoints.m:32 calls it (64-element SURF descriptors,
+ * 'Upright' false), the features the 'Des_match' bootstrap branch matches (matching_init.m:26-29).  A closed toolbox
+ * function; built as section 4 of Bay et al. describes it: the dominant direction of the Haar-wavelet responses
+ * (side 4 s) at the 109 sample points within 6 s of the point, Gaussian-weighted (sigma 2 s), taken from 42 sliding
+ * windows of pi/3; then a square of side 20 s turned to that direction, 4 x 4 subregions of 5 x 5 samples each,
+ * Haar responses of side 2 s weighted by a Gaussian (sigma 3.3 s) about the point, (sum dx, sum dy, sum |dx|,
+ * sum |dy|) per subregion, the 64 numbers normalised to unit length.  s = Scale; sample positions and sizes rounded
+ * to pixels; boxes clipped to the image, so every point gets a descriptor (no point is dropped).
+ * xy: n x 2 (x column then y column, leading dimension n / ld), 1-based as SURFPoints.Location; scale: n
+ * (SURFPoints.Scale); features: n x 64 with a point's 64 numbers contiguous (the transpose of MATLAB's N x 64 array
+ * in memory); orientation (may be NULL): n angles in radians, atan2 of the dominant direction in image coordinates
+ * (x right, y down).  upright != 0 skips the direction.  At most 2^24 pixels. */
+int vohip_extract_surf_features(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, const float *xy,
+                                const float *scale, int n, int upright, float *features_out, float *orientation_out);
+int vohip_extract_surf_features_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, const float *d_xy,
+                                    int ld, const float *d_scale, int n, int upright, float *d_features,
+                                    float *d_orientation);
+
+/* Stands in for indexPairs = matchFeatures(features1, features2) with the toolbox defaults for non-binary features
+ * (matching_init.m:29: 'Exhaustive', metric SSD, 'MatchThreshold' 1.0 percent, 'MaxRatio' 0.6, 'Unique' false): for
+ * every feature of the first set its nearest neighbour in the second by sum of squared differences (the lowest index
+ * of equals); the pair is kept when that distance is at most match_threshold percent of 4, the largest distance
+ * between unit vectors, and at most max_ratio^2 times the second nearest distance (the ratio test on Euclidean
+ * distances).  f0: n0 x dim, f1: n1 x dim, a feature's numbers contiguous.  pairs: up to n0 rows (i, j), 0-based,
+ * in the order of i; metric: their distances; *n_pairs_out / *d_count: how many. */
+int vohip_match_features(vohip_ctx *ctx, const float *f0, int n0, const float *f1, int n1, int dim, double match_threshold,
+                         double max_ratio, int *pairs_out, float *metric_out, int *n_pairs_out);
+int vohip_match_features_dev(vohip_ctx *ctx, const float *d_f0, int n0, const float *d_f1, int n1, int dim,
+                             double match_threshold, double max_ratio, int *d_pairs, float *d_metric, int *d_count);
+
 #ifdef __cplusplus
 }
 #endif

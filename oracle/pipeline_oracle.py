@@ -228,11 +228,21 @@ class OraclePipeline:
 # ---- bootstrap (main_demo.m:252-264) --------------------------------------------------------------
 
 def matching_init(img0, img_seqs, hp):
-    """Initialization/matching_init.m:1-45, 'KLT' branch: detect in img0, track through every
+    """Initialization/matching_init.m:1-45.  'KLT' branch: detect in img0, track through every
     image of img_seqs with a 31x31 / 5-level / 30-iteration tracker, forward-backward bound 3 px;
-    a point lost in an intermediate image stays lost."""
+    a point lost in an intermediate image stays lost.  'Des_match' branch: SURF points and descriptors of
+    the first and the last image, matched with matchFeatures' defaults."""
     img0 = np.ascontiguousarray(img0)
     opts = dict(zip(hp.feature_extract_options[::2], hp.feature_extract_options[1::2]))
+    if getattr(hp, "init_matching_method", "KLT") == "Des_match":                          # :25-32 (SURF points only)
+        img1 = np.ascontiguousarray(img_seqs[-1])
+        sets = []
+        for im in (img0, img1):
+            ab, _, scale, _ = orc.detect_surf(im, opts.get("MetricThreshold", 1000.0), 16)
+            loc = ab + np.float32(1.0)
+            sets.append((loc, orc.surf_descriptors(im, loc, scale)[0]))
+        pairs, _ = orc.match_features(sets[0][1], sets[1][1])
+        return sets[0][0][pairs[:, 0]], sets[1][0][pairs[:, 1]]
     ab, _, _ = orc.detect(img0, hp.feature_extract, opts)                                  # :12
     init_points_ = ab + np.float32(1.0)                                                    # :13 (single)
     pts = init_points_.astype(np.float64)

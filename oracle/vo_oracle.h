@@ -179,6 +179,12 @@ int vo_detect_fast(const uint8_t *img, int A, int B, double min_contrast, double
 void vo_surf_response(const uint8_t *img, int A, int B, int octave, int level, float *R);
 int vo_detect_surf(const uint8_t *img, int A, int B, double metric_threshold, int border, float *ab_out,
                    float *metric_out, float *scale_out, int cap);
+/* This project's definitions of the SURF descriptor (extractFeatures on SURFPoints, genKeypoints.m:32) and of
+ * matchFeatures with its defaults (matching_init.m:29); see surf_oracle.c. */
+void vo_surf_descriptors(const uint8_t *img, int A, int B, int swap_xy, const float *xy, const float *scale, int n,
+                         int upright, float *features, float *orientation);
+int vo_match_features(const float *f0, int n0, const float *f1, int n1, int dim, double match_threshold, double max_ratio,
+                      int *pairs, float *metric);
 
 #ifdef __cplusplus
 }

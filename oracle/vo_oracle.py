@@ -352,6 +352,42 @@ def detect_surf(img_ab, metric_threshold=1000.0, border=16, cap=16384):
     return np.stack([ab[:n], ab[cap:cap + n]], axis=1).copy(), metric[:n].copy(), scale[:n].copy(), total
 
 
+def surf_descriptors(img, xy1, scale, upright=False):
+    """img uint8 (rows, cols) in either storage order; xy1 (n, 2) 1-based (x, y) float32 (SURFPoints.Location); scale (n,).
+    Returns features (n, 64) float32 and orientation (n,) float32."""
+    img = np.asarray(img)
+    swap = bool(img.flags.f_contiguous and not img.flags.c_contiguous)
+    store = np.ascontiguousarray(img.T) if swap else np.ascontiguousarray(img)
+    B, A = store.shape
+    xy1 = np.asarray(xy1, dtype=np.float32).reshape(-1, 2)
+    n = xy1.shape[0]
+    cols = np.ascontiguousarray(np.concatenate([xy1[:, 0], xy1[:, 1]]), dtype=np.float32)
+    sc = np.ascontiguousarray(scale, dtype=np.float32)
+    feats = np.zeros((n, 64), dtype=np.float32)
+    ori = np.zeros(n, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    lib().vo_surf_descriptors(store.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_int(int(swap)), cols.ctypes.data_as(fp),
+                              sc.ctypes.data_as(fp), C.c_int(n), C.c_int(int(upright)), feats.ctypes.data_as(fp),
+                              ori.ctypes.data_as(fp))
+    return feats, ori
+
+
+def match_features(f0, f1, match_threshold=1.0, max_ratio=0.6):
+    """matchFeatures(f0, f1) with the toolbox defaults.  Returns index pairs (m, 2) 0-based and their distances."""
+    f0 = np.ascontiguousarray(f0, dtype=np.float32)
+    f1 = np.ascontiguousarray(f1, dtype=np.float32)
+    n0, dim = f0.shape
+    n1 = f1.shape[0]
+    pairs = np.zeros((max(n0, 1), 2), dtype=np.int32)
+    metric = np.zeros(max(n0, 1), dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    lib().vo_match_features.restype = C.c_int
+    m = lib().vo_match_features(f0.ctypes.data_as(fp), C.c_int(n0), f1.ctypes.data_as(fp), C.c_int(n1), C.c_int(dim),
+                                C.c_double(match_threshold), C.c_double(max_ratio),
+                                pairs.ctypes.data_as(C.POINTER(C.c_int)), metric.ctypes.data_as(fp))
+    return pairs[:m].copy(), metric[:m].copy()
+
+
 def detect(img_ab, method, options, border=16):
     """genKeypoints.m:1-33 for the detectors: options as the name-value dict of the reference."""
     if method == "SURF":

@@ -192,6 +192,14 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_detect_surf_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                                C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_extract_surf_features": (C.c_int, [C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int,
+                                               C.c_int, c_float_p, c_float_p]),
+    "vohip_extract_surf_features_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vohip_match_features": (C.c_int, [C.c_void_p, c_float_p, C.c_int, c_float_p, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        c_int_p, c_float_p, c_int_p]),
+    "vohip_match_features_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                            C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vohip_pyramid_build": (C.c_int, [C.c_void_p, C.c_int, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vohip_pyramid_build_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "vohip_pyramid_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's bootstrap (main_demo.m:252-264):
 
-  matching_init          Initialization/matching_init.m:1-45        ('KLT' branch)
-  pose_estimation_init   Initialization/pose_estimation_init.m:1-37 ('fundamental' branch)
+  matching_init          Initialization/matching_init.m:1-45        ('KLT' and 'Des_match' branches)
+  pose_estimation_init   Initialization/pose_estimation_init.m:1-37 ('fundamental' and 'essential' branches)
   triangulation_init     Initialization/triangulation_init.m:1-34
   compProjMat            Initialization/compProjMat.m:1-6
   relativeCameraPose     the toolbox call at pose_estimation_init.m:29-33
@@ -19,7 +19,7 @@ from ._lib import colmajor, dptr
 from .ba import T_refinement
 from .fmatrix import estimateFundamentalMatrix
 from .geometry import linearTriangulation
-from .keypoints import genKeypoints
+from .keypoints import genKeypoints, matchFeatures
 from .klt import PointTracker
 
 
@@ -44,9 +44,16 @@ def relativeCameraPose(E, K, inlierPoints1, inlierPoints2, ctx=None):
 def matching_init(img0, img_seqs, hyper_paras, ctx=None):
     """[init_points, matched_points] = matching_init(img0, img_seqs, hyper_paras)"""
     method = getattr(hyper_paras, "init_matching_method", "KLT")
-    if method != "KLT":
-        raise NotImplementedError("init_matching_method '%s' is not built (only 'KLT')" % method)
     img1 = img_seqs[-1]
+    if method == "Des_match":                                                              # :25-32
+        feat0, valid0 = genKeypoints(img0, hyper_paras.feature_extract, hyper_paras.feature_extract_options, ctx=ctx,
+                                     with_features=True)
+        feat1, valid1 = genKeypoints(img1, hyper_paras.feature_extract, hyper_paras.feature_extract_options, ctx=ctx,
+                                     with_features=True)
+        indexPairs, _ = matchFeatures(feat0, feat1, ctx=ctx)
+        return valid0.Location[indexPairs[:, 0]], valid1.Location[indexPairs[:, 1]]
+    if method != "KLT":
+        raise NotImplementedError("init_matching_method '%s' is not built ('KLT' and 'Des_match' are)" % method)
     tracker = PointTracker(NumPyramidLevels=5, MaxBidirectionalError=3, ctx=ctx)          # :8-10
     _, valid_key_candidates0 = genKeypoints(img0, hyper_paras.feature_extract, hyper_paras.feature_extract_options,
                                             ctx=ctx)                                       # :12

@@ -641,3 +641,381 @@ int vohip_detect_surf(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, in
 }
 
 }  // extern "C"
+
+// ---- SURF descriptors and their matching ----------------------------------------------------------------
+//
+// Stand-ins for extractFeatures(I, SURFPoints) (genKeypoints.m:32) and matchFeatures(feat0, feat1) with its
+// defaults (matching_init.m:26-29, the 'Des_match' bootstrap branch); closed toolbox functions, defined here
+// after section 4 of Bay et al.  The image is addressed as (x, y) whatever its storage; box sums are clipped
+// to the image;
+//   haarX(x, y, z) = sum over [x, x + z/2) x [y - z/2, y - z/2 + z) - sum over [x - z/2, x) x (same rows),
+//   haarY the same with the axes exchanged;  S = round(Scale), (X, Y) = (round(x), round(y)).
+//   Orientation: the 109 offsets (i, j), i^2 + j^2 < 36: r = exp(-(i^2 + j^2)/8) (haarX, haarY)(X + i S, Y + j S, 4 S);
+//     42 windows between the directions 0.15 k and 0.15 k + pi/3 sum the r inside them (two cross products
+//     >= 0); the window with the largest squared sum (the first of equals) gives (co, si) = sum / |sum|.
+//   Descriptor: samples (i, j), i, j = -10..9, at ((i + .5) Scale, (j + .5) Scale) in the rotated frame, rounded
+//     to pixels; (haarX, haarY)(., ., 2 S) weighted by exp(-((i + .5)^2 + (j + .5)^2) / (2 3.3^2)) and rotated
+//     back; each of the 4 x 4 subregions of 5 x 5 samples sums dx, dy, |dx|, |dy|; the 64 numbers divided by their
+//     Euclidean norm.  fp64 in a fixed order (sums in sample order), stored as fp32; every transcendental comes
+//     from tables the host makes, so the kernel's decisions (which window, which pixel) are those of a CPU
+//     statement of the same rule, bit for bit.
+//   Matching: d(i, j) = sum_k (f0[i][k] - f1[j][k])^2 in fp32, k ascending; for every i the nearest j (the
+//     lowest of equals) and the second nearest distance; kept when d1 <= 4 MatchThreshold / 100 and
+//     d1 <= MaxRatio^2 d2 (the ratio test on Euclidean distances); pairs in the order of i.
+// Kernels: surf_descriptor_kernel, a wavefront per point (109 + 400 Haar responses through LDS, the windows and
+// the subregions one lane each); match_nearest_kernel, a wavefront per feature of the first set (lanes stride
+// over the second set, two-smallest merge by shuffles); match_compact_kernel, one workgroup, ordered.
+namespace {
+
+struct surf_tables {
+    double w_ori[36];        // exp(-r2 / 8), r2 = i^2 + j^2
+    double w_desc[100];      // exp(-((i + .5)^2 + (j + .5)^2) / (2 3.3^2)), index 10 |i + .5| + |j + .5| (floors)
+    double win[4][42];       // window k: first edge (cos, sin), second edge (cos, sin)
+    int off_i[112], off_j[112];   // the 109 offsets, j outer, i inner
+};
+
+const surf_tables &host_tables()
+{
+    static surf_tables t;
+    static bool made = false;
+    if (!made) {
+        for (int r2 = 0; r2 < 36; ++r2) t.w_ori[r2] = std::exp(-(double)r2 / 8.0);
+        for (int i = 0; i < 10; ++i)
+            for (int j = 0; j < 10; ++j)
+                t.w_desc[10 * i + j] = std::exp(-((i + 0.5) * (i + 0.5) + (j + 0.5) * (j + 0.5)) / (2.0 * 3.3 * 3.3));
+        for (int k = 0; k < 42; ++k) {
+            t.win[0][k] = std::cos(0.15 * k);
+            t.win[1][k] = std::sin(0.15 * k);
+            t.win[2][k] = std::cos(0.15 * k + 3.14159265358979323846 / 3.0);
+            t.win[3][k] = std::sin(0.15 * k + 3.14159265358979323846 / 3.0);
+        }
+        int m = 0;
+        for (int j = -6; j <= 6; ++j)
+            for (int i = -6; i <= 6; ++i)
+                if (i * i + j * j < 36) {
+                    t.off_i[m] = i;
+                    t.off_j[m] = j;
+                    ++m;
+                }
+        made = true;
+    }
+    return t;
+}
+
+#pragma clang fp contract(off)
+
+struct px_image {   // the integral image addressed as (x, y)
+    const uint32_t *T;
+    int A1, W, H, swap;
+    __device__ __forceinline__ int box(int x0, int y0, int x1, int y1) const
+    {
+        x0 = max(x0, 0);
+        y0 = max(y0, 0);
+        x1 = min(x1, W);
+        y1 = min(y1, H);
+        if (x1 <= x0 || y1 <= y0) return 0;
+        return swap ? box_sum(T, A1, y0, x0, y1, x1) : box_sum(T, A1, x0, y0, x1, y1);
+    }
+    __device__ __forceinline__ double haar_x(int x, int y, int z) const
+    {
+        return (double)(box(x, y - z / 2, x + z / 2, y - z / 2 + z) - box(x - z / 2, y - z / 2, x, y - z / 2 + z));
+    }
+    __device__ __forceinline__ double haar_y(int x, int y, int z) const
+    {
+        return (double)(box(x - z / 2, y, x - z / 2 + z, y + z / 2) - box(x - z / 2, y - z / 2, x - z / 2 + z, y));
+    }
+};
+
+constexpr int DESC_WAVES = 4;
+
+// xy: x column then y column (leading dimension ld), 1-based as the toolbox objects hold them
+__global__ __launch_bounds__(64 * DESC_WAVES) void surf_descriptor_kernel(px_image im, const surf_tables *__restrict__ tab,
+                                                                          const float *__restrict__ xy, int ld,
+                                                                          const float *__restrict__ scale, int n, int upright,
+                                                                          float *__restrict__ features,
+                                                                          float *__restrict__ orientation)
+{
+    __shared__ double sX[DESC_WAVES][400], sY[DESC_WAVES][400];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = min((int)blockIdx.x * DESC_WAVES + wave, n - 1);   // (a spare wavefront repeats the last point)
+    double *rx = sX[wave], *ry = sY[wave];
+    const double x = (double)xy[p] - 1.0, y = (double)xy[ld + p] - 1.0, sc = (double)scale[p];
+    const int S = (int)floor(sc + 0.5), X = (int)floor(x + 0.5), Y = (int)floor(y + 0.5);
+    double co = 1.0, si = 0.0;
+    if (!upright) {
+        for (int m = lane; m < 109; m += 64) {
+            const int i = tab->off_i[m], j = tab->off_j[m];
+            const double w = tab->w_ori[i * i + j * j];
+            rx[m] = w * im.haar_x(X + i * S, Y + j * S, 4 * S);
+            ry[m] = w * im.haar_y(X + i * S, Y + j * S, 4 * S);
+        }
+        __syncthreads();
+        double nn = -1.0, sx = 0.0, sy = 0.0;
+        if (lane < 42) {
+            const double wu = tab->win[0][lane], wv = tab->win[1][lane], eu = tab->win[2][lane], ev = tab->win[3][lane];
+            for (int q = 0; q < 109; ++q) {
+                const double c1 = wu * ry[q] - wv * rx[q], c2 = rx[q] * ev - ry[q] * eu;
+                if (c1 >= 0.0 && c2 >= 0.0) {
+                    sx += rx[q];
+                    sy += ry[q];
+                }
+            }
+            nn = sx * sx + sy * sy;
+        }
+        int k = lane;   // the largest squared sum, the first window of equals
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double n2 = __shfl_xor(nn, m, 64), x2 = __shfl_xor(sx, m, 64), y2 = __shfl_xor(sy, m, 64);
+            const int k2 = __shfl_xor(k, m, 64);
+            if (n2 > nn || (n2 == nn && k2 < k)) {
+                nn = n2;
+                sx = x2;
+                sy = y2;
+                k = k2;
+            }
+        }
+        if (nn > 0.0) {
+            const double nrm = sqrt(nn);
+            co = sx / nrm;
+            si = sy / nrm;
+        }
+        __syncthreads();   // (the responses are dead: their memory is used again below)
+    }
+    for (int t = lane; t < 400; t += 64) {
+        const int j = t / 20 - 10, i = t - (t / 20) * 20 - 10;
+        const double u = ((double)i + 0.5) * sc, v = ((double)j + 0.5) * sc;
+        const int xs = (int)floor((x + (co * u - si * v)) + 0.5), ys = (int)floor((y + (si * u + co * v)) + 0.5);
+        const int ai = i >= 0 ? i : -1 - i, aj = j >= 0 ? j : -1 - j;   // floor(|i + .5|)
+        const double w = tab->w_desc[10 * ai + aj];
+        const double hx = w * im.haar_x(xs, ys, 2 * S), hy = w * im.haar_y(xs, ys, 2 * S);
+        rx[t] = co * hx + si * hy;
+        ry[t] = co * hy - si * hx;
+    }
+    __syncthreads();
+    double c[4] = {0.0, 0.0, 0.0, 0.0};
+    if (lane < 16) {
+        const int q = lane >> 2, pp = lane & 3;
+        for (int jj = 0; jj < 5; ++jj)
+            for (int ii = 0; ii < 5; ++ii) {
+                const int t = (5 * q + jj) * 20 + (5 * pp + ii);
+                const double dx = rx[t], dy = ry[t];
+                c[0] += dx;
+                c[1] += dy;
+                c[2] += fabs(dx);
+                c[3] += fabs(dy);
+            }
+    }
+    __syncthreads();
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rx[4 * lane + k] = c[k];
+    }
+    __syncthreads();
+    double ss = 0.0;
+    for (int k = 0; k < 64; ++k) ss += rx[k] * rx[k];
+    const double nrm = sqrt(ss);
+    if ((int)blockIdx.x * DESC_WAVES + wave < n) {
+        features[(size_t)p * 64 + lane] = (float)(nrm > 0.0 ? rx[lane] / nrm : 0.0);
+        if (orientation && lane == 0) orientation[p] = (float)atan2(si, co);
+    }
+}
+
+// Nearest and second nearest feature of the second set for feature i of the first: one wavefront per i.
+__global__ __launch_bounds__(256) void match_nearest_kernel(const float *__restrict__ f0, int n0, const float *__restrict__ f1,
+                                                            int n1, int dim, float thr, float r2, int *__restrict__ match_j,
+                                                            float *__restrict__ match_d)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n0) return;
+    const float *a = f0 + (size_t)i * dim;
+    float d1 = INFINITY, d2 = INFINITY;
+    int j1 = 0x7fffffff;
+    for (int j = lane; j < n1; j += 64) {
+        const float *b = f1 + (size_t)j * dim;
+        float d = 0.0f;
+        for (int k = 0; k < dim; ++k) {
+            const float e = a[k] - b[k];
+            d += e * e;
+        }
+        if (d < d1) {   // (a lane sees its j in ascending order: the first of equals stays)
+            d2 = d1;
+            d1 = d;
+            j1 = j;
+        } else if (d < d2) {
+            d2 = d;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float e1 = __shfl_xor(d1, m, 64), e2 = __shfl_xor(d2, m, 64);
+        const int k1 = __shfl_xor(j1, m, 64);
+        // the two smallest of {d1, d2, e1, e2}; of equal nearest distances the lower index
+        const bool theirs = e1 < d1 || (e1 == d1 && k1 < j1);
+        const float lo = theirs ? e1 : d1, other = theirs ? d1 : e1, second = theirs ? e2 : d2;
+        j1 = theirs ? k1 : j1;
+        d1 = lo;
+        d2 = fminf(other, second);
+    }
+    if (lane == 0) {
+        bool keep = j1 != 0x7fffffff && d1 <= thr;
+        if (keep && n1 > 1) keep = d1 <= r2 * d2;
+        match_j[i] = keep ? j1 : -1;
+        match_d[i] = d1;
+    }
+}
+
+// The kept pairs in the order of i: one workgroup of 1024 threads walks the first set in spans of 1024.
+__global__ __launch_bounds__(1024) void match_compact_kernel(const int *__restrict__ match_j, const float *__restrict__ match_d,
+                                                             int n0, int *__restrict__ pairs, float *__restrict__ metric,
+                                                             int *__restrict__ count)
+{
+    __shared__ int sWave[16];
+    __shared__ int sBase;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sBase = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n0; i0 += 1024) {
+        const int i = i0 + tid;
+        const int j = i < n0 ? match_j[i] : -1;
+        const unsigned long long bal = __ballot(j >= 0);
+        if (lane == 0) sWave[wave] = __popcll(bal);
+        __syncthreads();
+        int before = sBase;
+        for (int w = 0; w < wave; ++w) before += sWave[w];
+        if (j >= 0) {
+            const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+            pairs[2 * pos] = i;
+            pairs[2 * pos + 1] = j;
+            metric[pos] = match_d[i];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int total = 0;
+            for (int w = 0; w < 16; ++w) total += sWave[w];
+            sBase += total;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *count = sBase;
+}
+
+#pragma clang fp contract(fast)
+
+int features_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, const float *d_xy, int ld,
+                 const float *d_scale, int n, int upright, float *d_features, float *d_orientation)
+{
+    VOHIP_REQUIRE(ctx, d_img && d_xy && d_scale && d_features, "NULL argument");
+    VOHIP_REQUIRE(ctx, n >= 1 && ld >= n, "n >= 1 points, ld >= n");
+    VOHIP_TRY(check_args(ctx, rows, cols, 0.0, 0, 1));
+    const surf_geom g = make_geom(colmajor ? rows : cols, colmajor ? cols : rows);
+    vohip_buf &b = ctx->bufs[B_SURF_SCRATCH];
+    VOHIP_TRY(vohip_reserve(ctx, b, vohip_surf_scratch_bytes(rows, cols)));
+    void *d_tab;
+    VOHIP_TRY(vohip_upload(ctx, B_SURF_TABLES, &host_tables(), sizeof(surf_tables), &d_tab));
+    hipStream_t st = ctx->stream;
+    char *p = (char *)b.ptr;
+    uint32_t *T = (uint32_t *)p;
+    p += sizeof(uint32_t) * g.t_stride;
+    uint32_t *P = (uint32_t *)p;
+    p += sizeof(uint32_t) * g.p_stride + sizeof(float) * g.r_stride;
+    int *cells = (int *)p;
+    hipLaunchKernelGGL(surf_integral_rows_kernel, dim3((g.B + 3) / 4, 1), dim3(256), 0, st, d_img, T, cells, g);
+    const dim3 cgrid((g.A + 63) / 64, (g.nch + 3) / 4, 1);
+    hipLaunchKernelGGL(surf_integral_colsum_kernel, cgrid, dim3(64, 4), 0, st, (const uint32_t *)T, P, g);
+    hipLaunchKernelGGL(surf_integral_colscan_kernel, cgrid, dim3(64, 4), 0, st, T, (const uint32_t *)P, g);
+    px_image im;
+    im.T = T;
+    im.A1 = g.A1;
+    im.W = cols;
+    im.H = rows;
+    im.swap = colmajor ? 1 : 0;
+    hipLaunchKernelGGL(surf_descriptor_kernel, dim3((n + DESC_WAVES - 1) / DESC_WAVES), dim3(64 * DESC_WAVES), 0, st, im,
+                       (const surf_tables *)d_tab, d_xy, ld, d_scale, n, upright ? 1 : 0, d_features, d_orientation);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+int match_dev(vohip_ctx *ctx, const float *d_f0, int n0, const float *d_f1, int n1, int dim, double match_threshold,
+              double max_ratio, int *d_pairs, float *d_metric, int *d_count)
+{
+    VOHIP_REQUIRE(ctx, d_f0 && d_f1 && d_pairs && d_metric && d_count, "NULL argument");
+    VOHIP_REQUIRE(ctx, n0 >= 1 && n1 >= 1 && dim >= 1, "empty feature set");
+    VOHIP_REQUIRE(ctx, match_threshold > 0.0 && match_threshold <= 100.0, "MatchThreshold must lie in (0, 100]");
+    VOHIP_REQUIRE(ctx, max_ratio > 0.0 && max_ratio <= 1.0, "MaxRatio must lie in (0, 1]");
+    vohip_buf &b = ctx->bufs[B_SURF_MATCH];
+    VOHIP_TRY(vohip_reserve(ctx, b, (sizeof(int) + sizeof(float)) * (size_t)n0));
+    int *match_j = (int *)b.ptr;
+    float *match_d = (float *)(match_j + n0);
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(match_nearest_kernel, dim3((n0 + 3) / 4), dim3(256), 0, st, d_f0, n0, d_f1, n1, dim,
+                       (float)(4.0 * match_threshold / 100.0), (float)(max_ratio * max_ratio), match_j, match_d);
+    hipLaunchKernelGGL(match_compact_kernel, dim3(1), dim3(1024), 0, st, (const int *)match_j, (const float *)match_d, n0,
+                       d_pairs, d_metric, d_count);
+    VOHIP_HIP(ctx, hipGetLastError());
+    return VOHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vohip_extract_surf_features_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, const float *d_xy,
+                                    int ld, const float *d_scale, int n, int upright, float *d_features,
+                                    float *d_orientation)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    return features_dev(ctx, d_img, rows, cols, colmajor, d_xy, ld, d_scale, n, upright, d_features, d_orientation);
+}
+
+int vohip_extract_surf_features(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, const float *xy,
+                                const float *scale, int n, int upright, float *features_out, float *orientation_out)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, img && xy && scale && features_out, "NULL argument");
+    VOHIP_REQUIRE(ctx, rows >= 1 && cols >= 1 && n >= 1, "bad size");
+    void *d_img, *d_xy, *d_scale, *d_feat, *d_ori;
+    VOHIP_TRY(vohip_upload(ctx, B_IMG_STAGE, img, (size_t)rows * cols, &d_img));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE0, xy, sizeof(float) * 2 * (size_t)n, &d_xy));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE1, scale, sizeof(float) * (size_t)n, &d_scale));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE2, nullptr, sizeof(float) * 64 * (size_t)n, &d_feat));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE3, nullptr, sizeof(float) * (size_t)n, &d_ori));
+    VOHIP_TRY(features_dev(ctx, (const uint8_t *)d_img, rows, cols, colmajor, (const float *)d_xy, n, (const float *)d_scale, n,
+                           upright, (float *)d_feat, (float *)d_ori));
+    VOHIP_TRY(vohip_download(ctx, features_out, d_feat, sizeof(float) * 64 * (size_t)n));
+    if (orientation_out) VOHIP_TRY(vohip_download(ctx, orientation_out, d_ori, sizeof(float) * (size_t)n));
+    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VOHIP_OK;
+}
+
+int vohip_match_features_dev(vohip_ctx *ctx, const float *d_f0, int n0, const float *d_f1, int n1, int dim,
+                             double match_threshold, double max_ratio, int *d_pairs, float *d_metric, int *d_count)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    return match_dev(ctx, d_f0, n0, d_f1, n1, dim, match_threshold, max_ratio, d_pairs, d_metric, d_count);
+}
+
+int vohip_match_features(vohip_ctx *ctx, const float *f0, int n0, const float *f1, int n1, int dim, double match_threshold,
+                         double max_ratio, int *pairs_out, float *metric_out, int *n_pairs_out)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, f0 && f1 && pairs_out && metric_out && n_pairs_out, "NULL argument");
+    VOHIP_REQUIRE(ctx, n0 >= 1 && n1 >= 1 && dim >= 1, "empty feature set");
+    void *d_f0, *d_f1, *d_pairs, *d_metric, *d_count;
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE0, f0, sizeof(float) * (size_t)n0 * dim, &d_f0));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE1, f1, sizeof(float) * (size_t)n1 * dim, &d_f1));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE2, nullptr, sizeof(int) * 2 * (size_t)n0, &d_pairs));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE3, nullptr, sizeof(float) * (size_t)n0, &d_metric));
+    VOHIP_TRY(vohip_upload(ctx, B_STAGE4, nullptr, 256, &d_count));
+    VOHIP_TRY(match_dev(ctx, (const float *)d_f0, n0, (const float *)d_f1, n1, dim, match_threshold, max_ratio, (int *)d_pairs,
+                        (float *)d_metric, (int *)d_count));
+    int m = 0;
+    VOHIP_TRY(vohip_download(ctx, &m, d_count, sizeof(int)));
+    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VOHIP_TRY(vohip_download(ctx, pairs_out, d_pairs, sizeof(int) * 2 * (size_t)m));
+    VOHIP_TRY(vohip_download(ctx, metric_out, d_metric, sizeof(float) * (size_t)m));
+    VOHIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_pairs_out = m;
+    return VOHIP_OK;
+}
+
+}  // extern "C"

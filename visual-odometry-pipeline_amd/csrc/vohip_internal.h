@@ -33,7 +33,7 @@ enum vohip_buf_id {
     B_IMG_STAGE,
     B_HARRIS_SCRATCH,
     B_HARRIS_BATCH,
-    B_SURF_SCRATCH, B_SURF_BATCH,
+    B_SURF_SCRATCH, B_SURF_BATCH, B_SURF_TABLES, B_SURF_MATCH,
     B_FM_NRM, B_FM_F, B_FM_COUNTS, H_FM_COUNTS,
     B_BA_INDEX, B_BA_FRAME, B_BA_LM, B_BA_UV, B_BA_COUNT, B_BA_STATE, B_BA_TRIAL, B_BA_SPART, B_BA_GPART,
     B_BA_E, B_BA_GL, B_BA_W, B_BA_DP, B_BA_PART, B_BA_STATUS, H_BA_STATUS, B_BA_SRED, B_BA_GRED,

@@ -83,14 +83,75 @@ def _detect_device_image(ctx, image, min_quality, filter_size, border, method, c
     return cornerPoints(loc, metric[:total].cpu().numpy())
 
 
-def genKeypoints(image, method="SURF", options=None, ctx=None):
+def _host_image(image):
+    """A uint8 image as (array in its own storage order, colmajor flag); device images are copied to the host."""
+    if hasattr(image, "data_ptr"):
+        image = image.cpu().numpy()
+    img = np.asarray(image)
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise TypeError("image must be a 2-D uint8 array")
+    colmajor = bool(img.flags.f_contiguous and not img.flags.c_contiguous)
+    if not (img.flags.c_contiguous or img.flags.f_contiguous):
+        img = np.ascontiguousarray(img)
+    return img, colmajor
+
+
+def extractFeatures(image, points, Upright=False, ctx=None):
+    """[features, validPoints] = extractFeatures(I, points) for SURFPoints (genKeypoints.m:32): N x 64 single SURF
+    descriptors; validPoints are the points themselves with their Orientation filled in (boxes are clipped to the
+    image, no point is dropped).  Other point types would get the toolbox's binary FREAK descriptors, which are
+    not built: NotImplementedError."""
+    if not isinstance(points, SURFPoints):
+        raise NotImplementedError("extractFeatures is built for SURFPoints only (FREAK descriptors of corner points are not)")
+    ctx = ctx or _lib.default_context()
+    n = points.Count
+    if n == 0:
+        return np.zeros((0, 64), dtype=np.float32), points
+    img, colmajor = _host_image(image)
+    loc = np.ascontiguousarray(points.Location, dtype=np.float32)
+    xy = np.ascontiguousarray(np.concatenate([loc[:, 0], loc[:, 1]]))
+    scale = np.ascontiguousarray(points.Scale, dtype=np.float32)
+    feats = np.zeros((n, 64), dtype=np.float32)
+    ori = np.zeros(n, dtype=np.float32)
+    ctx.check(_lib.load().vohip_extract_surf_features(
+        ctx.handle, img.ctypes.data_as(_lib.c_uint8_p), img.shape[0], img.shape[1], int(colmajor),
+        xy.ctypes.data_as(_lib.c_float_p), scale.ctypes.data_as(_lib.c_float_p), n, int(bool(Upright)),
+        feats.ctypes.data_as(_lib.c_float_p), ori.ctypes.data_as(_lib.c_float_p)))
+    valid = SURFPoints(points.Location, points.Metric, points.Scale)
+    valid.Orientation = ori
+    return feats, valid
+
+
+def matchFeatures(features1, features2, MatchThreshold=1.0, MaxRatio=0.6, ctx=None):
+    """indexPairs = matchFeatures(features1, features2) (matching_init.m:29) with the toolbox defaults for non-binary
+    features: P x 2 index pairs, 0-BASED here (MATLAB's are 1-based), in the order of features1.  A second output,
+    the pairs' distances, as matchFeatures' matchmetric."""
+    ctx = ctx or _lib.default_context()
+    f1 = np.ascontiguousarray(features1, dtype=np.float32)
+    f2 = np.ascontiguousarray(features2, dtype=np.float32)
+    if f1.ndim != 2 or f2.ndim != 2 or f1.shape[1] != f2.shape[1]:
+        raise ValueError("feature sets must be N1 x D and N2 x D")
+    if f1.shape[0] == 0 or f2.shape[0] == 0:
+        return np.zeros((0, 2), dtype=np.int32), np.zeros(0, dtype=np.float32)
+    pairs = np.zeros((f1.shape[0], 2), dtype=np.int32)
+    metric = np.zeros(f1.shape[0], dtype=np.float32)
+    m = C.c_int(0)
+    ctx.check(_lib.load().vohip_match_features(
+        ctx.handle, f1.ctypes.data_as(_lib.c_float_p), f1.shape[0], f2.ctypes.data_as(_lib.c_float_p), f2.shape[0],
+        f1.shape[1], float(MatchThreshold), float(MaxRatio), pairs.ctypes.data_as(_lib.c_int_p),
+        metric.ctypes.data_as(_lib.c_float_p), C.byref(m)))
+    return pairs[:m.value].copy(), metric[:m.value].copy()
+
+
+def genKeypoints(image, method="SURF", options=None, ctx=None, with_features=False):
     """[features, valid_key_points] = genKeypoints(image, method, options)
 
     method 'SURF' (the default, as in genKeypoints.m:3-5) with options {'MetricThreshold', t}
     (main_eval.m:151,167), 'Harris' or 'MinEigen' with {'MinQuality', q, 'FilterSize', 5}, or 'FAST' with
     {'MinContrast', c, 'MinQuality', q} (main_eval.m:172-173).  Two extra options have no MATLAB
-    counterpart: 'Border' (default 16) and 'Capacity'.  `features` is None: the
-    continuous-operation loop never reads it (main_demo.m:377 discards it).  The other detectors
+    counterpart: 'Border' (default 16) and 'Capacity'.  `features` is None (the continuous-operation loop never
+    reads it, main_demo.m:377 discards it) unless with_features is set, as the 'Des_match' bootstrap branch does
+    (matching_init.m:26-27): then the SURF descriptors of extractFeatures (SURF points only).  The other detectors
     of the reference's table (BRISK, ORB, SIFT) are closed-source toolbox functions
     that are not rebuilt here."""
     if method not in DETECTORS:
@@ -106,6 +167,9 @@ def genKeypoints(image, method="SURF", options=None, ctx=None):
     cap = int(opts.pop("Capacity", DEFAULT_CAPACITY))
     if opts:
         raise ValueError("unknown option(s): %s" % ", ".join(opts))
+    if with_features:
+        _, points = genKeypoints(image, method, options, ctx=ctx)
+        return extractFeatures(image, points, ctx=ctx)                       # genKeypoints.m:32
     if hasattr(image, "data_ptr"):
         return None, _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap, min_contrast,
                                           metric_threshold)
