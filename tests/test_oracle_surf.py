@@ -137,3 +137,123 @@ def test_points_are_strict_maxima_of_their_block_and_transposition_exchanges_the
     assert totalT == total
     key = lambda p, m: sorted(zip(np.round(p[:, 0], 3).tolist(), np.round(p[:, 1], 3).tolist(), m.tolist()))
     assert key(abT[:, ::-1], metricT) == key(ab, metric)
+
+
+# ---- descriptors and matching --------------------------------------------------------------------------
+
+def _descriptor_numpy(img, x1, y1, sc, upright):
+    """The descriptor definition written with plain pixel sums (no integral image), one point."""
+    I = img.astype(np.int64)
+    H, W = I.shape
+
+    def box(x0, y0, x1_, y1_):
+        x0, y0, x1_, y1_ = max(x0, 0), max(y0, 0), min(x1_, W), min(y1_, H)
+        return int(I[y0:y1_, x0:x1_].sum()) if x1_ > x0 and y1_ > y0 else 0
+
+    def haar_x(x, y, z):
+        return float(box(x, y - z // 2, x + z // 2, y - z // 2 + z) - box(x - z // 2, y - z // 2, x, y - z // 2 + z))
+
+    def haar_y(x, y, z):
+        return float(box(x - z // 2, y, x - z // 2 + z, y + z // 2) - box(x - z // 2, y - z // 2, x - z // 2 + z, y))
+
+    x, y = float(x1) - 1.0, float(y1) - 1.0
+    S, X, Y = int(np.floor(sc + 0.5)), int(np.floor(x + 0.5)), int(np.floor(y + 0.5))
+    co, si = 1.0, 0.0
+    if not upright:
+        r = []
+        for j in range(-6, 7):
+            for i in range(-6, 7):
+                if i * i + j * j < 36:
+                    w = np.exp(-(i * i + j * j) / 8.0)
+                    r.append((w * haar_x(X + i * S, Y + j * S, 4 * S), w * haar_y(X + i * S, Y + j * S, 4 * S)))
+        r = np.array(r)
+        best, bx, by = 0.0, 0.0, 0.0
+        for k in range(42):
+            u, v = (np.cos(0.15 * k), np.sin(0.15 * k)), (np.cos(0.15 * k + np.pi / 3), np.sin(0.15 * k + np.pi / 3))
+            inside = (u[0] * r[:, 1] - u[1] * r[:, 0] >= 0) & (r[:, 0] * v[1] - r[:, 1] * v[0] >= 0)
+            sx, sy = r[inside, 0].sum(), r[inside, 1].sum()
+            if sx * sx + sy * sy > best * (1 + 1e-12):
+                best, bx, by = sx * sx + sy * sy, sx, sy
+        if best > 0:
+            co, si = bx / np.sqrt(best), by / np.sqrt(best)
+    d = np.zeros((4, 4, 4))
+    for j in range(-10, 10):
+        for i in range(-10, 10):
+            u, v = (i + 0.5) * sc, (j + 0.5) * sc
+            xs, ys = int(np.floor(x + co * u - si * v + 0.5)), int(np.floor(y + si * u + co * v + 0.5))
+            w = np.exp(-((i + 0.5) ** 2 + (j + 0.5) ** 2) / (2 * 3.3 ** 2))
+            hx, hy = w * haar_x(xs, ys, 2 * S), w * haar_y(xs, ys, 2 * S)
+            dx, dy = co * hx + si * hy, co * hy - si * hx
+            d[(j + 10) // 5, (i + 10) // 5] += (dx, dy, abs(dx), abs(dy))
+    d = d.reshape(-1)
+    n = np.linalg.norm(d)
+    return (d / n if n > 0 else d), np.arctan2(si, co)
+
+
+def test_descriptors_match_a_plain_pixel_sum_statement(oracle, vo):
+    img = vo.synth.to_uint8(vo.synth.textured_image(150, 200, seed=4))
+    ab, metric, scale, total = oracle.detect_surf(img, 300.0, 16)
+    assert total > 20
+    loc = ab + np.float32(1.0)
+    pick = np.linspace(0, total - 1, 12).astype(int)
+    # plus points whose sampling squares leave the image
+    extra = np.array([[2.0, 2.0], [199.0, 149.0], [100.5, 3.25]], dtype=np.float32)
+    pts = np.vstack([loc[pick], extra])
+    scs = np.concatenate([scale[pick], np.array([2.0, 3.1, 6.4], dtype=np.float32)])
+    for upright in (True, False):
+        feats, ori = oracle.surf_descriptors(img, pts, scs, upright=upright)
+        assert feats.shape == (len(pts), 64)
+        for k in range(len(pts)):
+            want, want_ori = _descriptor_numpy(img, pts[k, 0], pts[k, 1], float(scs[k]), upright)
+            assert np.abs(feats[k] - want).max() < 2e-6, (k, upright)
+            assert abs(ori[k] - want_ori) < 1e-5
+    # the storage order of the image does not matter (MATLAB's arrays are column-major)
+    fF, oF = oracle.surf_descriptors(np.asfortranarray(img), pts, scs)
+    fC, oC = oracle.surf_descriptors(img, pts, scs)
+    np.testing.assert_array_equal(fF, fC)
+    np.testing.assert_array_equal(oF, oC)
+
+
+def test_descriptors_follow_a_quarter_turn_and_matching_finds_it(oracle, vo):
+    """A quarter turn of the image maps the sampling pattern onto itself up to pixel rounding: the points of
+    the turned image match the original's where they belong, and their directions turn with them."""
+    img = vo.synth.to_uint8(vo.synth.textured_image(300, 400, seed=9))
+    ab, _, scale, total = oracle.detect_surf(img, 500.0, 30)
+    f0, o0 = oracle.surf_descriptors(img, ab + np.float32(1.0), scale)
+    turned = np.ascontiguousarray(np.rot90(img))             # (x, y) -> (y, W - 1 - x)
+    ab3, _, scale3, total3 = oracle.detect_surf(turned, 500.0, 30)
+    f3, o3 = oracle.surf_descriptors(turned, ab3 + np.float32(1.0), scale3)
+    pairs, dist = oracle.match_features(f0, f3)
+    assert len(pairs) > 0.4 * total
+    W = img.shape[1]
+    want = np.stack([ab[pairs[:, 0], 1], W - 1 - ab[pairs[:, 0], 0]], axis=1)
+    ok = np.abs(ab3[pairs[:, 1]] - want).max(axis=1) < 0.6
+    assert ok.mean() > 0.9
+    turn = np.angle(np.exp(1j * (o3[pairs[ok, 1]] - o0[pairs[ok, 0]])))
+    assert np.median(np.abs(turn + np.pi / 2)) < 0.05       # a quarter turn, counter-clockwise on the screen = -pi/2 with y down
+
+
+def test_matching_is_the_stated_rule(oracle):
+    rng = np.random.default_rng(8)
+    a = rng.normal(size=(300, 64))
+    b = np.vstack([a[:200] + 0.03 * rng.normal(size=(200, 64)), rng.normal(size=(150, 64))])[rng.permutation(350)]
+    a = (a / np.linalg.norm(a, axis=1, keepdims=True)).astype(np.float32)
+    b = (b / np.linalg.norm(b, axis=1, keepdims=True)).astype(np.float32)
+    d = ((a[:, None, :].astype(np.float64) - b[None].astype(np.float64)) ** 2).sum(axis=2)
+    order = np.argsort(d, axis=1, kind="stable")
+    for mt, mr in ((1.0, 0.6), (5.0, 0.8), (100.0, 1.0)):
+        pairs, dist = oracle.match_features(a, b, mt, mr)
+        d1, d2 = d[np.arange(300), order[:, 0]], d[np.arange(300), order[:, 1]]
+        keep = (d1 <= 4 * mt / 100) & (d1 <= mr * mr * d2)
+        # (float32 sums against float64 ones: leave out the pairs within rounding of a bound)
+        sure = (np.abs(d1 - 4 * mt / 100) > 1e-5) & (np.abs(d1 - mr * mr * d2) > 1e-5)
+        got = np.zeros(300, dtype=bool)
+        got[pairs[:, 0]] = True
+        np.testing.assert_array_equal(got[sure], keep[sure])
+        np.testing.assert_array_equal(pairs[:, 1], order[pairs[:, 0], 0])
+        np.testing.assert_allclose(dist, d1[pairs[:, 0]], atol=1e-5)
+        assert np.all(np.diff(pairs[:, 0]) > 0)
+    pairs, _ = oracle.match_features(a, b)
+    assert 150 < len(pairs) <= 200          # the 200 noisy copies, less those another random vector comes close to
+    # a single candidate has no second neighbour: the ratio test passes
+    assert len(oracle.match_features(a[:5], a[:1], 100.0, 0.1)[0]) == 5
