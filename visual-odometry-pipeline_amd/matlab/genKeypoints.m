@@ -1,7 +1,9 @@
 function [features, valid_key_points] = genKeypoints(image, method, options)
 % Drop-in for utils/genKeypoints.m for the natively built detectors ('SURF', 'Harris', 'MinEigen', 'FAST').
-% features is [] (the continuous-operation loop discards it); valid_key_points is a cornerPoints (SURF:
-% SURFPoints) object, so .Location / .Metric / indexing behave as before.
+% valid_key_points is a cornerPoints (SURF: SURFPoints) object, so .Location / .Metric / indexing behave as before.
+% features is [] for the corner detectors (the continuous-operation loop discards it, main_demo.m:377) and, for
+% SURF, the N x 64 descriptors of extractFeatures (genKeypoints.m:32), which the 'Des_match' bootstrap branch
+% matches; the loop's own per-frame detections go through vohip.FrameLoop and never come here.
 if nargin == 1, method = 'SURF'; end          % the reference's default
 if nargin < 3, options = {}; end
 opts = struct('MinQuality', 0.01, 'FilterSize', 5, 'MinContrast', 0.2, 'MetricThreshold', 1000);
@@ -12,8 +14,8 @@ end
 switch method
     case 'SURF'
         [loc, metric, scale] = vohip_mex('detect_surf', image, opts.MetricThreshold, 16);
-        features = [];
-        valid_key_points = SURFPoints(loc, 'Metric', metric, 'Scale', scale);
+        [features, orientation] = vohip_mex('surf_features', image, loc, scale, 0);       % genKeypoints.m:32
+        valid_key_points = SURFPoints(loc, 'Metric', metric, 'Scale', scale, 'Orientation', orientation);
         return
     case 'Harris'
         [loc, metric] = vohip_mex('detect_corners', image, opts.MinQuality, opts.FilterSize, 16, 0);

@@ -338,6 +338,56 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         mxFree(xy);
         mxFree(metric);
         mxFree(scale);
+    } else if (is("surf_features")) {
+        // [features (N x 64 single), orientation] = vohip_mex('surf_features', image uint8, Location (N x 2 single), Scale, upright)
+        if (!mxIsUint8(in[0]) || !mxIsSingle(in[1]) || !mxIsSingle(in[2]))
+            mexErrMsgIdAndTxt("vohip:type", "image must be uint8, Location and Scale single");
+        const int n = rows(in[1]);
+        plhs[0] = mxCreateNumericMatrix(n, 64, mxSINGLE_CLASS, mxREAL);
+        mxArray *ori = mxCreateNumericMatrix(n, 1, mxSINGLE_CLASS, mxREAL);
+        if (n > 0) {
+            float *f = scratch<float>((size_t)64 * n);   // a point's 64 numbers contiguous: the transpose of MATLAB's array
+            check(vohip_extract_surf_features(c, mxGetUint8s(in[0]), rows(in[0]), cols(in[0]), 1, mxGetSingles(in[1]),
+                                              mxGetSingles(in[2]), n, nrhs > 4 ? (int)mxGetScalar(in[3]) : 0, f,
+                                              mxGetSingles(ori)));
+            float *out = mxGetSingles(plhs[0]);
+            for (int k = 0; k < 64; ++k)
+                for (int i = 0; i < n; ++i) out[(size_t)k * n + i] = f[(size_t)i * 64 + k];
+            mxFree(f);
+        }
+        if (nlhs > 1) plhs[1] = ori;
+    } else if (is("match_features")) {
+        // [indexPairs (P x 2 double, 1-based), metric] = vohip_mex('match_features', features1, features2, MatchThreshold, MaxRatio)
+        if (!mxIsSingle(in[0]) || !mxIsSingle(in[1]) || cols(in[0]) != cols(in[1]))
+            mexErrMsgIdAndTxt("vohip:type", "features must be single N1 x D and N2 x D");
+        const int n0 = rows(in[0]), n1 = rows(in[1]), dim = cols(in[0]);
+        int m = 0;
+        int32_t *pairs = scratch<int32_t>((size_t)2 * (n0 + 1));
+        float *metric = scratch<float>((size_t)n0 + 1);
+        if (n0 > 0 && n1 > 0) {
+            float *f0 = scratch<float>((size_t)n0 * dim), *f1 = scratch<float>((size_t)n1 * dim);
+            const float *a = mxGetSingles(in[0]), *b = mxGetSingles(in[1]);
+            for (int i = 0; i < n0; ++i)
+                for (int k = 0; k < dim; ++k) f0[(size_t)i * dim + k] = a[(size_t)k * n0 + i];
+            for (int i = 0; i < n1; ++i)
+                for (int k = 0; k < dim; ++k) f1[(size_t)i * dim + k] = b[(size_t)k * n1 + i];
+            check(vohip_match_features(c, f0, n0, f1, n1, dim, nrhs > 3 ? mxGetScalar(in[2]) : 1.0,
+                                       nrhs > 4 ? mxGetScalar(in[3]) : 0.6, pairs, metric, &m));
+            mxFree(f0);
+            mxFree(f1);
+        }
+        plhs[0] = mxCreateDoubleMatrix(m, 2, mxREAL);
+        double *ip = mxGetDoubles(plhs[0]);
+        for (int i = 0; i < m; ++i) {
+            ip[i] = pairs[2 * i] + 1.0;
+            ip[m + i] = pairs[2 * i + 1] + 1.0;
+        }
+        if (nlhs > 1) {
+            plhs[1] = mxCreateNumericMatrix(m, 1, mxSINGLE_CLASS, mxREAL);
+            std::memcpy(mxGetSingles(plhs[1]), metric, sizeof(float) * m);
+        }
+        mxFree(pairs);
+        mxFree(metric);
     } else if (is("pyramid_build")) {
         // vohip_mex('pyramid_build', slot, image uint8, levels)
         if (!mxIsUint8(in[1])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
