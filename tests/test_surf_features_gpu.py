@@ -98,6 +98,14 @@ def test_matching_matches_oracle_and_finds_a_known_shift(vo, ctx, oracle):
     assert len(wp) > 20
     np.testing.assert_array_equal(p, wp)
     np.testing.assert_array_equal(d, wd)
+    a, b = rng.normal(size=(130, 80)).astype(np.float32), rng.normal(size=(257, 80)).astype(np.float32)   # (longer than 64: the untiled kernel)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b /= np.linalg.norm(b, axis=1, keepdims=True)
+    p, d = vo.matchFeatures(a, b, MatchThreshold=60.0, MaxRatio=0.95, ctx=ctx)
+    wp, wd = oracle.match_features(a, b, 60.0, 0.95)
+    assert len(wp) > 5
+    np.testing.assert_array_equal(p, wp)
+    np.testing.assert_array_equal(d, wd)
     assert vo.matchFeatures(np.zeros((0, 64), np.float32), f1, ctx=ctx)[0].shape == (0, 2)
     with pytest.raises(vo.VohipError):
         vo.matchFeatures(f0, f1, MaxRatio=1.5, ctx=ctx)

@@ -64,6 +64,19 @@ def main():
     e1.record(stream)
     ctx.synchronize()
     out["SURF_batch"] = {"frames": nb, "us_per_frame": 1e3 * e0.elapsed_time(e1) / 5 / nb}
+    # the 'Des_match' bootstrap's two stages on this frame's SURF points (host arrays in and out, as the bootstrap calls them)
+    import time
+    feats, pts = vo.genKeypoints(frame, "SURF", ["MetricThreshold", 200], ctx=ctx, with_features=True)
+    frame2 = scene.render(vo.synth.corridor_trajectory(4, step=0.7)[3])
+    feats2, pts2 = vo.genKeypoints(frame2, "SURF", ["MetricThreshold", 200], ctx=ctx, with_features=True)
+    for name, fn in (("extractFeatures", lambda: vo.extractFeatures(frame, pts, ctx=ctx)),
+                     ("matchFeatures", lambda: vo.matchFeatures(feats, feats2, ctx=ctx))):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            r = fn()
+        out[name] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / 20, "points": [pts.Count, pts2.Count],
+                     "pairs": int(len(r[0])) if name == "matchFeatures" else None}
     print(json.dumps(out, indent=1))
 
 

@@ -864,6 +864,94 @@ __global__ __launch_bounds__(256) void match_nearest_kernel(const float *__restr
     }
 }
 
+// The same for features of at most 64 numbers (SURF's): a workgroup takes 16 features of the first set (4 per
+// wavefront) and walks the second set in tiles of 64 staged in LDS (rows 65 floats apart: a lane reads its own row
+// without bank conflicts); a lane keeps one feature of the tile against its wavefront's four, so every number of the
+// tile is read once per four distances and the first set's numbers come as 16-byte broadcasts.  Each distance is
+// still the sum over k ascending in fp32: the results are those of match_nearest_kernel, bit for bit.
+constexpr int MT_I = 16, MT_J = 64, MT_D = 64;
+__global__ __launch_bounds__(256) void match_nearest_tiled_kernel(const float *__restrict__ f0, int n0,
+                                                                  const float *__restrict__ f1, int n1, int dim, float thr,
+                                                                  float r2, int *__restrict__ match_j,
+                                                                  float *__restrict__ match_d)
+{
+    __shared__ __align__(16) float sA[MT_I][MT_D];
+    __shared__ float sB[MT_J][MT_D + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * MT_I;
+    for (int q = tid; q < MT_I * MT_D; q += 256) {
+        const int r = q / MT_D, k = q - r * MT_D;
+        sA[r][k] = i0 + r < n0 && k < dim ? f0[(size_t)(i0 + r) * dim + k] : 0.0f;
+    }
+    float d1[4], d2[4];
+    int j1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d1[r] = d2[r] = INFINITY;
+        j1[r] = 0x7fffffff;
+    }
+    const int kmax = (dim + 3) & ~3;   // (numbers past dim are zero on both sides: (0 - 0)^2 adds nothing)
+    for (int j0 = 0; j0 < n1; j0 += MT_J) {
+        __syncthreads();
+        for (int q = tid; q < MT_J * MT_D; q += 256) {
+            const int r = q / MT_D, k = q - r * MT_D;
+            sB[r][k] = j0 + r < n1 && k < dim ? f1[(size_t)(j0 + r) * dim + k] : 0.0f;
+        }
+        __syncthreads();
+        float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < kmax; k += 4) {
+            float b[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = sB[lane][k + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 a = *reinterpret_cast<const float4 *>(&sA[4 * wave + r][k]);
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float e = av[c] - b[c];
+                    d[r] += e * e;
+                }
+            }
+        }
+        const int j = j0 + lane;
+        if (j < n1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (d[r] < d1[r]) {
+                    d2[r] = d1[r];
+                    d1[r] = d[r];
+                    j1[r] = j;
+                } else if (d[r] < d2[r]) {
+                    d2[r] = d[r];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a1 = d1[r], a2 = d2[r];
+        int k1 = j1[r];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float e1 = __shfl_xor(a1, m, 64), e2 = __shfl_xor(a2, m, 64);
+            const int q1 = __shfl_xor(k1, m, 64);
+            const bool theirs = e1 < a1 || (e1 == a1 && q1 < k1);
+            const float lo = theirs ? e1 : a1, other = theirs ? a1 : e1, second = theirs ? e2 : a2;
+            k1 = theirs ? q1 : k1;
+            a1 = lo;
+            a2 = fminf(other, second);
+        }
+        const int i = i0 + 4 * wave + r;
+        if (lane == 0 && i < n0) {
+            bool keep = k1 != 0x7fffffff && a1 <= thr;
+            if (keep && n1 > 1) keep = a1 <= r2 * a2;
+            match_j[i] = keep ? k1 : -1;
+            match_d[i] = a1;
+        }
+    }
+}
+
 // The kept pairs in the order of i: one workgroup of 1024 threads walks the first set in spans of 1024.
 __global__ __launch_bounds__(1024) void match_compact_kernel(const int *__restrict__ match_j, const float *__restrict__ match_d,
                                                              int n0, int *__restrict__ pairs, float *__restrict__ metric,
@@ -947,8 +1035,12 @@ int match_dev(vohip_ctx *ctx, const float *d_f0, int n0, const float *d_f1, int 
     int *match_j = (int *)b.ptr;
     float *match_d = (float *)(match_j + n0);
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(match_nearest_kernel, dim3((n0 + 3) / 4), dim3(256), 0, st, d_f0, n0, d_f1, n1, dim,
-                       (float)(4.0 * match_threshold / 100.0), (float)(max_ratio * max_ratio), match_j, match_d);
+    if (dim <= MT_D)
+        hipLaunchKernelGGL(match_nearest_tiled_kernel, dim3((n0 + MT_I - 1) / MT_I), dim3(256), 0, st, d_f0, n0, d_f1, n1, dim,
+                           (float)(4.0 * match_threshold / 100.0), (float)(max_ratio * max_ratio), match_j, match_d);
+    else
+        hipLaunchKernelGGL(match_nearest_kernel, dim3((n0 + 3) / 4), dim3(256), 0, st, d_f0, n0, d_f1, n1, dim,
+                           (float)(4.0 * match_threshold / 100.0), (float)(max_ratio * max_ratio), match_j, match_d);
     hipLaunchKernelGGL(match_compact_kernel, dim3(1), dim3(1024), 0, st, (const int *)match_j, (const float *)match_d, n0,
                        d_pairs, d_metric, d_count);
     VOHIP_HIP(ctx, hipGetLastError());
