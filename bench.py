@@ -312,21 +312,22 @@ def tracker_of_loop(vo, torch, ctx, scene, frames, poses, steps, warmup, seed):
                             frames_of_run=warmup + steps)
 
 
-def bench_main_eval(vo, ctx, frames, poses, concurrent=1, group=0):
+def bench_main_eval(vo, ctx, frames, poses, concurrent=1, group=0, feats=("Harris", "MinEigen", "FAST"), repetition=4):
     """The batch evaluation of main_eval.m:20-23 on one GPU: a grid of 3 feature variants (Harris, MinEigen, FAST) x 4
     repetitions = 12 full runs (bootstrap on the first three frames, continuous operation on the rest,
     quantitative_eval, result record) of one KITTI-shape sequence whose images live in host memory; `concurrent`
     runs in flight at a time (a thread and a context each), or -- group -- the Harris and MinEigen runs as groups
     of that many loops in lockstep.  Returns runs/s and the frames/s of the grid as a whole (continuous-operation
-    frames / wall time, bootstraps and evaluations included)."""
+    frames / wall time, bootstraps and evaluations included).  feats / repetition: another grid of the same size,
+    e.g. main_eval.m:19's own four variants with SURF, the reference's default, among them."""
     seq = dict(name="kitti", images=frames, K=vo.synth.K_KITTI,
                ground_truth=np.array([[T[0, 3], T[2, 3]] for T in poses[:len(frames)]]))
     short = dict(seq, images=frames[:12])
-    vo.main_eval([short], feats=("Harris", "FAST"), repetition=2 if group and concurrent > 1 else 1, seed=10, ctx=ctx,
+    vo.main_eval([short], feats=("Harris", "FAST") if "SURF" not in feats else ("SURF", "FAST"),
+                 repetition=2 if group and concurrent > 1 else 1, seed=10, ctx=ctx,
                  concurrent=concurrent, group=min(group, 2) if concurrent > 1 else group)   # code objects, staging buffers
     t0 = time.perf_counter()
-    records = vo.main_eval([seq], feats=("Harris", "MinEigen", "FAST"), repetition=4, seed=10, ctx=ctx, concurrent=concurrent,
-                           group=group)
+    records = vo.main_eval([seq], feats=feats, repetition=repetition, seed=10, ctx=ctx, concurrent=concurrent, group=group)
     dt = time.perf_counter() - t0
     n_frames = sum(int(r["frame_ct"]) for r in records)
     return {"runs": len(records), "runs_per_s": len(records) / dt, "frames_per_s": n_frames / dt,
@@ -843,7 +844,12 @@ def main():
                 "one_run_at_a_time": bench_main_eval(vo, ctx, frames, poses),
                 "four_runs_in_flight": bench_main_eval(vo, ctx, frames, poses, concurrent=4),
                 "groups_of_8_loops_in_lockstep": bench_main_eval(vo, ctx, frames, poses, group=8),
-                "two_groups_of_6_in_flight": bench_main_eval(vo, ctx, frames, poses, concurrent=2, group=6)}
+                "two_groups_of_6_in_flight": bench_main_eval(vo, ctx, frames, poses, concurrent=2, group=6),
+                "two_groups_of_6_in_flight_grid_with_surf": dict(
+                    bench_main_eval(vo, ctx, frames, poses, concurrent=2, group=6,
+                                    feats=("SURF", "Harris", "MinEigen", "FAST"), repetition=3),
+                    workload="4 feature variants (SURF -- the reference's default, MetricThreshold 200 --, Harris, MinEigen, "
+                             "FAST) x 3 repetitions: the same 12 runs with SURF in the grid")}
 
         klt_loop = klt_stress = image_kernels = ba_runs = None
         n, h = args.points, args.hypotheses

@@ -364,26 +364,18 @@ __device__ __forceinline__ bool surf_test(const float *p0, const float *p1, cons
     return true;
 }
 
-// The samples of row gb of (octave o, middle level m) that may hold a point: first..last (empty when first > last).
-// Those at which the filter of level m + 1 lies inside the image, less one sample for the block; then the border.
-__device__ __forceinline__ void candidate_range(const surf_geom &g, int o, int m, int gb, int lo, int *first, int *last)
-{
-    const int s = 1 << o, htop = (g.L[4 * o + m + 1] - 1) / 2;
-    const int lo_g = (htop + s - 1) / s + 1;
-    const int hi_a = (g.A - 1 - htop >= 0 ? (g.A - 1 - htop) / s : -1) - 1;
-    const int hi_b = (g.B - 1 - htop >= 0 ? (g.B - 1 - htop) / s : -1) - 1;
-    const int b = gb * s;
-    const bool row_ok = gb >= lo_g && gb <= hi_b && b >= lo && b < g.B - lo;
-    *first = max(lo_g, (lo + s - 1) / s);
-    *last = min(hi_a, (g.A - lo - 1) / s);   // a = ga s <= A - lo - 1
-    if (!row_ok) *last = *first - 1;
-}
+// The samples of (octave o, middle level m), pair k = 2 o + (m - 1), that may hold a point: columns
+// first_a..last_a of rows first_b..last_b (empty when a first exceeds its last).  Those at which the filter of level
+// m + 1 lies inside the image, less one sample for the block; then the border.  Made on the host.
+struct surf_ranges {
+    int first_a[SURF_MID], last_a[SURF_MID], first_b[SURF_MID], last_b[SURF_MID];
+};
 
 constexpr int XT_A = 64, XT_B = 4, XS_A = XT_A + 2, XS_B = XT_B + 2;   // tile of samples; staged with a ring of one
 
 __global__ __launch_bounds__(256) void surf_extrema_kernel(const float *__restrict__ R, int *__restrict__ cells,
                                                            int *__restrict__ subs, surf_point *__restrict__ recs, surf_geom g,
-                                                           float thr, int lo)
+                                                           float thr, surf_ranges rg)
 {
     R += blockIdx.y * g.r_stride;
     cells += blockIdx.y * g.cell_stride;
@@ -419,14 +411,13 @@ __global__ __launch_bounds__(256) void surf_extrema_kernel(const float *__restri
     const int c = (wave + 1) * XS_A + (lane + 1);
 #pragma unroll
     for (int m = 1; m <= 2; ++m) {
-        int first, last;
-        candidate_range(g, o, m, gb, lo, &first, &last);
+        const int pair = 2 * o + (m - 1);
         surf_point pt;
-        const bool hit = ga >= first && ga <= last &&
+        const bool hit = ga >= rg.first_a[pair] && ga <= rg.last_a[pair] && gb >= rg.first_b[pair] && gb <= rg.last_b[pair] &&
                          surf_test(&sR[m - 1][c], &sR[m][c], &sR[m + 1][c], XS_A, ga, gb, thr, 1 << o, g.L[4 * o + m],
                                    g.L[4 * o + m] - g.L[4 * o + m - 1], &pt);
         const unsigned long long bal = __ballot(hit);
-        const int n = __popcll(bal), pair = 2 * o + (m - 1);
+        const int n = __popcll(bal);
         const int sub = g.sub_first[pair] + gb * g.tiles_a[o] + ta;
         if (hit) recs[(size_t)sub * SURF_SUB_CAP + __popcll(bal & ((1ull << lane) - 1ull))] = pt;
         if (lane == 0) {
@@ -479,6 +470,25 @@ __global__ __launch_bounds__(256) void surf_emit_kernel(const int *__restrict__ 
 
 #pragma clang fp contract(fast)
 
+surf_ranges make_ranges(const surf_geom &g, int lo)
+{
+    surf_ranges r;
+    for (int o = 0; o < SURF_OCT; ++o)
+        for (int m = 1; m <= 2; ++m) {
+            const int s = 1 << o, k = 2 * o + (m - 1), htop = (g.L[4 * o + m + 1] - 1) / 2;
+            const int lo_g = (htop + s - 1) / s + 1, lo_s = (lo + s - 1) / s;
+            auto last_of = [&](int len) {   // the last sample whose block lies inside and whose pixel keeps the border
+                const int fit = len - 1 - htop >= 0 ? (len - 1 - htop) / s - 1 : -1;
+                const int keep = len - lo - 1 >= 0 ? (len - lo - 1) / s : -1;
+                return fit < keep ? fit : keep;
+            };
+            r.first_a[k] = r.first_b[k] = lo_g > lo_s ? lo_g : lo_s;
+            r.last_a[k] = last_of(g.A);
+            r.last_b[k] = last_of(g.B);
+        }
+    return r;
+}
+
 surf_norms make_norms(const surf_geom &g)
 {
     surf_norms nm;
@@ -517,7 +527,7 @@ int enqueue_images(vohip_ctx *ctx, hipStream_t st, void *scratch, surf_geom g, c
     hipLaunchKernelGGL(surf_response_kernel, dim3(g.resp0_tiles + g.tile_first[SURF_MAPS] - g.tile_first[SURF_LEV], n),
                        dim3(256), 0, st, (const uint32_t *)T, R, g, make_norms(g));
     hipLaunchKernelGGL(surf_extrema_kernel, dim3(g.otile_first[SURF_OCT], n), dim3(256), 0, st, (const float *)R, cells, subs,
-                       recs, g, (float)metric_threshold, lo);
+                       recs, g, (float)metric_threshold, make_ranges(g, lo));
     hipLaunchKernelGGL(surf_emit_kernel, dim3((nsubs + 3) / 4, n), dim3(256), 0, st, (const int *)cells, (const int *)subs,
                        (const surf_point *)recs, g, cap, colmajor ? 1 : 0, d_xy, d_metric, d_scale, d_counts);
     VOHIP_HIP(ctx, hipGetLastError());
@@ -674,31 +684,33 @@ struct surf_tables {
     int off_i[112], off_j[112];   // the 109 offsets, j outer, i inner
 };
 
+surf_tables make_tables()
+{
+    surf_tables t{};
+    for (int r2 = 0; r2 < 36; ++r2) t.w_ori[r2] = std::exp(-(double)r2 / 8.0);
+    for (int i = 0; i < 10; ++i)
+        for (int j = 0; j < 10; ++j)
+            t.w_desc[10 * i + j] = std::exp(-((i + 0.5) * (i + 0.5) + (j + 0.5) * (j + 0.5)) / (2.0 * 3.3 * 3.3));
+    for (int k = 0; k < 42; ++k) {
+        t.win[0][k] = std::cos(0.15 * k);
+        t.win[1][k] = std::sin(0.15 * k);
+        t.win[2][k] = std::cos(0.15 * k + 3.14159265358979323846 / 3.0);
+        t.win[3][k] = std::sin(0.15 * k + 3.14159265358979323846 / 3.0);
+    }
+    int m = 0;
+    for (int j = -6; j <= 6; ++j)
+        for (int i = -6; i <= 6; ++i)
+            if (i * i + j * j < 36) {
+                t.off_i[m] = i;
+                t.off_j[m] = j;
+                ++m;
+            }
+    return t;
+}
+
 const surf_tables &host_tables()
 {
-    static surf_tables t;
-    static bool made = false;
-    if (!made) {
-        for (int r2 = 0; r2 < 36; ++r2) t.w_ori[r2] = std::exp(-(double)r2 / 8.0);
-        for (int i = 0; i < 10; ++i)
-            for (int j = 0; j < 10; ++j)
-                t.w_desc[10 * i + j] = std::exp(-((i + 0.5) * (i + 0.5) + (j + 0.5) * (j + 0.5)) / (2.0 * 3.3 * 3.3));
-        for (int k = 0; k < 42; ++k) {
-            t.win[0][k] = std::cos(0.15 * k);
-            t.win[1][k] = std::sin(0.15 * k);
-            t.win[2][k] = std::cos(0.15 * k + 3.14159265358979323846 / 3.0);
-            t.win[3][k] = std::sin(0.15 * k + 3.14159265358979323846 / 3.0);
-        }
-        int m = 0;
-        for (int j = -6; j <= 6; ++j)
-            for (int i = -6; i <= 6; ++i)
-                if (i * i + j * j < 36) {
-                    t.off_i[m] = i;
-                    t.off_j[m] = j;
-                    ++m;
-                }
-        made = true;
-    }
+    static const surf_tables t = make_tables();   // (made once, by whichever thread comes first)
     return t;
 }
 
