@@ -628,6 +628,27 @@ int vohip_detect_surf_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int co
 int vohip_detect_surf_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
                                 double metric_threshold, int border, float *d_xy, float *d_metric, int cap, int *d_counts);
 
+/* Stands in for genKeypoints.m:1-33 with method 'BRISK' (dispatch table genKeypoints.m:20; main_eval.m:170-171 passes
+ * {'MinQuality', 2e-3}): detectBRISKFeatures(image, 'MinContrast', c, 'MinQuality', q, 'NumOctaves', n) with the toolbox
+ * defaults 0.2, 0.1 and 4.  The scale-space FAST detector of Leutenegger et al. (ICCV 2011): 2 n layers (octaves by
+ * half-sampling, intra-octaves from a 2/3 resampling of the image) at the scales 1, 1.5, 2, 3, 4, 6, 8, 12; the FAST 9-16
+ * score of every layer's pixels (threshold round(255 c)); a keypoint is a strict maximum of its 8 neighbours in its layer
+ * whose score also exceeds the scores of the layers above and below inside its 3 x 3 patch and q times the largest score of
+ * all layers; sub-pixel position by a parabola per axis, mapped to the image; Scale (scale_out, may be NULL) by a parabola
+ * through the three layers' scores (the layer below the image: FAST 5-8 at scale 2/3), in units of the image's pixel.
+ * Only the positions are used by the pipeline.  Points closer than `border` pixels to an edge are dropped as for the other
+ * detectors.  Output layout as vohip_detect_corners; order: layer, then pixel order.  At most 2^26 pixels.  The batch
+ * call serves n images stored one after the other (lists of n single calls, bit for bit). */
+int vohip_detect_brisk(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double min_contrast,
+                       double min_quality, int num_octaves, int border, float *xy_out, float *metric_out, float *scale_out,
+                       int cap, int *n_out);
+int vohip_detect_brisk_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, double min_contrast,
+                           double min_quality, int num_octaves, int border, float *d_xy, float *d_metric, float *d_scale,
+                           int cap, int *d_count);
+int vohip_detect_brisk_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                                 double min_contrast, double min_quality, int num_octaves, int border, float *d_xy,
+                                 float *d_metric, int cap, int *d_counts);
+
 /* Stands in for extractFeatures(image, SURFPoints) as genKeypoints.m:32 calls it (64-element SURF descriptors,
  * 'Upright' false), the features the 'Des_match' bootstrap branch matches (matching_init.m:26-29).  A closed toolbox
  * function; built as section 4 of Bay et al. describes it: the dominant direction of the Haar-wavelet responses

@@ -186,6 +186,17 @@ void vo_surf_descriptors(const uint8_t *img, int A, int B, int swap_xy, const fl
 int vo_match_features(const float *f0, int n0, const float *f1, int n1, int dim, double match_threshold, double max_ratio,
                       int *pairs, float *metric);
 
+/* ---- brisk_oracle.c -------------------------------------------------------------------- */
+
+/* This project's definition of the BRISK detector that stands in for detectBRISKFeatures (genKeypoints.m:20); see
+ * brisk_oracle.c.  Layers 0..7 in the order of their scale 1, 1.5, 2, 3, 4, 6, 8, 12. */
+void vo_brisk_half(const uint8_t *src, int A, int B, uint8_t *dst);
+void vo_brisk_twothirds(const uint8_t *src, int A, int B, uint8_t *dst);
+void vo_brisk_layer(const uint8_t *img, int A, int B, int k, uint8_t *out, int *Ak, int *Bk);
+void vo_fast58_score(const uint8_t *img, int A, int B, int *S);
+int vo_detect_brisk(const uint8_t *img, int A, int B, double min_contrast, double min_quality, int num_octaves, int border,
+                    float *ab_out, float *metric_out, float *scale_out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -388,10 +388,49 @@ def match_features(f0, f1, match_threshold=1.0, max_ratio=0.6):
     return pairs[:m].copy(), metric[:m].copy()
 
 
+def brisk_layer(img_ab, k):
+    """Layer k (0..7, scales 1, 1.5, 2, 3, 4, 6, 8, 12) of the BRISK pyramid: uint8 (B_k, A_k)."""
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    out = np.zeros(A * B + 1, dtype=np.uint8)
+    Ak, Bk = C.c_int(0), C.c_int(0)
+    lib().vo_brisk_layer(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_int(k), out.ctypes.data_as(_bp),
+                         C.byref(Ak), C.byref(Bk))
+    return out[:Ak.value * Bk.value].reshape(Bk.value, Ak.value).copy()
+
+
+def fast58_score(img_ab):
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    S = np.zeros((B, A), dtype=np.int32)
+    lib().vo_fast58_score(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), S.ctypes.data_as(C.POINTER(C.c_int)))
+    return S
+
+
+def detect_brisk(img_ab, min_contrast=0.2, min_quality=0.1, num_octaves=4, border=16, cap=16384):
+    """img_ab uint8 (B, A).  Returns ab (n, 2) float32 0-based (a, b), metric (n,), scale (n,), total found."""
+    img = np.ascontiguousarray(img_ab, dtype=np.uint8)
+    B, A = img.shape
+    ab = np.zeros(2 * cap, dtype=np.float32)
+    metric = np.zeros(cap, dtype=np.float32)
+    scale = np.zeros(cap, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    lib().vo_detect_brisk.restype = C.c_int
+    total = lib().vo_detect_brisk(img.ctypes.data_as(_bp), C.c_int(A), C.c_int(B), C.c_double(min_contrast),
+                                  C.c_double(min_quality), C.c_int(num_octaves), C.c_int(border), ab.ctypes.data_as(fp),
+                                  metric.ctypes.data_as(fp), scale.ctypes.data_as(fp), C.c_int(cap))
+    n = min(total, cap)
+    return np.stack([ab[:n], ab[cap:cap + n]], axis=1).copy(), metric[:n].copy(), scale[:n].copy(), total
+
+
 def detect(img_ab, method, options, border=16):
     """genKeypoints.m:1-33 for the detectors: options as the name-value dict of the reference."""
     if method == "SURF":
         ab, metric, _, total = detect_surf(img_ab, options.get("MetricThreshold", 1000.0), border)
+        return ab, metric, total
+    if method == "BRISK":
+        ab, metric, _, total = detect_brisk(img_ab, options.get("MinContrast", 0.2), options.get("MinQuality", 0.1),
+                                            options.get("NumOctaves", 4), border)
         return ab, metric, total
     if method == "FAST":
         return detect_fast(img_ab, options.get("MinContrast", 0.2), options.get("MinQuality", 0.1), border)

@@ -47,7 +47,7 @@ def test_capacity_flat_and_errors(vo, ctx):
     _, kp = vo.genKeypoints(np.full((64, 64), 7, np.uint8), "Harris", ["MinQuality", 2e-4], ctx=ctx)
     assert kp.Count == 0 and kp.Location.shape == (0, 2)
     with pytest.raises(NotImplementedError):
-        vo.genKeypoints(g["img"], "BRISK", ["MinQuality", 2e-3], ctx=ctx)
+        vo.genKeypoints(g["img"], "ORB", ["ScaleFactor", 1.2], ctx=ctx)
     with pytest.raises(ValueError):
         vo.genKeypoints(g["img"], "Harris", ["Bogus", 1], ctx=ctx)
 

@@ -12,7 +12,7 @@ from .evaluation import (alignError, alignEstimateToGroundTruth, experiment_name
                          quantitative_eval, run_group, run_sequence, save_results)
 from .fmatrix import draw_octets, estimateFundamentalMatrix, octets_from_uniforms
 from .frame_pipeline import VOGroupDevice, VOPipelineDevice
-from .keypoints import SURFPoints, cornerPoints, extractFeatures, genKeypoints, matchFeatures
+from .keypoints import BRISKPoints, SURFPoints, cornerPoints, extractFeatures, genKeypoints, matchFeatures
 from .klt import PointTracker, Pyramid
 from .pipeline import (VO_bundle_adjust, VOPipeline, default_hyper_paras, init_state, update_candidate,
                        update_landmarks)

@@ -192,6 +192,12 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_detect_surf_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                                C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_detect_brisk": (C.c_int, [C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                                      c_float_p, c_float_p, c_float_p, C.c_int, c_int_p]),
+    "vohip_detect_brisk_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int,
+                                          C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_detect_brisk_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_extract_surf_features": (C.c_int, [C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, c_float_p, c_float_p, C.c_int,
                                                C.c_int, c_float_p, c_float_p]),
     "vohip_extract_surf_features_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -37,6 +37,8 @@
 
 #include <cmath>
 
+#include "fast_score.h"
+
 namespace {
 
 constexpr int TA = 64, TB = 16, FS = 5, HALF = FS / 2;
@@ -276,8 +278,7 @@ __global__ __launch_bounds__(256) void corner_tile_kernel(const uint8_t *__restr
 }
 
 // FAST: the segment-test score of every pixel of the tile and its 1 px ring from the uint8 tile with a
-// 4 px halo (3 for the circle + 1 for the ring).  Sliding minima over 9 of the 16 differences by doubling
-// (windows of 2, 4, 8, then one more): 4 x 16 min per polarity.
+// 4 px halo (3 for the circle + 1 for the ring).
 __global__ __launch_bounds__(256) void fast_tile_kernel(const uint8_t *__restrict__ img, int A, int B, int tiles_a,
                                                         int tiles_b, int threshold, int lo,
                                                         corner_rec *__restrict__ recs, int *__restrict__ tile_count,
@@ -320,40 +321,13 @@ __global__ __launch_bounds__(256) void fast_tile_kernel(const uint8_t *__restric
         if (q < FA * FB) sI[q] = (int)px[k];
     }
     __syncthreads();
-    // circle of radius 3, clockwise from the top: offsets (da, db)
-    constexpr int CA[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
-    constexpr int CB[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
     float best = -INFINITY;
     for (int q = tid; q < RA * RB; q += 256) {
         const int rb = q / RA, ra = q - rb * RA;
         const int a = a0 - 1 + ra, b = b0 - 1 + rb;
         int score = 0;
         if (a >= 3 && a < A - 3 && b >= 3 && b < B - 3) {
-            const int *c = sI + (rb + 3) * FA + (ra + 3);
-            const int p = c[0];
-            int d[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) d[k] = c[CB[k] * FA + CA[k]] - p;
-            int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                lo2[k] = min(d[k], d[(k + 1) & 15]);
-                hi2[k] = max(d[k], d[(k + 1) & 15]);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                lo4[k] = min(lo2[k], lo2[(k + 2) & 15]);
-                hi4[k] = max(hi2[k], hi2[(k + 2) & 15]);
-            }
-            int bright = -255, dark = -255;   // max over the arcs of min(d) and of min(-d) = -max(d)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-                const int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-                bright = max(bright, lo9);
-                dark = max(dark, -hi9);
-            }
-            const int sc = max(bright, dark) - 1;
+            const int sc = vohip_dev::fast_score_9_16(sI + (rb + 3) * FA + (ra + 3), FA);
             score = sc >= threshold ? sc : 0;
         }
         const float r = (float)score;

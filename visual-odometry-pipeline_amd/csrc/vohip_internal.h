@@ -34,6 +34,7 @@ enum vohip_buf_id {
     B_HARRIS_SCRATCH,
     B_HARRIS_BATCH,
     B_SURF_SCRATCH, B_SURF_BATCH, B_SURF_TABLES, B_SURF_MATCH,
+    B_BRISK_SCRATCH, B_BRISK_BATCH,
     B_FM_NRM, B_FM_F, B_FM_COUNTS, H_FM_COUNTS,
     B_BA_INDEX, B_BA_FRAME, B_BA_LM, B_BA_UV, B_BA_COUNT, B_BA_STATE, B_BA_TRIAL, B_BA_SPART, B_BA_GPART,
     B_BA_E, B_BA_GL, B_BA_W, B_BA_DP, B_BA_PART, B_BA_STATUS, H_BA_STATUS, B_BA_SRED, B_BA_GRED,
@@ -215,6 +216,14 @@ int vohip_detect_surf_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, con
 int vohip_detect_surf_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
                                     double metric_threshold, int border, float *d_xy, float *d_metric, int cap,
                                     int *d_counts);
+// BRISK (detector 4): as for SURF.
+size_t vohip_brisk_scratch_bytes(int rows, int cols);
+int vohip_detect_brisk_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, const uint8_t *d_img, int rows, int cols,
+                               int colmajor, double min_contrast, double min_quality, int num_octaves, int border,
+                               float *d_xy, float *d_metric, float *d_scale, int cap, int *d_count);
+int vohip_detect_brisk_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                                     double min_contrast, double min_quality, int num_octaves, int border, float *d_xy,
+                                     float *d_metric, int cap, int *d_counts);
 int vohip_pose_refine_enqueue(vohip_ctx *ctx, double *d_T, const double *d_kp_uv, const double *d_X, int n,
                               const int *d_n, const double K[9], int max_iter, double ftol, double xtol,
                               double *d_stats, const vohip_seqs *seqs = nullptr);

@@ -1,5 +1,5 @@
 """Host-side mirror of utils/genKeypoints.m:1-33 for the detectors built natively
-('SURF', 'Harris', 'MinEigen', 'FAST').  Detection runs in libvohip.so on the GPU; no CPU fallback."""
+('SURF', 'Harris', 'MinEigen', 'FAST', 'BRISK').  Detection runs in libvohip.so on the GPU; no CPU fallback."""
 import ctypes as C
 
 import numpy as np
@@ -8,8 +8,8 @@ from . import _lib
 
 DEFAULT_BORDER = 16     # px dropped at the image edge, the stand-in for extractFeatures' margin
 DEFAULT_CAPACITY = 16384
-DETECTORS = {"Harris": 0, "MinEigen": 1, "FAST": 2, "SURF": 3}   # rows of the dispatch table, genKeypoints.m:16-19
-DEFAULT_MIN_QUALITY = {"Harris": 0.01, "MinEigen": 0.01, "FAST": 0.1, "SURF": 0.0}   # the toolbox defaults
+DETECTORS = {"Harris": 0, "MinEigen": 1, "FAST": 2, "SURF": 3, "BRISK": 4}   # rows of the dispatch table, genKeypoints.m:16-20
+DEFAULT_MIN_QUALITY = {"Harris": 0.01, "MinEigen": 0.01, "FAST": 0.1, "SURF": 0.0, "BRISK": 0.1}   # the toolbox defaults
 DEFAULT_METRIC_THRESHOLD = 1000.0    # detectSURFFeatures' default
 
 
@@ -37,6 +37,14 @@ class SURFPoints(cornerPoints):
         self.Scale = Scale
 
 
+class BRISKPoints(cornerPoints):
+    """Location, Metric and Scale (the scale-space level of the keypoint in units of the image's pixel)."""
+
+    def __init__(self, Location, Metric, Scale):
+        cornerPoints.__init__(self, Location, Metric)
+        self.Scale = Scale
+
+
 def _options(options):
     """MATLAB name-value cell {'MinQuality', 2e-4, ...} as list/tuple or dict."""
     if options is None:
@@ -49,7 +57,8 @@ def _options(options):
     return {opts[i]: opts[i + 1] for i in range(0, len(opts), 2)}
 
 
-def _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap, min_contrast, metric_threshold):
+def _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap, min_contrast, metric_threshold,
+                         num_octaves=4):
     """Detection on a uint8 image already resident on the GPU (an object with data_ptr() and
     shape, row-major): only the keypoint list crosses the bus."""
     import torch
@@ -66,6 +75,10 @@ def _detect_device_image(ctx, image, min_quality, filter_size, border, method, c
         ctx.check(_lib.load().vohip_detect_surf_dev(ctx.handle, image.data_ptr(), rows, cols, 0, metric_threshold, border,
                                                     xy.data_ptr(), metric.data_ptr(), scratch["scale"].data_ptr(), cap,
                                                     count.data_ptr()))
+    elif method == "BRISK":
+        ctx.check(_lib.load().vohip_detect_brisk_dev(ctx.handle, image.data_ptr(), rows, cols, 0, min_contrast, min_quality,
+                                                     num_octaves, border, xy.data_ptr(), metric.data_ptr(),
+                                                     scratch["scale"].data_ptr(), cap, count.data_ptr()))
     elif method == "FAST":
         ctx.check(_lib.load().vohip_detect_fast_dev(ctx.handle, image.data_ptr(), rows, cols, 0, min_contrast, min_quality,
                                                     border, xy.data_ptr(), metric.data_ptr(), cap, count.data_ptr()))
@@ -78,8 +91,9 @@ def _detect_device_image(ctx, image, min_quality, filter_size, border, method, c
     if total > cap:
         raise _lib.VohipError(_lib.VOHIP_CAPACITY_EXCEEDED, "%d corners found, capacity %d" % (total, cap))
     loc = torch.stack([xy[:total], xy[cap:cap + total]], dim=1).cpu().numpy()
-    if method == "SURF":
-        return SURFPoints(loc, metric[:total].cpu().numpy(), scratch["scale"][:total].cpu().numpy())
+    if method in ("SURF", "BRISK"):
+        return (SURFPoints if method == "SURF" else BRISKPoints)(loc, metric[:total].cpu().numpy(),
+                                                                scratch["scale"][:total].cpu().numpy())
     return cornerPoints(loc, metric[:total].cpu().numpy())
 
 
@@ -148,11 +162,12 @@ def genKeypoints(image, method="SURF", options=None, ctx=None, with_features=Fal
 
     method 'SURF' (the default, as in genKeypoints.m:3-5) with options {'MetricThreshold', t}
     (main_eval.m:151,167), 'Harris' or 'MinEigen' with {'MinQuality', q, 'FilterSize', 5}, or 'FAST' with
-    {'MinContrast', c, 'MinQuality', q} (main_eval.m:172-173).  Two extra options have no MATLAB
+    {'MinContrast', c, 'MinQuality', q} (main_eval.m:172-173), or 'BRISK' with {'MinContrast', c, 'MinQuality', q,
+    'NumOctaves', n} (main_eval.m:170-171).  Two extra options have no MATLAB
     counterpart: 'Border' (default 16) and 'Capacity'.  `features` is None (the continuous-operation loop never
     reads it, main_demo.m:377 discards it) unless with_features is set, as the 'Des_match' bootstrap branch does
     (matching_init.m:26-27): then the SURF descriptors of extractFeatures (SURF points only).  The other detectors
-    of the reference's table (BRISK, ORB, SIFT) are closed-source toolbox functions
+    of the reference's table (ORB, SIFT) are closed-source toolbox functions
     that are not rebuilt here."""
     if method not in DETECTORS:
         raise NotImplementedError("genKeypoints: method '%s' is not built natively (%s are)"
@@ -160,7 +175,8 @@ def genKeypoints(image, method="SURF", options=None, ctx=None, with_features=Fal
     ctx = ctx or _lib.default_context()
     opts = _options(options)
     min_quality = float(opts.pop("MinQuality", DEFAULT_MIN_QUALITY[method])) if method != "SURF" else 0.0
-    min_contrast = float(opts.pop("MinContrast", 0.2)) if method == "FAST" else 0.0
+    min_contrast = float(opts.pop("MinContrast", 0.2)) if method in ("FAST", "BRISK") else 0.0
+    num_octaves = int(opts.pop("NumOctaves", 4)) if method == "BRISK" else 4
     metric_threshold = float(opts.pop("MetricThreshold", DEFAULT_METRIC_THRESHOLD)) if method == "SURF" else 0.0
     filter_size = int(opts.pop("FilterSize", 5)) if method in ("Harris", "MinEigen") else 5
     border = int(opts.pop("Border", DEFAULT_BORDER))
@@ -172,7 +188,7 @@ def genKeypoints(image, method="SURF", options=None, ctx=None, with_features=Fal
         return extractFeatures(image, points, ctx=ctx)                       # genKeypoints.m:32
     if hasattr(image, "data_ptr"):
         return None, _detect_device_image(ctx, image, min_quality, filter_size, border, method, cap, min_contrast,
-                                          metric_threshold)
+                                          metric_threshold, num_octaves)
     img = np.asarray(image)
     if img.dtype != np.uint8 or img.ndim != 2:
         raise TypeError("image must be a 2-D uint8 array")
@@ -190,6 +206,14 @@ def genKeypoints(image, method="SURF", options=None, ctx=None, with_features=Fal
             scale.ctypes.data_as(_lib.c_float_p), cap, C.byref(n)))
         k = n.value
         return None, SURFPoints(np.stack([xy[:k], xy[k:2 * k]], axis=1).copy(), metric[:k].copy(), scale[:k].copy())
+    if method == "BRISK":
+        scale = np.zeros(cap, dtype=np.float32)
+        ctx.check(_lib.load().vohip_detect_brisk(
+            ctx.handle, img.ctypes.data_as(_lib.c_uint8_p), img.shape[0], img.shape[1], int(colmajor), min_contrast,
+            min_quality, num_octaves, border, xy.ctypes.data_as(_lib.c_float_p), metric.ctypes.data_as(_lib.c_float_p),
+            scale.ctypes.data_as(_lib.c_float_p), cap, C.byref(n)))
+        k = n.value
+        return None, BRISKPoints(np.stack([xy[:k], xy[k:2 * k]], axis=1).copy(), metric[:k].copy(), scale[:k].copy())
     if method == "FAST":
         ctx.check(_lib.load().vohip_detect_fast(
             ctx.handle, img.ctypes.data_as(_lib.c_uint8_p), img.shape[0], img.shape[1], int(colmajor), min_contrast,
