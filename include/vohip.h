@@ -230,7 +230,7 @@ typedef struct vohip_frame vohip_frame;
 typedef struct vohip_frame_params {
     int klt_block, klt_levels, klt_max_iter;   /* vision.PointTracker arguments, main_demo.m:342-343 */
     double klt_max_bidir_error;
-    int detector;                              /* 0 Harris, 1 MinEigen, 2 FAST, 3 SURF (genKeypoints.m:16-19,31-32) */
+    int detector;                              /* 0 Harris, 1 MinEigen, 2 FAST, 3 SURF, 4 BRISK (genKeypoints.m:16-20,31-32) */
     double min_quality;
     int filter_size, border;
     double r_discard_redundant;                /* hyper_paras, main_demo.m:36-43, 72-75 */
@@ -245,6 +245,7 @@ typedef struct vohip_frame_params {
                                                   reprojection errors below 100 px in both views */
     double min_contrast;                       /* detector 2: detectFASTFeatures' 'MinContrast' (main_eval.m:172-173) */
     double metric_threshold;                   /* detector 3: detectSURFFeatures' 'MetricThreshold' (main_eval.m:151,167) */
+    int brisk_octaves;                         /* detector 4: detectBRISKFeatures' 'NumOctaves' (with min_contrast and min_quality) */
 } vohip_frame_params;
 
 typedef struct vohip_frame_pose {
@@ -337,8 +338,8 @@ int vohip_frame_state(vohip_frame *f, double *P_rc, double *X, double *ids, doub
  * The sequences are stored ones: vohip_group_prepare copies sequence `seq`'s n images (n <= max_frames;
  * image 0 is the one the loop is reset on, main_demo.m:342-344, images 1.. are the loop's frames) to the
  * device and makes all their pyramids and corner lists by batched launches, as vohip_frame_prepare does
- * (detector < 0: the group's detector and thresholds; else 0 Harris / 1 MinEigen / 2 FAST / 3 SURF with
- * min_quality and the detector's other threshold in the last argument -- FAST's 'MinContrast', SURF's
+ * (detector < 0: the group's detector and thresholds; else 0 Harris / 1 MinEigen / 2 FAST / 3 SURF / 4 BRISK with
+ * min_quality and the detector's other threshold in the last argument -- FAST's and BRISK's 'MinContrast', SURF's
  * 'MetricThreshold': the feature variants of main_eval.m:165-174 may share a group, the loop only reads the
  * corner lists).
  * vohip_group_reset gives sequence `seq` its initial state (as vohip_frame_reset; the image is prepared

@@ -300,6 +300,46 @@ def test_device_loop_with_surf_detector_matches_cpu_restatement(vo, ctx, oracle,
         d.close()
 
 
+def test_device_loop_with_brisk_detector_matches_cpu_restatement(vo, ctx, oracle, sequence):
+    """The 'BRISK' feature variant of main_eval.m:170-171 ({'MinQuality', 2e-3}) through the whole loop: keypoints of
+    eight scale-space layers as starting points and candidates.  Bar as for the other detectors; the look-ahead and
+    the prepared form bit-identical to the plain one."""
+    from oracle import pipeline_oracle as po
+    scene, poses, frames = sequence
+    hp = vo.default_hyper_paras("kitti")
+    hp.feature_extract = "BRISK"
+    hp.feature_extract_options = ["MinQuality", 2e-3]
+    ab, _, _, total = oracle.detect_brisk(frames[0], 0.2, 2e-3, 4, 16)
+    assert total > 200
+    xy = (ab + 1.0).astype(np.float64)
+    X0 = scene.backproject(poses[0], xy)
+    ref = po.OraclePipeline(K, frames[0], X0, xy, poses[0], hp, 3, 2, np.random.default_rng(7), vo.draw_triples,
+                            vo.draw_octets)
+    dev = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(7), ctx=ctx)
+    ahead = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(7), ctx=ctx)
+    stored = vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=hp, rng=np.random.default_rng(7), ctx=ctx)
+    stored.prepare(frames[1:8])
+    for i in range(1, 7):
+        Tr = ref.process_frame(frames[i])
+        Td = dev.process_frame(frames[i])
+        Ta = ahead.process_frame(frames[i], next_image=frames[i + 1])
+        Ts = stored.process_frame(frames[i], next_image=frames[i + 1])
+        np.testing.assert_array_equal(Ta, Td)
+        np.testing.assert_array_equal(Ts, Td)
+        assert dev.num_X[-1] == ref.S.num_X[-1] and dev.num_C[-1] == ref.S.num_C[-1], i
+        assert dev.last_counts.n_detected == ahead.last_counts.n_detected == stored.last_counts.n_detected > 100
+        assert np.linalg.norm(Tr[:3, 3] - Td[:3, 3]) < 1e-5, i
+        dR = Tr[:3, :3].T @ Td[:3, :3]
+        assert np.arccos(np.clip((np.trace(dR) - 1) / 2, -1, 1)) < 1e-5, i
+        assert np.linalg.norm(Td[:3, 3] - poses[i][:3, 3]) < 0.25, i
+    np.testing.assert_array_equal(dev.S.X[3], ref.S.X[3])
+    np.testing.assert_array_equal(dev.S.C, ahead.S.C)
+    np.testing.assert_array_equal(dev.S.C, stored.S.C)
+    assert dev.num_C[-1] > 0
+    for d in (dev, ahead, stored):
+        d.close()
+
+
 def test_device_loop_accepts_device_images_and_reports_errors(vo, ctx, oracle, sequence):
     import torch
     scene, poses, frames = sequence

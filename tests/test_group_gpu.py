@@ -125,14 +125,14 @@ def test_group_retries_one_sequence_alone(vo, ctx, oracle, worlds):
 
 
 def test_group_feature_variants_and_a_sequence_that_stops(vo, ctx, oracle, worlds):
-    """Harris, MinEigen, FAST and SURF sequences in one group (main_eval.m:165-174: the loop only reads the corner lists),
+    """Harris, MinEigen, FAST, SURF and BRISK sequences in one group (main_eval.m:165-174: the loop only reads the corner lists),
     and a sequence whose localisation finds no pose (landmarks that fit no camera): it stops with the single
     loop's error while the others run on unchanged."""
     hp = vo.default_hyper_paras("kitti")
     feats = [("Harris", ["MinQuality", 2e-4]), ("MinEigen", ["MinQuality", 2e-3]), ("Harris", ["MinQuality", 2e-4]),
-             ("FAST", ["MinContrast", 0.11]), ("SURF", ["MetricThreshold", 200])]
+             ("FAST", ["MinContrast", 0.11]), ("SURF", ["MetricThreshold", 200]), ("BRISK", ["MinQuality", 2e-3])]
     specs = []
-    for s in range(5):
+    for s in range(6):
         scene, poses, frames = worlds[s % 3]
         frames = frames[:6]
         X0, xy = _start(oracle, scene, poses, frames, thin=500, seed=20 + s)
@@ -141,8 +141,8 @@ def test_group_feature_variants_and_a_sequence_that_stops(vo, ctx, oracle, world
         specs.append((frames, X0, xy, poses[0], 60 + s))
     refs = [_single(vo, ctx, hp, *sp, feat=feats[s]) for s, sp in enumerate(specs)]
     assert refs[2]["err"] is not None and refs[0]["err"] is None and refs[1]["err"] is None
-    assert refs[3]["err"] is None and refs[4]["err"] is None
-    group = vo.VOGroupDevice(K, (H, W), 5, 6, hyper_paras=hp, ctx=ctx)
+    assert refs[3]["err"] is None and refs[4]["err"] is None and refs[5]["err"] is None
+    group = vo.VOGroupDevice(K, (H, W), 6, 6, hyper_paras=hp, ctx=ctx)
     for s, (frames, X0, xy, T0, seed) in enumerate(specs):
         fo = dict(zip(feats[s][1][::2], feats[s][1][1::2]))
         group.add_sequence(s, frames, X0, xy, T0, rng=np.random.default_rng(seed), feature_extract=feats[s][0],
@@ -151,7 +151,7 @@ def test_group_feature_variants_and_a_sequence_that_stops(vo, ctx, oracle, world
     group.run()
     assert group.seqs[2].error is not None and type(group.seqs[2].error) is type(refs[2]["err"])
     assert len(group.seqs[2].est_trans) == len(refs[2]["T"]) + 1
-    for s in (0, 1, 3, 4):
+    for s in (0, 1, 3, 4, 5):
         assert group.seqs[s].error is None
         _compare(group, s, refs[s])
     group.close()

@@ -46,7 +46,7 @@ class FrameParams(C.Structure):
                 ("fm_threshold", C.c_double), ("fm_confidence", C.c_double), ("cap_landmarks", C.c_int),
                 ("cap_candidates", C.c_int), ("cap_corners", C.c_int), ("max_hypotheses", C.c_int),
                 ("slot_a", C.c_int), ("slot_b", C.c_int), ("slot_c", C.c_int), ("is_BA", C.c_int),
-                ("min_contrast", C.c_double), ("metric_threshold", C.c_double)]
+                ("min_contrast", C.c_double), ("metric_threshold", C.c_double), ("brisk_octaves", C.c_int)]
 
 
 class FramePose(C.Structure):

@@ -938,8 +938,9 @@ size_t layout(vohip_frame *f, char *base)
     f->F2 = carve<double>(p, 2 * C);
     f->T2 = carve<double>(p, 12 * C);
     f->Xnew = carve<double>(p, 3 * C);
-    f->corner_scratch = carve<char>(p, f->prm.detector == 3 ? vohip_surf_scratch_bytes(f->rows, f->cols)   // (first: zero from the start)
-                                                             : vohip_corner_scratch_bytes(f->rows, f->cols));
+    f->corner_scratch = carve<char>(p, f->prm.detector == 3   ? vohip_surf_scratch_bytes(f->rows, f->cols)   // (first: zero from the start)
+                                       : f->prm.detector == 4 ? vohip_brisk_scratch_bytes(f->rows, f->cols)
+                                                              : vohip_corner_scratch_bytes(f->rows, f->cols));
     f->Rt_all = carve<double>(p, 48 * H);
     f->M_all = carve<double>(p, 48 * H);
     f->u8 = carve<double>(p, 8 * T);
@@ -968,7 +969,7 @@ size_t layout(vohip_frame *f, char *base)
 
 inline int blocks256(int n) { return n < 1 ? 1 : (n + 255) / 256; }
 
-// The one threshold option a detector has beside MinQuality: FAST's 'MinContrast', SURF's 'MetricThreshold'.
+// The one threshold option a detector has beside MinQuality: FAST's and BRISK's 'MinContrast', SURF's 'MetricThreshold'.
 inline double detector_option(const vohip_frame_params &p) { return p.detector == 3 ? p.metric_threshold : p.min_contrast; }
 
 struct stream_swap {
@@ -1108,7 +1109,8 @@ int enqueue_detection(vohip_frame *f, const uint8_t *d_img, int par, hipEvent_t 
     if (ready) VOHIP_HIP(ctx, hipStreamWaitEvent(s, ready, 0));   // (NULL: the image was on the device all along)
     VOHIP_TRY(vohip_detect_corners_enqueue(ctx, s, f->corner_scratch, &f->det_calls, d_img, f->rows, f->cols,
                                            f->colmajor, p.min_quality, p.filter_size, p.border, p.detector,
-                                           detector_option(p), f->corner_xy[par], f->corner_metric[par], f->capK, f->cnt + N_DET + par));
+                                           detector_option(p), f->corner_xy[par], f->corner_metric[par], f->capK, f->cnt + N_DET + par,
+                                           p.brisk_octaves));
     hipLaunchKernelGGL(detection_rows_kernel, dim3(blocks256(f->capK)), dim3(256), 0, s, f->corner_xy[par], f->capK,
                        f->cnt + N_DET + par, f->capL + f->capC, f->capU, f->U_xy[par], f->U_live[par]);
     VOHIP_HIP(ctx, hipGetLastError());
@@ -1387,6 +1389,7 @@ void vohip_frame_default_params(vohip_frame_params *p)
     p->is_BA = 0;
     p->min_contrast = 0.2;        // detectFASTFeatures' default
     p->metric_threshold = 1000.0; // detectSURFFeatures' default
+    p->brisk_octaves = 4;         // detectBRISKFeatures' default
 }
 
 int vohip_frame_create(vohip_ctx *ctx, const double K[9], int rows, int cols, int colmajor,
@@ -1876,7 +1879,7 @@ int vohip_frame_prepare(vohip_frame *f, const uint8_t *const *images, int n, int
             VOHIP_TRY(vohip_detect_corners_batch_enqueue(ctx, f->prep_imgs + img_bytes * c, m, f->rows, f->cols, f->colmajor,
                                                          p.min_quality, p.filter_size, p.border, p.detector,
                                                          xy + 2 * (size_t)f->capK * c, f->prep_metric + (size_t)f->capK * c, f->capK,
-                                                         f->prep_counts + c, detector_option(p)));
+                                                         f->prep_counts + c, detector_option(p), p.brisk_octaves));
         }
     }
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
@@ -2107,7 +2110,7 @@ int vohip_group_prepare(vohip_group *g, int seq, const uint8_t *const *images, i
         min_quality = p.min_quality;
         min_contrast = detector_option(p);
     }
-    VOHIP_REQUIRE(ctx, detector >= 0 && detector <= 3, "detector: 0 = Harris, 1 = MinEigen, 2 = FAST, 3 = SURF");
+    VOHIP_REQUIRE(ctx, detector >= 0 && detector <= 4, "detector: 0 = Harris, 1 = MinEigen, 2 = FAST, 3 = SURF, 4 = BRISK");
     const size_t img_bytes = (size_t)f->rows * f->cols;
     uint8_t *imgs = prep_of_seq(f, f->prep_imgs, seq);
     for (int k = 0; k < n; ++k) {
@@ -2123,7 +2126,7 @@ int vohip_group_prepare(vohip_group *g, int seq, const uint8_t *const *images, i
         const int m = n - c < chunk ? n - c : chunk;
         VOHIP_TRY(vohip_detect_corners_batch_enqueue(ctx, imgs + img_bytes * c, m, f->rows, f->cols, f->colmajor, min_quality,
                                                      p.filter_size, p.border, detector, xy + 2 * (size_t)f->capK * c,
-                                                     metric + (size_t)f->capK * c, f->capK, counts + c, min_contrast));
+                                                     metric + (size_t)f->capK * c, f->capK, counts + c, min_contrast, p.brisk_octaves));
     }
     VOHIP_HIP(ctx, hipStreamSynchronize(s));
     f->seqs[seq].n_frames = n;
@@ -2139,7 +2142,7 @@ int vohip_group_prepare_like(vohip_group *g, int seq, int from_seq, int detector
     vohip_ctx *ctx = f->ctx;
     VOHIP_REQUIRE(ctx, seq != from_seq && f->seqs[from_seq].n_frames >= 2, "the other sequence must be a prepared one");
     VOHIP_REQUIRE(ctx, !f->g_inflight, "a frame is in flight (vohip_group_finish)");
-    VOHIP_REQUIRE(ctx, detector >= -2 && detector <= 3, "detector: -2 = the other sequence's corner lists, -1 = the group's, 0..3");
+    VOHIP_REQUIRE(ctx, detector >= -2 && detector <= 4, "detector: -2 = the other sequence's corner lists, -1 = the group's, 0..4");
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const vohip_frame_params &p = f->prm;
@@ -2169,7 +2172,7 @@ int vohip_group_prepare_like(vohip_group *g, int seq, int from_seq, int detector
             const int m = n - c < chunk ? n - c : chunk;
             VOHIP_TRY(vohip_detect_corners_batch_enqueue(ctx, imgs + img_bytes * c, m, f->rows, f->cols, f->colmajor, min_quality,
                                                          p.filter_size, p.border, detector, xy + 2 * (size_t)f->capK * c,
-                                                         metric + (size_t)f->capK * c, f->capK, counts + c, min_contrast));
+                                                         metric + (size_t)f->capK * c, f->capK, counts + c, min_contrast, p.brisk_octaves));
         }
     }
     VOHIP_HIP(ctx, hipStreamSynchronize(s));

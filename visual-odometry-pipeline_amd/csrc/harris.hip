@@ -491,14 +491,18 @@ size_t vohip_corner_scratch_bytes(int rows, int cols)
 // counts the uses of this scratch (the two maximum slots alternate: a call clears the other one).
 int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, unsigned *calls, const uint8_t *d_img,
                                  int rows, int cols, int colmajor, double min_quality, int filter_size, int border,
-                                 int method, double min_contrast, float *d_xy, float *d_metric, int cap, int *d_count)
+                                 int method, double min_contrast, float *d_xy, float *d_metric, int cap, int *d_count,
+                                 int brisk_octaves)
 {
     VOHIP_REQUIRE(ctx, d_img && d_xy && d_metric && d_count && scratch && calls, "NULL argument");
     if (method == 3)   // SURF: `min_contrast` carries 'MetricThreshold', the scratch is vohip_surf_scratch_bytes(rows, cols) long
         return vohip_detect_surf_enqueue(ctx, st, scratch, d_img, rows, cols, colmajor, min_contrast, border, d_xy, d_metric,
                                          nullptr, cap, d_count);
+    if (method == 4)   // BRISK: the scratch is vohip_brisk_scratch_bytes(rows, cols) long
+        return vohip_detect_brisk_enqueue(ctx, st, scratch, d_img, rows, cols, colmajor, min_contrast, min_quality, brisk_octaves,
+                                          border, d_xy, d_metric, nullptr, cap, d_count);
     VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
-    VOHIP_REQUIRE(ctx, method >= 0 && method <= 2, "method: 0 = Harris, 1 = MinEigen, 2 = FAST, 3 = SURF");
+    VOHIP_REQUIRE(ctx, method >= 0 && method <= 2, "method: 0 = Harris, 1 = MinEigen, 2 = FAST, 3 = SURF, 4 = BRISK");
     VOHIP_REQUIRE(ctx, method == 2 || filter_size == FS, "only FilterSize 5 (the toolbox default) is built");
     VOHIP_REQUIRE(ctx, method != 2 || (min_contrast > 0.0 && min_contrast < 1.0), "MinContrast must lie in (0, 1)");
     VOHIP_REQUIRE(ctx, cap >= 1 && cap <= 16384, "cap must be 1..16384");
@@ -542,15 +546,18 @@ int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, 
 // counts, maximum and output lists, so the lists are those of n single calls, bit for bit.
 int vohip_detect_corners_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
                                        double min_quality, int filter_size, int border, int method, float *d_xy,
-                                       float *d_metric, int cap, int *d_counts, double min_contrast)
+                                       float *d_metric, int cap, int *d_counts, double min_contrast, int brisk_octaves)
 {
     VOHIP_REQUIRE(ctx, d_imgs && d_xy && d_metric && d_counts, "NULL argument");
     VOHIP_REQUIRE(ctx, n >= 1 && n <= 65535, "1..65535 images per call");
     if (method == 3)   // SURF: `min_contrast` carries 'MetricThreshold'
         return vohip_detect_surf_batch_enqueue(ctx, d_imgs, n, rows, cols, colmajor, min_contrast, border, d_xy, d_metric, cap,
                                                d_counts);
+    if (method == 4)
+        return vohip_detect_brisk_batch_enqueue(ctx, d_imgs, n, rows, cols, colmajor, min_contrast, min_quality, brisk_octaves,
+                                                border, d_xy, d_metric, cap, d_counts);
     VOHIP_REQUIRE(ctx, rows >= 8 && cols >= 8, "image too small");
-    VOHIP_REQUIRE(ctx, method >= 0 && method <= 2, "method: 0 = Harris, 1 = MinEigen, 2 = FAST, 3 = SURF");
+    VOHIP_REQUIRE(ctx, method >= 0 && method <= 2, "method: 0 = Harris, 1 = MinEigen, 2 = FAST, 3 = SURF, 4 = BRISK");
     VOHIP_REQUIRE(ctx, method == 2 || filter_size == FS, "only FilterSize 5 (the toolbox default) is built");
     VOHIP_REQUIRE(ctx, method != 2 || (min_contrast > 0.0 && min_contrast < 1.0), "MinContrast must lie in (0, 1)");
     VOHIP_REQUIRE(ctx, cap >= 1 && cap <= 16384, "cap must be 1..16384");

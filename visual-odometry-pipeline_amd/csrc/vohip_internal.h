@@ -202,12 +202,14 @@ int vohip_candidate_triangulate_enqueue(vohip_ctx *ctx, const double *d_cur_rc, 
 size_t vohip_corner_scratch_bytes(int rows, int cols);
 int vohip_detect_corners_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, unsigned *calls, const uint8_t *d_img,
                                  int rows, int cols, int colmajor, double min_quality, int filter_size, int border,
-                                 int method, double min_contrast, float *d_xy, float *d_metric, int cap, int *d_count);
+                                 int method, double min_contrast, float *d_xy, float *d_metric, int cap, int *d_count,
+                                 int brisk_octaves = 4);
 // Slot `slot` shows the pyramid at d_pyr (layout of vohip_pyramid_batch_dev) until the slot is built again; nothing is copied.
 int vohip_pyramid_attach(vohip_ctx *ctx, int slot, const float *d_pyr, int rows, int cols, int colmajor, int levels);
 int vohip_detect_corners_batch_enqueue(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
                                        double min_quality, int filter_size, int border, int method, float *d_xy,
-                                       float *d_metric, int cap, int *d_counts, double min_contrast = 0.2);
+                                       float *d_metric, int cap, int *d_counts, double min_contrast = 0.2,
+                                       int brisk_octaves = 4);
 // SURF (detector 3): scratch of a single image; detection on `st` with caller-owned scratch; a stored sequence.
 size_t vohip_surf_scratch_bytes(int rows, int cols);
 int vohip_detect_surf_enqueue(vohip_ctx *ctx, hipStream_t st, void *scratch, const uint8_t *d_img, int rows, int cols,

@@ -289,6 +289,7 @@ def run_group(runs, ctx=None, group=None, n_slots=None, max_frames=None):
 
 
 EVAL_FEATURE_OPTIONS = {"SURF": ["MetricThreshold", 200],     # main_eval.m:166-167
+                        "BRISK": ["MinQuality", 2e-3],       # main_eval.m:170-171
                         "Harris": ["MinQuality", 2e-4],      # main_eval.m:168-169
                         "MinEigen": ["MinQuality", 1e-2],    # genKeypoints.m:18 (no entry in main_eval's switch)
                         "FAST": ["MinContrast", 0.11]}       # main_eval.m:172-173

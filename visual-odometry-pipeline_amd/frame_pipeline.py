@@ -53,6 +53,7 @@ class VOPipelineDevice:
         prm.min_quality = float(fo.get("MinQuality", DEFAULT_MIN_QUALITY[self.hp.feature_extract]))
         prm.min_contrast = float(fo.get("MinContrast", 0.2))
         prm.metric_threshold = float(fo.get("MetricThreshold", 1000.0))
+        prm.brisk_octaves = int(fo.get("NumOctaves", 4))
         prm.filter_size = int(fo.get("FilterSize", 5))
         prm.r_discard_redundant = float(self.hp.r_discard_redundant)
         prm.angle_threshold_deg = float(self.hp.angle_threshold)
@@ -361,6 +362,7 @@ class VOGroupDevice:
         prm.min_quality = float(fo.get("MinQuality", DEFAULT_MIN_QUALITY[self.hp.feature_extract]))
         prm.min_contrast = float(fo.get("MinContrast", 0.2))
         prm.metric_threshold = float(fo.get("MetricThreshold", 1000.0))
+        prm.brisk_octaves = int(fo.get("NumOctaves", 4))
         prm.filter_size = int(fo.get("FilterSize", 5))
         prm.r_discard_redundant = float(self.hp.r_discard_redundant)
         prm.angle_threshold_deg = float(self.hp.angle_threshold)

@@ -50,6 +50,7 @@ classdef FrameGroup < handle
                     case 'MinEigen', det = 1; mq = 0.01;
                     case 'FAST',     det = 2; mq = 0.1;
                     case 'SURF',     det = 3; mq = 0; mc = 1000;   % (the last argument then carries MetricThreshold)
+                    case 'BRISK',    det = 4; mq = 0.1;
                     otherwise, error('vohip:FrameGroup', 'detector %s is not built natively', feature_extract);
                 end
                 if nargin > 7 && isfield(feature_params, 'MinQuality'), mq = feature_params.MinQuality; end

@@ -40,6 +40,9 @@ classdef FrameLoop < handle
                     case 'FAST',     p.detector = 2;
                         if ~isfield(p, 'min_quality'), p.min_quality = 0.1; end   % detectFASTFeatures' default
                     case 'SURF',     p.detector = 3;                              % genKeypoints.m:16
+                    case 'BRISK',    p.detector = 4;                              % genKeypoints.m:20
+                        if ~isfield(p, 'min_quality'), p.min_quality = 0.1; end   % detectBRISKFeatures' default
+                        if nargin > 3 && isfield(feature_params, 'NumOctaves'), p.brisk_octaves = feature_params.NumOctaves; end
                     otherwise, error('vohip:FrameLoop', 'detector %s is not built natively', hyper_paras.feature_extract);
                 end
             end

@@ -129,6 +129,7 @@ static void frame_params_from_struct(const mxArray *st, vohip_frame_params &p)
     p.is_BA = (int)field("is_BA", p.is_BA);
     p.min_contrast = field("min_contrast", p.min_contrast);
     p.metric_threshold = field("metric_threshold", p.metric_threshold);
+    p.brisk_octaves = (int)field("brisk_octaves", p.brisk_octaves);
 }
 
 // info struct array (1 x n) of the 'group_step' opcode, same fields as frame_outputs'
@@ -338,6 +339,25 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         mxFree(xy);
         mxFree(metric);
         mxFree(scale);
+    } else if (is("detect_brisk")) {
+        // [Location, Metric, Scale] = vohip_mex('detect_brisk', image uint8, min_contrast, min_quality, num_octaves, border)
+        if (!mxIsUint8(in[0])) mexErrMsgIdAndTxt("vohip:type", "image must be uint8");
+        const int cap = 16384;
+        float *xy = scratch<float>((size_t)2 * cap), *metric = scratch<float>((size_t)cap), *scale = scratch<float>((size_t)cap);
+        int n = 0;
+        check(vohip_detect_brisk(c, mxGetUint8s(in[0]), rows(in[0]), cols(in[0]), 1, mxGetScalar(in[1]), mxGetScalar(in[2]),
+                                 (int)mxGetScalar(in[3]), (int)mxGetScalar(in[4]), xy, metric, scale, cap, &n));
+        plhs[0] = mxCreateNumericMatrix(n, 2, mxSINGLE_CLASS, mxREAL);
+        plhs[1] = mxCreateNumericMatrix(n, 1, mxSINGLE_CLASS, mxREAL);
+        std::memcpy(mxGetSingles(plhs[0]), xy, sizeof(float) * 2 * n);   // n x 2, x column then y column
+        std::memcpy(mxGetSingles(plhs[1]), metric, sizeof(float) * n);
+        if (nlhs > 2) {
+            plhs[2] = mxCreateNumericMatrix(n, 1, mxSINGLE_CLASS, mxREAL);
+            std::memcpy(mxGetSingles(plhs[2]), scale, sizeof(float) * n);
+        }
+        mxFree(xy);
+        mxFree(metric);
+        mxFree(scale);
     } else if (is("surf_features")) {
         // [features (N x 64 single), orientation] = vohip_mex('surf_features', image uint8, Location (N x 2 single), Scale, upright)
         if (!mxIsUint8(in[0]) || !mxIsSingle(in[1]) || !mxIsSingle(in[2]))
@@ -406,7 +426,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         // vohip_mex('frame_create', K, rows, cols, params struct): the loop body of main_demo.m:377-427 as
         // one call per frame, state resident on the GPU (one loop per MATLAB session).  params fields
         // (all optional): r_discard_redundant, angle_threshold_deg, min_depth, max_depth, min_quality,
-        // filter_size, detector, min_contrast, metric_threshold, refine_pose, is_BA.
+        // filter_size, detector, min_contrast, metric_threshold, brisk_octaves, refine_pose, is_BA.
         if (g_frame) { vohip_frame_destroy(g_frame); g_frame = nullptr; }
         vohip_frame_params p;
         vohip_frame_default_params(&p);
@@ -543,7 +563,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                                  (int)mxGetScalar(in[5]), &g_group));
     } else if (is("group_prepare")) {
         // vohip_mex('group_prepare', seq (1-based), images (cell array of uint8; the first is the image the loop is
-        // reset on, main_demo.m:342-344), detector (-1: the group's, 0 Harris, 1 MinEigen, 2 FAST, 3 SURF), min_quality, min_contrast (SURF: metric_threshold))
+        // reset on, main_demo.m:342-344), detector (-1: the group's, 0 Harris, 1 MinEigen, 2 FAST, 3 SURF, 4 BRISK), min_quality, min_contrast (SURF: metric_threshold))
         // vohip_mex('group_prepare', seq, from_seq (a sequence that holds the same images), detector, min_quality, min_contrast)
         if (!g_group) mexErrMsgIdAndTxt("vohip:usage", "group_create first");
         const int seq = (int)mxGetScalar(in[0]) - 1;
