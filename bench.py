@@ -323,7 +323,7 @@ def bench_main_eval(vo, ctx, frames, poses, concurrent=1, group=0, feats=("Harri
     seq = dict(name="kitti", images=frames, K=vo.synth.K_KITTI,
                ground_truth=np.array([[T[0, 3], T[2, 3]] for T in poses[:len(frames)]]))
     short = dict(seq, images=frames[:12])
-    vo.main_eval([short], feats=("Harris", "FAST") if "SURF" not in feats else ("SURF", "FAST"),
+    vo.main_eval([short], feats=("Harris", "FAST") if "SURF" not in feats else feats,
                  repetition=2 if group and concurrent > 1 else 1, seed=10, ctx=ctx,
                  concurrent=concurrent, group=min(group, 2) if concurrent > 1 else group)   # code objects, staging buffers
     t0 = time.perf_counter()
@@ -486,13 +486,17 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
         ctx.check(lib.vohip_detect_fast_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 0.11, 0.1, 16,
                                             d_xy.data_ptr(), d_metric.data_ptr(), cap, d_count.data_ptr()))
 
+    def detect_brisk():   # main_eval.m:170-171
+        ctx.check(lib.vohip_detect_brisk_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 0.2, 2e-3, 4, 16, d_xy.data_ptr(),
+                                             d_metric.data_ptr(), None, cap, d_count.data_ptr()))
+
     def detect_surf():   # main_eval.m:166-167
         ctx.check(lib.vohip_detect_surf_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 200.0, 16, d_xy.data_ptr(),
                                             d_metric.data_ptr(), None, cap, d_count.data_ptr()))
 
     out = {}
     for name, fn in (("pyramid_build", build), ("fast_detection", detect_fast), ("surf_detection", detect_surf),
-                     ("corner_detection", detect)):
+                     ("brisk_detection", detect_brisk), ("corner_detection", detect)):
         fn()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -506,6 +510,8 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
             n_fast = min(int(d_count.item()), cap)
         if name == "surf_detection":
             n_surf = min(int(d_count.item()), cap)
+        if name == "brisk_detection":
+            n_brisk = min(int(d_count.item()), cap)
     px = float(rows * cols)
     levels = sum(0.25 ** l for l in range(5))
     n_corners = min(int(d_count.item()), cap)
@@ -530,12 +536,17 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
         ctx.check(lib.vohip_detect_corners_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 2e-4, 5, 16, 0,
                                                      b_xy.data_ptr(), b_metric.data_ptr(), cap, b_counts.data_ptr()))
 
+    def detect_brisk_batch():
+        ctx.check(lib.vohip_detect_brisk_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 0.2, 2e-3, 4, 16,
+                                                   b_xy.data_ptr(), b_metric.data_ptr(), cap, b_counts.data_ptr()))
+
     def detect_surf_batch():
         ctx.check(lib.vohip_detect_surf_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 200.0, 16,
                                                   b_xy.data_ptr(), b_metric.data_ptr(), cap, b_counts.data_ptr()))
 
     batched = {}
-    for name, fn in (("pyramid_build", build_batch), ("surf_detection", detect_surf_batch), ("corner_detection", detect_batch)):
+    for name, fn in (("pyramid_build", build_batch), ("surf_detection", detect_surf_batch),
+                     ("brisk_detection", detect_brisk_batch), ("corner_detection", detect_batch)):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -548,6 +559,8 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
         batched[name] = ev0.elapsed_time(ev1) / 5
         if name == "surf_detection":
             surf_b = float(torch.clamp(b_counts, max=cap).sum().item())
+        if name == "brisk_detection":
+            brisk_b = float(torch.clamp(b_counts, max=cap).sum().item())
     corners_b = float(torch.clamp(b_counts, max=cap).sum().item())
     bytes_det_b = px * nb + 8.0 * corners_b
     # SURF per image: the image in, the integral image (4 bytes per pixel) written by the row pass, read and
@@ -555,7 +568,17 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
     # response maps (4 (1 + 1/4 + 1/16) floats per pixel) written once and read once, 16 bytes per point out
     maps_px = 4.0 * (1.0 + 0.25 + 0.0625)
     bytes_surf = px * (1.0 + 4.0 * 4.0 + 2.0 * 4.0 * maps_px)
+    # BRISK per image: the image read by the two resamplings and the score pass, 1.0 byte per pixel of coarser layers
+    # written and read, 2.2 + 1 bytes per pixel of scores written once and read once, 16 bytes per keypoint out
+    bytes_brisk = px * (3.0 + 2.0 * 1.0 + 2.0 * 3.2)
     batch_out = {"frames": nb,
+                 "brisk_detection": {"ms": batched["brisk_detection"], "points": brisk_b,
+                                     "algorithmic_bytes": bytes_brisk * nb + 16.0 * brisk_b,
+                                     "achieved_gbs": (bytes_brisk * nb + 16.0 * brisk_b) / (batched["brisk_detection"] * 1e-3) / 1e9,
+                                     "peak_gbs": 8000.0,
+                                     "frac": (bytes_brisk * nb + 16.0 * brisk_b) / (batched["brisk_detection"] * 1e-3) / 1e9 / 8000.0,
+                                     "note": "ten launches serve the batch (seven resamplings, scores, extrema, placement); the "
+                                             "score pass (about 180 integer operations per pixel of 2.2 images) bounds it"},
                  "surf_detection": {"ms": batched["surf_detection"], "points": surf_b,
                                     "algorithmic_bytes": bytes_surf * nb + 16.0 * surf_b,
                                     "achieved_gbs": (bytes_surf * nb + 16.0 * surf_b) / (batched["surf_detection"] * 1e-3) / 1e9,
@@ -588,6 +611,9 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
             "corner_detection": {"ms": out["corner_detection"], "corners": n_corners, "algorithmic_bytes": bytes_det,
                                  "achieved_gbs": bytes_det / (out["corner_detection"] * 1e-3) / 1e9,
                                  "peak_gbs": 8000.0},
+            "brisk_detection": {"ms": out["brisk_detection"], "points": n_brisk, "algorithmic_bytes": bytes_brisk + 16.0 * n_brisk,
+                                "achieved_gbs": (bytes_brisk + 16.0 * n_brisk) / (out["brisk_detection"] * 1e-3) / 1e9,
+                                "peak_gbs": 8000.0},
             "surf_detection": {"ms": out["surf_detection"], "points": n_surf, "algorithmic_bytes": bytes_surf + 16.0 * n_surf,
                                "achieved_gbs": (bytes_surf + 16.0 * n_surf) / (out["surf_detection"] * 1e-3) / 1e9,
                                "peak_gbs": 8000.0},
@@ -785,7 +811,7 @@ def main():
             # the headline loop with the other detectors of main_eval.m:165-174 (SURF is the reference's default,
             # main_demo.m:25): only the detection on the side stream and the candidates it feeds differ
             variants = {}
-            for feat in (("SURF", ["MetricThreshold", 200]), ("FAST", ["MinContrast", 0.11])):
+            for feat in (("SURF", ["MetricThreshold", 200]), ("BRISK", ["MinQuality", 2e-3]), ("FAST", ["MinContrast", 0.11])):
                 el, inf = bench_frames(vo, torch, ctx, scene, frames, poses, args.steps, args.warmup, 100, nosync, nogather,
                                        feature=feat)
                 variants[feat[0]] = {"frames_per_s": args.steps / el, "options": feat[1],
@@ -845,11 +871,11 @@ def main():
                 "four_runs_in_flight": bench_main_eval(vo, ctx, frames, poses, concurrent=4),
                 "groups_of_8_loops_in_lockstep": bench_main_eval(vo, ctx, frames, poses, group=8),
                 "two_groups_of_6_in_flight": bench_main_eval(vo, ctx, frames, poses, concurrent=2, group=6),
-                "two_groups_of_6_in_flight_grid_with_surf": dict(
+                "two_groups_of_6_in_flight_reference_grid": dict(
                     bench_main_eval(vo, ctx, frames, poses, concurrent=2, group=6,
-                                    feats=("SURF", "Harris", "MinEigen", "FAST"), repetition=3),
-                    workload="4 feature variants (SURF -- the reference's default, MetricThreshold 200 --, Harris, MinEigen, "
-                             "FAST) x 3 repetitions: the same 12 runs with SURF in the grid")}
+                                    feats=("SURF", "Harris", "BRISK", "FAST"), repetition=3),
+                    workload="main_eval.m:19's own four feature variants (SURF -- the reference's default --, Harris, BRISK, "
+                             "FAST, with main_eval.m:165-174's options) x 3 repetitions: 12 runs")}
 
         klt_loop = klt_stress = image_kernels = ba_runs = None
         n, h = args.points, args.hypotheses

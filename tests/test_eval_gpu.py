@@ -123,8 +123,8 @@ def test_main_eval_grid_is_independent_of_world_size(vo, ctx, tmp_path):
         for key in ("est_trans", "est_rot", "num_X", "num_C", "num_new", "errs"):
             np.testing.assert_array_equal(whole[k][key], together[k][key], err_msg="concurrent %d %s" % (k, key))
     # ... and of whether its loop advances alone or in a group of loops in lockstep (three feature variants of
-    # main_eval.m:19, SURF -- the reference's default -- among them, three runs to a group)
-    feats3 = ("Harris", "SURF", "MinEigen")
+    # main_eval.m:19 -- with FAST above that is its whole list --, three runs to a group)
+    feats3 = ("Harris", "SURF", "BRISK")
     alone = vo.main_eval(sequences, feats=feats3, repetition=1, save_dir=str(tmp_path / "w4"), seed=9, ctx=ctx)
     grouped = vo.main_eval(sequences, feats=feats3, repetition=1, save_dir=str(tmp_path / "w5"), seed=9, ctx=ctx, group=3)
     for k in range(6):

@@ -8,7 +8,7 @@ from . import batch, synth
 from .ba import T_refinement, T_refinement_batch, baError, runBA
 from .bootstrap import (bootstrap, compProjMat, estimateEssentialMatrix, matching_init, pose_estimation_init,
                         relativeCameraPose, triangulation_init)
-from .evaluation import (alignError, alignEstimateToGroundTruth, experiment_name, load_results, main_eval,
+from .evaluation import (MAIN_EVAL_FEATS, alignError, alignEstimateToGroundTruth, experiment_name, load_results, main_eval,
                          quantitative_eval, run_group, run_sequence, save_results)
 from .fmatrix import draw_octets, estimateFundamentalMatrix, octets_from_uniforms
 from .frame_pipeline import VOGroupDevice, VOPipelineDevice

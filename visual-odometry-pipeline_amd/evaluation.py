@@ -288,6 +288,7 @@ def run_group(runs, ctx=None, group=None, n_slots=None, max_frames=None):
     return outs
 
 
+MAIN_EVAL_FEATS = ("SURF", "Harris", "BRISK", "FAST")         # main_eval.m:19
 EVAL_FEATURE_OPTIONS = {"SURF": ["MetricThreshold", 200],     # main_eval.m:166-167
                         "BRISK": ["MinQuality", 2e-3],       # main_eval.m:170-171
                         "Harris": ["MinQuality", 2e-4],      # main_eval.m:168-169
