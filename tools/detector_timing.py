@@ -34,6 +34,8 @@ def main():
                                                        d_xy.data_ptr(), d_metric.data_ptr(), cap, d_count.data_ptr()),
         "FAST": lambda: lib.vohip_detect_fast_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 0.11, 0.1, 16,
                                                   d_xy.data_ptr(), d_metric.data_ptr(), cap, d_count.data_ptr()),
+        "BRISK": lambda: lib.vohip_detect_brisk_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 0.2, 2e-3, 4, 16, d_xy.data_ptr(),
+                                                    d_metric.data_ptr(), None, cap, d_count.data_ptr()),
         "SURF": lambda: lib.vohip_detect_surf_dev(ctx.handle, d_frame.data_ptr(), rows, cols, 0, 200.0, 16, d_xy.data_ptr(),
                                                   d_metric.data_ptr(), None, cap, d_count.data_ptr()),
     }
