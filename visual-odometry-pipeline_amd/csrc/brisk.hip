@@ -18,7 +18,8 @@
 //        (2/3, S_-1) below; the top layer: its own scale); Metric = s;  output order: layer, then pixel order.
 // Exact integer arithmetic up to the refinement, which is fp32 / fp64 in a fixed order without contraction.
 // Kernels:
-//   brisk_sample_kernel    one layer from the one it is made of (a thread per output pixel), seven launches
+//   brisk_layers_kernel    all layers above the image in one launch, a thread per output pixel: the nested means
+//                          straight from the image (integer functions: the values of a layer by layer construction)
 //   brisk_score_kernel     all layers in one launch: 64 x 16 tiles with a 3 px halo staged in LDS as integers, the
 //                          segment-test score of every pixel -> one byte; layer 0's 5-8 scores from the same tile;
 //                          the maximum of all scores by one atomic per workgroup
@@ -118,25 +119,56 @@ size_t image_scratch_bytes(const brisk_geom &g)
     return g.px_stride + g.sc_stride + sizeof(int) * (g.cell_stride + g.sub_stride) + sizeof(brisk_point) * g.rec_stride;
 }
 
-// mode 0: half; 1: twothirds.  One thread per output pixel.
-__global__ __launch_bounds__(256) void brisk_sample_kernel(const uint8_t *__restrict__ src, size_t src_stride, int As,
-                                                           uint8_t *__restrict__ dst, size_t dst_stride, int Ad, int Bd, int mode)
+// A pixel of an octave (L halvings of the image) or of an intra-octave (the 2/3 resampling, then L halvings) straight
+// from the image: the nested means are integer functions of the pixels below them, so the value is the one the layer
+// by layer construction gives, and all seven layers come out of one launch (an image's 0.47 MB stay in the caches).
+template <int L>
+__device__ __forceinline__ int octave_px(const uint8_t *__restrict__ img, int A, int x, int y)
 {
-    src += blockIdx.z * src_stride;
-    dst += blockIdx.z * dst_stride;
-    const int a = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (a >= Ad || b >= Bd) return;
-    int v;
-    if (mode == 0) {
-        const uint8_t *p = src + (size_t)(2 * b) * As + 2 * a;
-        v = ((int)p[0] + (int)p[1] + (int)p[As] + (int)p[As + 1] + 2) / 4;
+    if constexpr (L == 0) {
+        return (int)img[(size_t)y * A + x];
     } else {
-        const int a0 = 3 * (a / 2) + 2 * (a % 2), b0 = 3 * (b / 2) + 2 * (b % 2);   // the pixel covered in full
-        const int am = 3 * (a / 2) + 1, bm = 3 * (b / 2) + 1;                       // the middle of the 3 x 3 block
-        v = (4 * (int)src[(size_t)b0 * As + a0] + 2 * (int)src[(size_t)b0 * As + am] + 2 * (int)src[(size_t)bm * As + a0] +
-             (int)src[(size_t)bm * As + am] + 4) / 9;
+        return (octave_px<L - 1>(img, A, 2 * x, 2 * y) + octave_px<L - 1>(img, A, 2 * x + 1, 2 * y) +
+                octave_px<L - 1>(img, A, 2 * x, 2 * y + 1) + octave_px<L - 1>(img, A, 2 * x + 1, 2 * y + 1) + 2) / 4;
     }
-    dst[(size_t)b * Ad + a] = (uint8_t)v;
+}
+template <int L>
+__device__ __forceinline__ int intra_px(const uint8_t *__restrict__ img, int A, int x, int y)
+{
+    if constexpr (L == 0) {
+        const int a0 = 3 * (x / 2) + 2 * (x % 2), b0 = 3 * (y / 2) + 2 * (y % 2);   // the pixel covered in full
+        const int am = 3 * (x / 2) + 1, bm = 3 * (y / 2) + 1;                       // the middle of the 3 x 3 block
+        return (4 * (int)img[(size_t)b0 * A + a0] + 2 * (int)img[(size_t)b0 * A + am] + 2 * (int)img[(size_t)bm * A + a0] +
+                (int)img[(size_t)bm * A + am] + 4) / 9;
+    } else {
+        return (intra_px<L - 1>(img, A, 2 * x, 2 * y) + intra_px<L - 1>(img, A, 2 * x + 1, 2 * y) +
+                intra_px<L - 1>(img, A, 2 * x, 2 * y + 1) + intra_px<L - 1>(img, A, 2 * x + 1, 2 * y + 1) + 2) / 4;
+    }
+}
+
+// All layers above the image in one launch: a thread per output pixel, workgroups of 64 x 4 pixels dealt to the layers.
+__global__ __launch_bounds__(256) void brisk_layers_kernel(const uint8_t *__restrict__ px0, uint8_t *__restrict__ px, brisk_geom g)
+{
+    px0 += blockIdx.y * g.img_stride;
+    px += blockIdx.y * g.px_stride;
+    int k = 1;
+#pragma unroll
+    for (int q = 2; q < BK_LAYERS; ++q) k += (int)blockIdx.x >= g.xt_first[q] - g.xt_first[1] ? 1 : 0;
+    const int t = (int)blockIdx.x - (g.xt_first[k] - g.xt_first[1]);
+    const int a = (t % g.spans[k]) * 64 + (threadIdx.x & 63), b = (t / g.spans[k]) * 4 + (threadIdx.x >> 6);
+    if (a >= g.A[k] || b >= g.B[k]) return;
+    const int A0 = g.A[0];
+    int v;
+    switch (k) {   // (the same in every lane of the workgroup)
+        case 1: v = intra_px<0>(px0, A0, a, b); break;
+        case 2: v = octave_px<1>(px0, A0, a, b); break;
+        case 3: v = intra_px<1>(px0, A0, a, b); break;
+        case 4: v = octave_px<2>(px0, A0, a, b); break;
+        case 5: v = intra_px<2>(px0, A0, a, b); break;
+        case 6: v = octave_px<3>(px0, A0, a, b); break;
+        default: v = intra_px<3>(px0, A0, a, b); break;
+    }
+    px[g.px_off[k] + (size_t)b * g.A[k] + a] = (uint8_t)v;
 }
 
 // px0: the images (layer 0); px: the pyramid blocks; sc: the score blocks; smax: an image's maximum score.
@@ -362,14 +394,8 @@ int enqueue_images(vohip_ctx *ctx, hipStream_t st, void *scratch, brisk_geom g, 
     g.metric_stride = cap;
     g.count_stride = 1;
     VOHIP_HIP(ctx, hipMemsetAsync(cells, 0, sizeof(int) * g.cell_stride * n, st));
-    for (int k = 1; k < g.nl; ++k) {
-        if (g.A[k] < 1 || g.B[k] < 1) continue;
-        const int from = k == 1 ? 0 : k - 2;
-        const uint8_t *src = from == 0 ? d_imgs : px + g.px_off[from];
-        hipLaunchKernelGGL(brisk_sample_kernel, dim3((g.A[k] + 63) / 64, (g.B[k] + 3) / 4, n), dim3(256), 0, st, src,
-                           from == 0 ? g.img_stride : g.px_stride, g.A[from], px + g.px_off[k], g.px_stride, g.A[k], g.B[k],
-                           k == 1 ? 1 : 0);
-    }
+    if (g.xt_first[BK_LAYERS] > g.xt_first[1])
+        hipLaunchKernelGGL(brisk_layers_kernel, dim3(g.xt_first[BK_LAYERS] - g.xt_first[1], n), dim3(256), 0, st, d_imgs, px, g);
     const int lo = border < 1 ? 1 : border, nsubs = g.sub_first[BK_LAYERS];
     int *smax = cells + g.cell_first[BK_LAYERS];
     hipLaunchKernelGGL(brisk_score_kernel, dim3(g.tile_first[BK_LAYERS], n), dim3(256), 0, st, d_imgs, (const uint8_t *)px, sc,
