@@ -19,7 +19,8 @@
 // Exact integer arithmetic up to the refinement, which is fp32 / fp64 in a fixed order without contraction.
 // Kernels:
 //   brisk_layers_kernel    all layers above the image in one launch, a thread per output pixel: the nested means
-//                          straight from the image (integer functions: the values of a layer by layer construction)
+//                          straight from the image (integer functions: the values of a layer by layer construction);
+//   brisk_sample_kernel    for a batch of images: one layer from the one it is made of, seven launches
 //   brisk_score_kernel     all layers in one launch: 64 x 16 tiles with a 3 px halo staged in LDS as integers, the
 //                          segment-test score of every pixel -> one byte; layer 0's 5-8 scores from the same tile;
 //                          the maximum of all scores by one atomic per workgroup
@@ -169,6 +170,28 @@ __global__ __launch_bounds__(256) void brisk_layers_kernel(const uint8_t *__rest
         default: v = intra_px<3>(px0, A0, a, b); break;
     }
     px[g.px_off[k] + (size_t)b * g.A[k] + a] = (uint8_t)v;
+}
+
+// One layer from the one it is made of, a thread per output pixel (mode 0: half; 1: twothirds): the streaming form
+// of the construction, which a batch of images uses (seven launches serve them all; the nested form reads more).
+__global__ __launch_bounds__(256) void brisk_sample_kernel(const uint8_t *__restrict__ src, size_t src_stride, int As,
+                                                           uint8_t *__restrict__ dst, size_t dst_stride, int Ad, int Bd, int mode)
+{
+    src += blockIdx.z * src_stride;
+    dst += blockIdx.z * dst_stride;
+    const int a = blockIdx.x * 64 + (threadIdx.x & 63), b = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (a >= Ad || b >= Bd) return;
+    int v;
+    if (mode == 0) {
+        const uint8_t *p = src + (size_t)(2 * b) * As + 2 * a;
+        v = ((int)p[0] + (int)p[1] + (int)p[As] + (int)p[As + 1] + 2) / 4;
+    } else {
+        const int a0 = 3 * (a / 2) + 2 * (a % 2), b0 = 3 * (b / 2) + 2 * (b % 2);   // the pixel covered in full
+        const int am = 3 * (a / 2) + 1, bm = 3 * (b / 2) + 1;                       // the middle of the 3 x 3 block
+        v = (4 * (int)src[(size_t)b0 * As + a0] + 2 * (int)src[(size_t)b0 * As + am] + 2 * (int)src[(size_t)bm * As + a0] +
+             (int)src[(size_t)bm * As + am] + 4) / 9;
+    }
+    dst[(size_t)b * Ad + a] = (uint8_t)v;
 }
 
 // px0: the images (layer 0); px: the pyramid blocks; sc: the score blocks; smax: an image's maximum score.
@@ -394,8 +417,19 @@ int enqueue_images(vohip_ctx *ctx, hipStream_t st, void *scratch, brisk_geom g, 
     g.metric_stride = cap;
     g.count_stride = 1;
     VOHIP_HIP(ctx, hipMemsetAsync(cells, 0, sizeof(int) * g.cell_stride * n, st));
-    if (g.xt_first[BK_LAYERS] > g.xt_first[1])
-        hipLaunchKernelGGL(brisk_layers_kernel, dim3(g.xt_first[BK_LAYERS] - g.xt_first[1], n), dim3(256), 0, st, d_imgs, px, g);
+    if (n == 1) {   // (one launch: a single image's layers are a matter of launch latencies)
+        if (g.xt_first[BK_LAYERS] > g.xt_first[1])
+            hipLaunchKernelGGL(brisk_layers_kernel, dim3(g.xt_first[BK_LAYERS] - g.xt_first[1], n), dim3(256), 0, st, d_imgs, px, g);
+    } else {
+        for (int k = 1; k < g.nl; ++k) {
+            if (g.A[k] < 1 || g.B[k] < 1) continue;
+            const int from = k == 1 ? 0 : k - 2;
+            const uint8_t *src = from == 0 ? d_imgs : px + g.px_off[from];
+            hipLaunchKernelGGL(brisk_sample_kernel, dim3((g.A[k] + 63) / 64, (g.B[k] + 3) / 4, n), dim3(256), 0, st, src,
+                               from == 0 ? g.img_stride : g.px_stride, g.A[from], px + g.px_off[k], g.px_stride, g.A[k], g.B[k],
+                               k == 1 ? 1 : 0);
+        }
+    }
     const int lo = border < 1 ? 1 : border, nsubs = g.sub_first[BK_LAYERS];
     int *smax = cells + g.cell_first[BK_LAYERS];
     hipLaunchKernelGGL(brisk_score_kernel, dim3(g.tile_first[BK_LAYERS], n), dim3(256), 0, st, d_imgs, (const uint8_t *)px, sc,
