@@ -661,7 +661,8 @@ int vohip_detect_brisk_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, i
  * xy: n x 2 (x column then y column, leading dimension n / ld), 1-based as SURFPoints.Location; scale: n
  * (SURFPoints.Scale); features: n x 64 with a point's 64 numbers contiguous (the transpose of MATLAB's N x 64 array
  * in memory); orientation (may be NULL): n angles in radians, atan2 of the dominant direction in image coordinates
- * (x right, y down).  upright != 0 skips the direction.  At most 2^24 pixels. */
+ * (x right, y down).  upright != 0 skips the direction.  At most 2^24 pixels; 0 < Scale <= 1e4 and positions within 1e6
+ * pixels of the image (checked by the host form; the device form trusts its caller). */
 int vohip_extract_surf_features(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, const float *xy,
                                 const float *scale, int n, int upright, float *features_out, float *orientation_out);
 int vohip_extract_surf_features_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, const float *d_xy,

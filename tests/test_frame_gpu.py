@@ -386,6 +386,14 @@ def test_overflow_stops_the_loop(vo, ctx, oracle, sequence):
         e.process_frame(frames[2])
     assert "vohip_frame_reset" in str(err.value)
     e.close()
+    # a detector's options are checked when the loop is made, not at the first frame that reaches the detector
+    import copy
+    for feat, opts in (("BRISK", ["NumOctaves", 7]), ("FAST", ["MinContrast", 1.5]), ("SURF", ["MetricThreshold", -3.0]),
+                       ("Harris", ["MinQuality", 2.0])):
+        bad = copy.copy(hp)
+        bad.feature_extract, bad.feature_extract_options = feat, opts
+        with pytest.raises(vo.VohipError):
+            vo.VOPipelineDevice(K, frames[0], X0, xy, poses[0], hyper_paras=bad, rng=np.random.default_rng(3), ctx=ctx)
 
 
 @pytest.mark.parametrize("on_device", [False, True, "pinned"])

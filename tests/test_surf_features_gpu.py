@@ -62,6 +62,12 @@ def test_points_at_the_image_edge_and_errors(vo, ctx, oracle):
     assert vo.extractFeatures(img, empty, ctx=ctx)[0].shape == (0, 64)
     with pytest.raises(NotImplementedError):
         vo.extractFeatures(img, vo.cornerPoints(loc, np.ones(len(loc), np.float32)), ctx=ctx)
+    for bad_scale in (0.0, -1.0, np.nan, 1e9):
+        with pytest.raises(vo.VohipError):
+            vo.extractFeatures(img, vo.SURFPoints(loc[:1], np.ones(1, np.float32), np.array([bad_scale], np.float32)), ctx=ctx)
+    with pytest.raises(vo.VohipError):
+        vo.extractFeatures(img, vo.SURFPoints(np.array([[np.inf, 3.0]], np.float32), np.ones(1, np.float32),
+                                              np.array([2.0], np.float32)), ctx=ctx)
 
 
 def test_matching_matches_oracle_and_finds_a_known_shift(vo, ctx, oracle):

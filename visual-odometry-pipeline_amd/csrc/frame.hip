@@ -1418,6 +1418,14 @@ int create_loops(vohip_ctx *ctx, const double K[9], int rows, int cols, int colm
                            p.slot_c < VOHIP_PYR_SLOTS,
                   "bad pyramid slots");
     VOHIP_REQUIRE(ctx, p.klt_block == 21 || p.klt_block == 31, "BlockSize 21 or 31");
+    // (the detector's own options are checked here, not at the first frame that reaches it)
+    VOHIP_REQUIRE(ctx, p.detector >= 0 && p.detector <= 4, "detector: 0 = Harris, 1 = MinEigen, 2 = FAST, 3 = SURF, 4 = BRISK");
+    VOHIP_REQUIRE(ctx, p.min_quality >= 0.0 && p.min_quality <= 1.0, "MinQuality must lie in [0, 1]");
+    VOHIP_REQUIRE(ctx, (p.detector != 2 && p.detector != 4) || (p.min_contrast > 0.0 && p.min_contrast < 1.0),
+                  "MinContrast must lie in (0, 1)");
+    VOHIP_REQUIRE(ctx, p.detector != 3 || p.metric_threshold >= 0.0, "MetricThreshold must be >= 0");
+    VOHIP_REQUIRE(ctx, p.detector != 4 || (p.brisk_octaves >= 0 && p.brisk_octaves <= 4), "NumOctaves must be 0..4");
+    VOHIP_REQUIRE(ctx, p.detector != 3 || (size_t)rows * cols <= ((size_t)1 << 24), "SURF: at most 2^24 pixels");
     VOHIP_HIP(ctx, hipSetDevice(ctx->device));
     vohip_frame *f = new (std::nothrow) vohip_frame;
     if (!f) return vohip_fail(ctx, VOHIP_ERR_HIP, "out of host memory");

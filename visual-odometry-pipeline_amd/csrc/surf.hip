@@ -1077,6 +1077,9 @@ int vohip_extract_surf_features(vohip_ctx *ctx, const uint8_t *img, int rows, in
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     VOHIP_REQUIRE(ctx, img && xy && scale && features_out, "NULL argument");
     VOHIP_REQUIRE(ctx, rows >= 1 && cols >= 1 && n >= 1, "bad size");
+    for (int i = 0; i < n; ++i)   // (the sampling pattern is 20 Scale wide: integer pixel arithmetic stays far from its limits)
+        VOHIP_REQUIRE(ctx, scale[i] > 0.0f && scale[i] <= 1.0e4f && std::fabs(xy[i]) <= 1.0e6f && std::fabs(xy[n + i]) <= 1.0e6f,
+                      "points must be finite, within 1e6 pixels of the image, with 0 < Scale <= 1e4");
     void *d_img, *d_xy, *d_scale, *d_feat, *d_ori;
     VOHIP_TRY(vohip_upload(ctx, B_IMG_STAGE, img, (size_t)rows * cols, &d_img));
     VOHIP_TRY(vohip_upload(ctx, B_STAGE0, xy, sizeof(float) * 2 * (size_t)n, &d_xy));

@@ -75,8 +75,13 @@ class VOPipelineDevice:
             self._colmajor = int(first_image.flags.f_contiguous and not first_image.flags.c_contiguous)
         self._shape = shape
         h = C.c_void_p()
-        self.ctx.check(lib.vohip_frame_create(self.ctx.handle, dptr(colmajor(self.K)), shape[0], shape[1], self._colmajor,
-                                              C.byref(prm), C.byref(h)))
+        try:
+            self.ctx.check(lib.vohip_frame_create(self.ctx.handle, dptr(colmajor(self.K)), shape[0], shape[1], self._colmajor,
+                                                  C.byref(prm), C.byref(h)))
+        except Exception:
+            free.extend(self._slots)   # (a loop that was not made holds no pyramid slots)
+            self._slots = []
+            raise
         self._h = h
         _lib._live_frames.add(self)
         X = np.ascontiguousarray(np.asarray(p_W_landmarks, dtype=np.float64).reshape(-1, 3))
@@ -382,8 +387,14 @@ class VOGroupDevice:
         self.n_sequences = int(n_sequences)
         self.max_frames = int(max_frames)
         h = C.c_void_p()
-        self.ctx.check(lib.vohip_group_create(self.ctx.handle, dptr(colmajor(self.K)), self._shape[0], self._shape[1],
-                                              self._colmajor, C.byref(prm), self.n_sequences, self.max_frames, C.byref(h)))
+        try:
+            self.ctx.check(lib.vohip_group_create(self.ctx.handle, dptr(colmajor(self.K)), self._shape[0], self._shape[1],
+                                                  self._colmajor, C.byref(prm), self.n_sequences, self.max_frames,
+                                                  C.byref(h)))
+        except Exception:
+            free.extend(self._slots)   # (a group that was not made holds no pyramid slots)
+            self._slots = []
+            raise
         self._h = h
         _lib._live_frames.add(self)
         self.first_hypotheses = 104
