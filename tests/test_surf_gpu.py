@@ -43,6 +43,8 @@ def test_surf_response_maps_and_edge_cases(vo, ctx, oracle):
         img += amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sg * sg))
     img = np.clip(img, 0, 255).astype(np.uint8)
     _, kp = vo.genKeypoints(img, "SURF", None, ctx=ctx)       # the toolbox default MetricThreshold 1000
+    _, kp_default = vo.genKeypoints(img, ctx=ctx)             # genKeypoints.m:3-5: the method defaults to SURF
+    np.testing.assert_array_equal(kp_default.Location, kp.Location)
     ab, metric, scale, total = oracle.detect_surf(img, 1000.0, 16)
     assert kp.Count == total >= 3
     np.testing.assert_array_equal(kp.Location, ab + 1.0)
