@@ -26,12 +26,13 @@
 //   surf_integral_colsum_kernel /  the slow axis in chunks of 32 rows: per-chunk column sums, then every
 //   surf_integral_colscan_kernel   chunk adds the chunks before it and runs down its own rows (all 32 loads
 //                                  of a thread in flight together); consecutive threads = consecutive columns.
-//   surf_response_kernel           all 12 (octave, level) maps in one launch: 32 lookups of the integral image
-//                                  per response (exact integer box sums, fp64 determinant).  Octave 0 from an
-//                                  LDS tile of the integral image (64 x 8 samples, four levels, 12.7 KB), octaves
-//                                  1 and 2 a thread per sample through the caches (the integral image stays in L2:
-//                                  1.9 MB for 1241 x 376).
-//   surf_extrema_kernel            a workgroup per tile of 64 x 4 samples of an octave: the four levels of the tile
+//   surf_response_kernel           one launch, two kinds of workgroup.  Octave 0 (three quarters of the responses) in
+//                                  one pass: an LDS tile of the integral image (64 x 8 samples + ring + filter reach,
+//                                  13.8 KB) -> the four levels of the tile and its ring in LDS (10.6 KB) -> both middle
+//                                  levels tested there; its maps never reach memory.  The 8 maps of octaves 1 and 2:
+//                                  a thread per sample through the caches (the integral image stays in L2: 1.9 MB for
+//                                  1241 x 376).  32 lookups per response (exact integer box sums, fp64 determinant).
+//   surf_extrema_kernel            (octaves 1, 2) a workgroup per tile of 64 x 4 samples of an octave: the four levels of the tile
 //                                  and a one-sample ring go to LDS once (6.3 KB), every thread tests its sample
 //                                  on both middle levels from there and refines the hits; a wavefront = one row
 //                                  of 64 samples = one (octave, level, row, span) sub-cell, whose points become
@@ -57,11 +58,13 @@ struct surf_point {   // 16 bytes
     float pa, pb, metric, scale;
 };
 
+constexpr int RT_A = 64, RT_B = 8, RT_H = 13;   // octave 0's tile of samples and the reach of its largest filter
+
 struct surf_geom {
     int A, B, A1;                        // image axes; row length of the integral image
     int GA[SURF_OCT], GB[SURF_OCT];      // samples per octave
     int L[SURF_MAPS];                    // filter side of map 4 o + level
-    unsigned map_off[SURF_MAPS];         // of a map within an image's responses (floats)
+    unsigned map_off[SURF_MAPS];         // of a map of octaves 1, 2 within an image's responses (floats)
     int tile_first[SURF_MAPS + 1];       // workgroups of the response launch before map k
     int tiles_a[SURF_OCT];
     int cell_first[SURF_MID + 1];        // cells before (octave, middle level) pair k = 2 o + (m - 1)
@@ -92,7 +95,7 @@ surf_geom make_geom(int A, int B)
         for (int i = 0; i < SURF_LEV; ++i) {
             g.L[4 * o + i] = SIZES[o][i];
             g.map_off[4 * o + i] = off;
-            off += (unsigned)((size_t)g.GA[o] * g.GB[o] + 63) / 64 * 64;
+            if (o > 0) off += (unsigned)((size_t)g.GA[o] * g.GB[o] + 63) / 64 * 64;   // (octave 0 is never stored)
             g.tile_first[4 * o + i] = tiles;
             tiles += g.tiles_a[o] * ((g.GB[o] + 3) / 4);
         }
@@ -109,7 +112,7 @@ surf_geom make_geom(int A, int B)
     g.cell_first[SURF_MID] = cells;
     g.sub_first[SURF_MID] = subs;
     g.otile_first[SURF_OCT] = otiles;
-    g.resp0_tiles = g.tiles_a[0] * ((B + 7) / 8);
+    g.resp0_tiles = g.tiles_a[0] * ((B + RT_B - 1) / RT_B);
     g.nch = (B + SURF_CH - 1) / SURF_CH;
     auto r256 = [](size_t v) { return (v + 255) / 256 * 256; };
     g.img_stride = (size_t)A * B;
@@ -241,63 +244,14 @@ __device__ __forceinline__ float surf_det(BOX sum, int a, int b, int L, double i
     return (float)(t1 - t3);
 }
 
-// Octave 0 (three quarters of all responses) from LDS: a workgroup stages the integral image under a tile of
-// 64 x 8 pixels and the reach of the largest filter of the octave (13 before, 14 after: 91 x 35 words, 12.7 KB) once
-// and makes the four levels of its 512 samples from there (128 LDS lookups per thread and row instead of 128
-// cache lookups; consecutive lanes read consecutive words).  The other two octaves, whose filters reach up to 50
-// pixels, read the integral image through the caches.
-constexpr int RT_A = 64, RT_B = 8, RT_H = 13, RS_A = RT_A + 2 * RT_H + 1, RS_B = RT_B + 2 * RT_H + 1;
-
-__global__ __launch_bounds__(256) void surf_response_kernel(const uint32_t *__restrict__ T, float *__restrict__ R, surf_geom g,
-                                                            surf_norms nm)
+// The maps of octaves 1 and 2 (a quarter of all responses), whose filters reach up to 50 pixels: a thread per sample
+// reads the integral image through the caches.  Octave 0 never becomes a map: surf_octave0_block below.
+// block = the workgroup's number among those of the maps 4..11.
+__device__ __forceinline__ void surf_maps_block(const uint32_t *__restrict__ T, float *__restrict__ R, const surf_geom &g,
+                                                const surf_norms &nm, int block)
 {
-    T += blockIdx.y * g.t_stride;
-    R += blockIdx.y * g.r_stride;
     const int A1 = g.A1;
-    if ((int)blockIdx.x < g.resp0_tiles) {
-        static_assert(SIZES[0][SURF_LEV - 1] == 2 * RT_H + 1, "the staged reach is that of octave 0's largest filter");
-        __shared__ uint32_t sT[RS_B * RS_A];
-        const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-        const int a0 = ((int)blockIdx.x % g.tiles_a[0]) * RT_A, b0 = ((int)blockIdx.x / g.tiles_a[0]) * RT_B;
-        constexpr int N = RS_A * RS_B, ROUNDS = (N + 255) / 256;
-        uint32_t v[ROUNDS];   // (all loads of the thread in flight together)
-#pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) {
-            const int q = min(tid + 256 * k, N - 1);
-            const int rb = q / RS_A, ra = q - rb * RS_A;
-            // (entries outside the integral image are only reached from samples whose filter does not fit)
-            const int ia = min(max(a0 - RT_H + ra, 0), g.A), ib = min(max(b0 - RT_H + rb, 0), g.B);
-            v[k] = T[(size_t)ib * A1 + ia];
-        }
-#pragma unroll
-        for (int k = 0; k < ROUNDS; ++k) {
-            const int q = tid + 256 * k;
-            if (q < N) sT[q] = v[k];
-        }
-        __syncthreads();
-        const int a = a0 + lane;
-        if (a >= g.A) return;
-        auto sum = [&](int x0, int y0, int x1, int y1) {
-            const int r0 = (y0 - (b0 - RT_H)) * RS_A - (a0 - RT_H), r1 = (y1 - (b0 - RT_H)) * RS_A - (a0 - RT_H);
-            return (int)((sT[r1 + x1] - sT[r0 + x1]) - (sT[r1 + x0] - sT[r0 + x0]));
-        };
-#pragma unroll
-        for (int half = 0; half < RT_B / 4; ++half) {
-            const int b = b0 + wave + 4 * half;
-            if (b >= g.B) break;
-#pragma unroll
-            for (int i = 0; i < SURF_LEV; ++i) {
-                constexpr int Ls[SURF_LEV] = {SIZES[0][0], SIZES[0][1], SIZES[0][2], SIZES[0][3]};
-                const int h = (Ls[i] - 1) / 2;
-                float r = 0.0f;
-                if (a - h >= 0 && a + h <= g.A - 1 && b - h >= 0 && b + h <= g.B - 1)
-                    r = surf_det(sum, a, b, Ls[i], nm.inv_lobe[i], nm.inv_sq[i]);
-                R[g.map_off[i] + (size_t)b * g.A + a] = r;
-            }
-        }
-        return;
-    }
-    const int bx = (int)blockIdx.x - g.resp0_tiles + g.tile_first[SURF_LEV];
+    const int bx = block + g.tile_first[SURF_LEV];
     int map = SURF_LEV;
 #pragma unroll
     for (int k = SURF_LEV + 1; k < SURF_MAPS; ++k) map += bx >= g.tile_first[k] ? 1 : 0;
@@ -383,10 +337,11 @@ __global__ __launch_bounds__(256) void surf_extrema_kernel(const float *__restri
     recs += blockIdx.y * g.rec_stride;
     __shared__ float sR[SURF_LEV][XS_B * XS_A];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int o = 0;
+    const int bx = (int)blockIdx.x + g.otile_first[1];   // (octave 0 is surf_response_kernel's)
+    int o = 1;
 #pragma unroll
-    for (int k = 1; k < SURF_OCT; ++k) o += (int)blockIdx.x >= g.otile_first[k] ? 1 : 0;
-    const int t = (int)blockIdx.x - g.otile_first[o];
+    for (int k = 2; k < SURF_OCT; ++k) o += bx >= g.otile_first[k] ? 1 : 0;
+    const int t = bx - g.otile_first[o];
     const int ta = t % g.tiles_a[o], tb = t / g.tiles_a[o];
     const int ga0 = ta * XT_A, gb0 = tb * XT_B, GA = g.GA[o], GB = g.GB[o];
     // (every load of the thread issued before the first one is waited for)
@@ -425,6 +380,101 @@ __global__ __launch_bounds__(256) void surf_extrema_kernel(const float *__restri
             if (n) atomicAdd(&cells[g.cell_first[pair] + gb], n);
         }
     }
+}
+
+// Octave 0 (three quarters of all responses) without its maps ever reaching memory: a workgroup stages the integral
+// image under a tile of 64 x 8 samples, a ring of one sample and the reach of the octave's largest filter (13 before,
+// 14 after: 93 x 37 words, 13.8 KB), makes the four levels of the tile and its ring from there into LDS (66 x 10 x 4
+// responses, 10.6 KB; consecutive lanes read consecutive words of the integral tile) and tests both middle levels
+// right away, as surf_extrema_kernel does for the other octaves: records per span of a row, counts per span and cell.
+constexpr int RS_A = RT_A + 2 + 2 * RT_H + 1, RS_B = RT_B + 2 + 2 * RT_H + 1;   // staged integral tile
+constexpr int RR_A = RT_A + 2, RR_B = RT_B + 2;                                // responses of the tile and its ring
+
+__device__ __forceinline__ void surf_octave0_block(const uint32_t *__restrict__ T, int *__restrict__ cells,
+                                                   int *__restrict__ subs, surf_point *__restrict__ recs, const surf_geom &g,
+                                                   const surf_norms &nm, float thr, const surf_ranges &rg, int block)
+{
+    static_assert(SIZES[0][SURF_LEV - 1] == 2 * RT_H + 1, "the staged reach is that of octave 0's largest filter");
+    __shared__ uint32_t sT[RS_B * RS_A];
+    __shared__ float sR[SURF_LEV][RR_B * RR_A];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ta = block % g.tiles_a[0], tb = block / g.tiles_a[0];
+    const int a0 = ta * RT_A, b0 = tb * RT_B, A1 = g.A1;
+    const int ia0 = a0 - 1 - RT_H, ib0 = b0 - 1 - RT_H;   // the first staged entry of the integral image
+    {
+        constexpr int N = RS_A * RS_B, ROUNDS = (N + 255) / 256;
+        uint32_t v[ROUNDS];   // (all loads of the thread in flight together)
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int q = min(tid + 256 * k, N - 1);
+            const int rb = q / RS_A, ra = q - rb * RS_A;
+            // (entries outside the integral image are only reached from samples whose filter does not fit)
+            const int ia = min(max(ia0 + ra, 0), g.A), ib = min(max(ib0 + rb, 0), g.B);
+            v[k] = T[(size_t)ib * A1 + ia];
+        }
+#pragma unroll
+        for (int k = 0; k < ROUNDS; ++k) {
+            const int q = tid + 256 * k;
+            if (q < N) sT[q] = v[k];
+        }
+    }
+    __syncthreads();
+    auto sum = [&](int x0, int y0, int x1, int y1) {
+        const int r0 = (y0 - ib0) * RS_A - ia0, r1 = (y1 - ib0) * RS_A - ia0;
+        return (int)((sT[r1 + x1] - sT[r0 + x1]) - (sT[r1 + x0] - sT[r0 + x0]));
+    };
+    for (int q = tid; q < RR_A * RR_B; q += 256) {
+        const int rb = q / RR_A, ra = q - rb * RR_A;
+        const int a = a0 - 1 + ra, b = b0 - 1 + rb;
+#pragma unroll
+        for (int i = 0; i < SURF_LEV; ++i) {
+            constexpr int Ls[SURF_LEV] = {SIZES[0][0], SIZES[0][1], SIZES[0][2], SIZES[0][3]};
+            const int h = (Ls[i] - 1) / 2;
+            float r = 0.0f;
+            if (a - h >= 0 && a + h <= g.A - 1 && b - h >= 0 && b + h <= g.B - 1)
+                r = surf_det(sum, a, b, Ls[i], nm.inv_lobe[i], nm.inv_sq[i]);
+            sR[i][q] = r;
+        }
+    }
+    __syncthreads();
+    const int ga = a0 + lane;
+#pragma unroll
+    for (int half = 0; half < RT_B / 4; ++half) {
+        const int gb = b0 + wave + 4 * half;
+        if (gb >= g.GB[0]) break;   // (a whole wavefront)
+        const int c = (wave + 4 * half + 1) * RR_A + (lane + 1);
+#pragma unroll
+        for (int m = 1; m <= 2; ++m) {
+            const int pair = m - 1;
+            surf_point pt;
+            const bool hit = ga >= rg.first_a[pair] && ga <= rg.last_a[pair] && gb >= rg.first_b[pair] && gb <= rg.last_b[pair] &&
+                             surf_test(&sR[m - 1][c], &sR[m][c], &sR[m + 1][c], RR_A, ga, gb, thr, 1, g.L[m], g.L[m] - g.L[m - 1],
+                                       &pt);
+            const unsigned long long bal = __ballot(hit);
+            const int n = __popcll(bal);
+            const int sub = g.sub_first[pair] + gb * g.tiles_a[0] + ta;
+            if (hit) recs[(size_t)sub * SURF_SUB_CAP + __popcll(bal & ((1ull << lane) - 1ull))] = pt;
+            if (lane == 0) {
+                subs[sub] = n;
+                if (n) atomicAdd(&cells[g.cell_first[pair] + gb], n);
+            }
+        }
+    }
+}
+
+// One launch for both: the first resp0_tiles workgroups take octave 0 through LDS, the others make the maps of
+// octaves 1 and 2 through the caches, so that for a single image the two kinds of work share the chip.
+__global__ __launch_bounds__(256) void surf_response_kernel(const uint32_t *__restrict__ T, float *__restrict__ R,
+                                                            int *__restrict__ cells, int *__restrict__ subs,
+                                                            surf_point *__restrict__ recs, surf_geom g, surf_norms nm, float thr,
+                                                            surf_ranges rg)
+{
+    T += blockIdx.y * g.t_stride;
+    if ((int)blockIdx.x < g.resp0_tiles)
+        surf_octave0_block(T, cells + blockIdx.y * g.cell_stride, subs + blockIdx.y * g.sub_stride,
+                           recs + blockIdx.y * g.rec_stride, g, nm, thr, rg, (int)blockIdx.x);
+    else
+        surf_maps_block(T, R + blockIdx.y * g.r_stride, g, nm, (int)blockIdx.x - g.resp0_tiles);
 }
 
 // One wavefront per sub-cell, in the order of the output: (octave, level) pair, row of samples, span.
@@ -524,10 +574,12 @@ int enqueue_images(vohip_ctx *ctx, hipStream_t st, void *scratch, surf_geom g, c
     const dim3 cgrid((g.A + 63) / 64, (g.nch + 3) / 4, n);
     hipLaunchKernelGGL(surf_integral_colsum_kernel, cgrid, dim3(64, 4), 0, st, (const uint32_t *)T, P, g);
     hipLaunchKernelGGL(surf_integral_colscan_kernel, cgrid, dim3(64, 4), 0, st, T, (const uint32_t *)P, g);
+    const surf_norms nm = make_norms(g);
+    const surf_ranges rg = make_ranges(g, lo);
     hipLaunchKernelGGL(surf_response_kernel, dim3(g.resp0_tiles + g.tile_first[SURF_MAPS] - g.tile_first[SURF_LEV], n),
-                       dim3(256), 0, st, (const uint32_t *)T, R, g, make_norms(g));
-    hipLaunchKernelGGL(surf_extrema_kernel, dim3(g.otile_first[SURF_OCT], n), dim3(256), 0, st, (const float *)R, cells, subs,
-                       recs, g, (float)metric_threshold, make_ranges(g, lo));
+                       dim3(256), 0, st, (const uint32_t *)T, R, cells, subs, recs, g, nm, (float)metric_threshold, rg);
+    hipLaunchKernelGGL(surf_extrema_kernel, dim3(g.otile_first[SURF_OCT] - g.otile_first[1], n), dim3(256), 0, st,
+                       (const float *)R, cells, subs, recs, g, (float)metric_threshold, rg);
     hipLaunchKernelGGL(surf_emit_kernel, dim3((nsubs + 3) / 4, n), dim3(256), 0, st, (const int *)cells, (const int *)subs,
                        (const surf_point *)recs, g, cap, colmajor ? 1 : 0, d_xy, d_metric, d_scale, d_counts);
     VOHIP_HIP(ctx, hipGetLastError());
