@@ -564,10 +564,11 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
     corners_b = float(torch.clamp(b_counts, max=cap).sum().item())
     bytes_det_b = px * nb + 8.0 * corners_b
     # SURF per image: the image in, the integral image (4 bytes per pixel) written by the row pass, read and
-    # written by the column pass and read by the response pass (32 lookups per response come out of L2), the 12
-    # response maps (4 (1 + 1/4 + 1/16) floats per pixel) written once and read once, 16 bytes per point out
+    # written by the column pass and read by the response pass (32 lookups per response come out of L2), the 8
+    # response maps of octaves 1 and 2 (4 (1/4 + 1/16) floats per pixel) written once and read once (octave 0 is
+    # tested from LDS and never stored), 16 bytes per point out
     maps_px = 4.0 * (1.0 + 0.25 + 0.0625)
-    bytes_surf = px * (1.0 + 4.0 * 4.0 + 2.0 * 4.0 * maps_px)
+    bytes_surf = px * (1.0 + 4.0 * 4.0 + 2.0 * 4.0 * 4.0 * (0.25 + 0.0625))
     # BRISK per image: the image read by the two resamplings and the score pass, 1.0 byte per pixel of coarser layers
     # written and read, 2.2 + 1 bytes per pixel of scores written once and read once, 16 bytes per keypoint out
     bytes_brisk = px * (3.0 + 2.0 * 1.0 + 2.0 * 3.2)
@@ -586,8 +587,8 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
                                     "frac": (bytes_surf * nb + 16.0 * surf_b) / (batched["surf_detection"] * 1e-3) / 1e9 / 8000.0,
                                     "lookups_per_s": 32.0 * maps_px * px * nb / (batched["surf_detection"] * 1e-3),
                                     "note": "six launches serve the batch; the response pass makes 32 four-byte lookups of the "
-                                            "integral image per response (1.9 MB per image, L2-resident), which is what it "
-                                            "is bound by"},
+                                            "integral image per response (LDS tiles for octave 0, the L2-resident 1.9 MB "
+                                            "integral image for octaves 1 and 2), which is what it is bound by"},
                  "pyramid_build": {"ms": batched["pyramid_build"], "algorithmic_bytes": bytes_pyr * nb,
                                    "achieved_gbs": bytes_pyr * nb / (batched["pyramid_build"] * 1e-3) / 1e9, "peak_gbs": 8000.0,
                                    "frac": bytes_pyr * nb / (batched["pyramid_build"] * 1e-3) / 1e9 / 8000.0,

@@ -32,8 +32,8 @@
 //                                  levels tested there; its maps never reach memory.  The 8 maps of octaves 1 and 2:
 //                                  a thread per sample through the caches (the integral image stays in L2: 1.9 MB for
 //                                  1241 x 376).  32 lookups per response (exact integer box sums, fp64 determinant).
-//   surf_extrema_kernel            (octaves 1, 2) a workgroup per tile of 64 x 4 samples of an octave: the four levels of the tile
-//                                  and a one-sample ring go to LDS once (6.3 KB), every thread tests its sample
+//   surf_extrema_kernel            octaves 1 and 2: a workgroup per tile of 64 x 4 samples, whose four levels
+//                                  and a one-sample ring go to LDS once (6.3 KB); every thread tests its sample
 //                                  on both middle levels from there and refines the hits; a wavefront = one row
 //                                  of 64 samples = one (octave, level, row, span) sub-cell, whose points become
 //                                  records in sample order (ballot ranks) and whose count is added to its
@@ -41,8 +41,8 @@
 //   surf_emit_kernel               one wavefront per sub-cell that holds points: ranks it behind the cells before
 //                                  its own and the spans before it in its cell, and writes its records there.
 //                                  Ordered and deterministic.
-// Per image: the uint8 image read once, the integral image written twice and read ~3 times, 2.45 M
-// responses (9.8 MB for 1241 x 376) written once and read once, 16 bytes per point written twice.
+// Per image: the uint8 image read once, the integral image written twice and read ~3 times, the 0.58 M
+// responses of octaves 1 and 2 (2.3 MB for 1241 x 376) written once and read once, 16 bytes per point written twice.
 #include "vohip_internal.h"
 
 #include <cmath>
@@ -550,7 +550,7 @@ surf_norms make_norms(const surf_geom &g)
     return nm;
 }
 
-// The six launches over n images whose scratch lies image after image at `scratch`.
+// The launches over n images whose scratch lies image after image at `scratch`.
 int enqueue_images(vohip_ctx *ctx, hipStream_t st, void *scratch, surf_geom g, const uint8_t *d_imgs, int n, int colmajor,
                    double metric_threshold, int border, float *d_xy, float *d_metric, float *d_scale, int cap, int *d_counts)
 {
