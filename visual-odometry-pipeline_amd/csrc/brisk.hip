@@ -21,10 +21,13 @@
 //   brisk_layers_kernel    all layers above the image in one launch, a thread per output pixel: the nested means
 //                          straight from the image (integer functions: the values of a layer by layer construction);
 //   brisk_sample_kernel    for a batch of images: one layer from the one it is made of, seven launches
-//   brisk_score_kernel     all layers in one launch: 64 x 16 tiles with a 3 px halo staged in LDS as integers, the
-//                          segment-test score of every pixel -> one byte; layer 0's 5-8 scores from the same tile;
-//                          the maximum of all scores by one atomic per workgroup
-//   brisk_extrema_kernel   all layers in one launch, a wavefront per span of 64 pixels of a row: the tests above from
+//   brisk_score_kernel     all layers in one launch: 64 x 16 tiles with a 3 px halo staged in LDS as integers; every
+//                          pixel takes the four-lookup compass test a passing pixel cannot fail, the few that pass
+//                          queue up in LDS and get the full segment-test score, the others score 0 -> one byte per
+//                          pixel; layer 0's 5-8 scores from the same tile; the maximum of all scores by one atomic
+//                          per workgroup
+//   brisk_extrema_kernel   all layers in one launch, a wavefront per span of 64 pixels of a row (it ends at once when
+//                          the score pass has marked the span as holding no score above 0): the tests above from
 //                          the score maps (L2-resident bytes), the hits become records in pixel order (ballot ranks),
 //                          counted per span and, by an integer atomic, per (layer, row) cell
 //   brisk_emit_kernel      a wavefront per non-empty span ranks it behind the cells and spans before it and copies
@@ -196,16 +199,19 @@ __global__ __launch_bounds__(256) void brisk_sample_kernel(const uint8_t *__rest
 
 // px0: the images (layer 0); px: the pyramid blocks; sc: the score blocks; smax: an image's maximum score.
 __global__ __launch_bounds__(256) void brisk_score_kernel(const uint8_t *__restrict__ px0, const uint8_t *__restrict__ px,
-                                                          uint8_t *__restrict__ sc, int *__restrict__ smax, brisk_geom g,
-                                                          int threshold)
+                                                          uint8_t *__restrict__ sc, int *__restrict__ smax,
+                                                          int *__restrict__ subs, brisk_geom g, int threshold)
 {
     px0 += blockIdx.y * g.img_stride;
     px += blockIdx.y * g.px_stride;
     sc += blockIdx.y * g.sc_stride;
     smax += blockIdx.y * g.cell_stride;
+    subs += blockIdx.y * g.sub_stride;
     __shared__ int sI[BK_FA * BK_FB];
-    __shared__ int sMax;
-    const int tid = threadIdx.x;
+    __shared__ int sMax, sQn;
+    __shared__ unsigned sRows;   // bit r: row r of the tile holds a score above 0
+    __shared__ unsigned short sQ[BK_TA * BK_TB];
+    const int tid = threadIdx.x, lane = tid & 63;
     int k = 0;
 #pragma unroll
     for (int q = 1; q < BK_LAYERS; ++q) k += (int)blockIdx.x >= g.tile_first[q] ? 1 : 0;
@@ -213,7 +219,11 @@ __global__ __launch_bounds__(256) void brisk_score_kernel(const uint8_t *__restr
     const uint8_t *img = k == 0 ? px0 : px + g.px_off[k];
     const int t = (int)blockIdx.x - g.tile_first[k];
     const int a0 = (t % g.tiles_a[k]) * BK_TA, b0 = (t / g.tiles_a[k]) * BK_TB;
-    if (tid == 0) sMax = 0;
+    if (tid == 0) {
+        sMax = 0;
+        sQn = 0;
+        sRows = 0u;
+    }
     // (every load of the thread issued before the first one is waited for)
     constexpr int N = BK_FA * BK_FB, ROUNDS = (N + 255) / 256;
     uint8_t v[ROUNDS];
@@ -230,29 +240,61 @@ __global__ __launch_bounds__(256) void brisk_score_kernel(const uint8_t *__restr
         if (q < N) sI[q] = (int)v[r];
     }
     __syncthreads();
-    int best = 0;
+    // Two rounds.  An arc of 9 of the 16 circle pixels holds two neighbouring compass points (top, right, bottom,
+    // left), so a pixel whose score reaches the threshold has two neighbouring compass points both brighter than the
+    // centre by more than the threshold, or both darker: every pixel takes that test of four lookups, the few that
+    // pass (a few per cent at the toolbox's MinContrast) queue up in LDS and the full segment test then runs on the
+    // queue with all lanes busy.  The others score 0, as the full test would have said.
+    const int T = threshold + 1;
+    static_assert(BK_TA * BK_TB % 256 == 0, "every thread makes the same number of rounds (ballots)");
     for (int q = tid; q < BK_TA * BK_TB; q += 256) {
         const int rb = q / BK_TA, ra = q - rb * BK_TA;
         const int a = a0 + ra, b = b0 + rb;
-        if (a >= A || b >= B) continue;
         const int *c = sI + (rb + 3) * BK_FA + (ra + 3);
-        int score = 0;
-        if (a >= 3 && a < A - 3 && b >= 3 && b < B - 3) {
-            const int s = vohip_dev::fast_score_9_16(c, BK_FA);
-            score = s >= threshold ? s : 0;
+        bool cand = false;
+        if (a < A && b < B) {
+            if (a >= 3 && a < A - 3 && b >= 3 && b < B - 3) {
+                const int p = c[0];
+                const int d0 = c[-3 * BK_FA] - p, d4 = c[3] - p, d8 = c[3 * BK_FA] - p, d12 = c[-3] - p;
+                const bool b0_ = d0 >= T, b4 = d4 >= T, b8 = d8 >= T, b12 = d12 >= T;
+                const bool k0 = d0 <= -T, k4 = d4 <= -T, k8 = d8 <= -T, k12 = d12 <= -T;
+                cand = ((b0_ | b8) & (b4 | b12)) | ((k0 | k8) & (k4 | k12));
+            }
+            if (!cand) sc[g.sc_off[k] + (size_t)b * A + a] = (uint8_t)0;
+            if (k == 0) {
+                const int s58 = a >= 1 && a < A - 1 && b >= 1 && b < B - 1 ? vohip_dev::fast_score_5_8(c, BK_FA) : 0;
+                sc[g.sc_off[BK_LAYERS] + (size_t)b * A + a] = (uint8_t)s58;
+            }
         }
-        sc[g.sc_off[k] + (size_t)b * A + a] = (uint8_t)score;
+        const unsigned long long bal = __ballot(cand);
+        if (bal) {   // (wave-uniform)
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sQn, __popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (cand) sQ[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)q;
+        }
+    }
+    __syncthreads();
+    int best = 0;
+    for (int i = tid, n = sQn; i < n; i += 256) {
+        const int q = sQ[i];
+        const int rb = q / BK_TA, ra = q - rb * BK_TA;
+        const int s = vohip_dev::fast_score_9_16(sI + (rb + 3) * BK_FA + (ra + 3), BK_FA);
+        const int score = s >= threshold ? s : 0;
+        sc[g.sc_off[k] + (size_t)(b0 + rb) * A + (a0 + ra)] = (uint8_t)score;
         best = max(best, score);
-        if (k == 0) {
-            const int s58 = a >= 1 && a < A - 1 && b >= 1 && b < B - 1 ? vohip_dev::fast_score_5_8(c, BK_FA) : 0;
-            sc[g.sc_off[BK_LAYERS] + (size_t)b * A + a] = (uint8_t)s58;
-        }
+        if (score > 0) atomicOr(&sRows, 1u << rb);
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) best = max(best, __shfl_xor(best, m, 64));
     if ((tid & 63) == 0 && best > 0) atomicMax(&sMax, best);
     __syncthreads();
     if (tid == 0 && sMax > 0) atomicMax(smax, sMax);
+    // a tile is as wide as the spans of the extrema pass: tell that pass which spans of a row hold no score at all
+    // (most of them), so that it does not read them; it replaces the mark by the span's number of keypoints
+    static_assert(BK_TA == 64, "a tile row = a span of the extrema pass");
+    if (tid < BK_TB && b0 + tid < B)
+        subs[g.sub_first[k] + (b0 + tid) * g.spans[k] + a0 / BK_TA] = (sRows >> tid) & 1u ? -1 : 0;
 }
 
 __device__ __forceinline__ int floor_div(int n, int d) { return n >= 0 ? n / d : -((-n + d - 1) / d); }
@@ -287,6 +329,8 @@ __global__ __launch_bounds__(256) void brisk_extrema_kernel(const uint8_t *__res
     const int t = (int)blockIdx.x - g.xt_first[k];
     const int span = t % g.spans[k], b = (t / g.spans[k]) * 4 + wave, a = span * 64 + lane;
     if (b >= B) return;   // (a whole wavefront)
+    const int sub = g.sub_first[k] + b * g.spans[k] + span;
+    if (subs[sub] == 0) return;   // (a whole wavefront: the score pass found nothing above 0 in this span)
     const float thr = min_quality * (float)cells[g.cell_first[BK_LAYERS]];   // (the slot behind the cells: the maximum score)
     const uint8_t *S = sc + g.sc_off[k];
     bool hit = false;
@@ -346,7 +390,6 @@ __global__ __launch_bounds__(256) void brisk_extrema_kernel(const uint8_t *__res
     }
     const unsigned long long bal = __ballot(hit);
     const int n = __popcll(bal);
-    const int sub = g.sub_first[k] + b * g.spans[k] + span;
     if (hit) recs[(size_t)sub * BK_SUB_CAP + __popcll(bal & ((1ull << lane) - 1ull))] = pt;
     if (lane == 0) {
         subs[sub] = n;
@@ -433,7 +476,7 @@ int enqueue_images(vohip_ctx *ctx, hipStream_t st, void *scratch, brisk_geom g, 
     const int lo = border < 1 ? 1 : border, nsubs = g.sub_first[BK_LAYERS];
     int *smax = cells + g.cell_first[BK_LAYERS];
     hipLaunchKernelGGL(brisk_score_kernel, dim3(g.tile_first[BK_LAYERS], n), dim3(256), 0, st, d_imgs, (const uint8_t *)px, sc,
-                       smax, g, (int)std::floor(min_contrast * 255.0 + 0.5));
+                       smax, subs, g, (int)std::floor(min_contrast * 255.0 + 0.5));
     hipLaunchKernelGGL(brisk_extrema_kernel, dim3(g.xt_first[BK_LAYERS], n), dim3(256), 0, st, (const uint8_t *)sc, cells, subs,
                        recs, g, (float)min_quality, lo);
     hipLaunchKernelGGL(brisk_emit_kernel, dim3((nsubs + 3) / 4, n), dim3(256), 0, st, (const int *)cells, (const int *)subs,
