@@ -609,6 +609,12 @@ int vohip_detect_fast(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, in
                       double min_quality, int border, float *xy_out, float *metric_out, int cap, int *n_out);
 int vohip_detect_fast_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int cols, int colmajor, double min_contrast,
                           double min_quality, int border, float *d_xy, float *d_metric, int cap, int *d_count);
+/* vohip_detect_fast_dev for n images of one size stored one after the other, with the output layout of
+ * vohip_detect_corners_batch_dev: the lists of n single calls, bit for bit (main_eval.m:172-173's variant over a
+ * stored sequence; no counterpart in the reference, which reads one image per iteration).  Asynchronous. */
+int vohip_detect_fast_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                                double min_contrast, double min_quality, int border, float *d_xy, float *d_metric, int cap,
+                                int *d_counts);
 
 /* Stands in for genKeypoints.m:1-33 with method 'SURF', the reference's default detector (dispatch table
  * genKeypoints.m:16; main_demo.m:25; main_eval.m:151,167 pass {'MetricThreshold', 10 / 200}):

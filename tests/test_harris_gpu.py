@@ -159,3 +159,42 @@ def test_batched_detection_and_pyramids_equal_single_calls(vo, ctx, method):
         assert off == per
         pyr.release()
     del stream
+
+
+def test_batched_fast_equals_single_calls(vo, ctx):
+    """vohip_detect_fast_batch_dev over a stored sequence: every image's list is that of a single call, bit for bit;
+    the corner batch call takes Harris and MinEigen only."""
+    import torch
+    lib = vo._lib.load()
+    scene = vo.synth.CorridorScene(seed=12, width=640, height=232)
+    poses = vo.synth.corridor_trajectory(5, step=0.7)
+    frames = np.stack([scene.render(T) for T in poses])
+    n, rows, cols = frames.shape
+    dev = torch.device("cuda", 0)
+    d_imgs = torch.from_numpy(frames).to(dev)
+    cap = 4096
+    d_xy = torch.zeros((n, 2, cap), dtype=torch.float32, device=dev)
+    d_metric = torch.zeros((n, cap), dtype=torch.float32, device=dev)
+    d_counts = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(2):   # (a second batch on the same scratch)
+        ctx.check(lib.vohip_detect_fast_batch_dev(ctx.handle, d_imgs.data_ptr(), n, rows, cols, 0, 0.11, 0.1, 16,
+                                                  d_xy.data_ptr(), d_metric.data_ptr(), cap, d_counts.data_ptr()))
+    ctx.synchronize()
+    counts = d_counts.cpu().numpy()
+    assert counts.min() > 100
+    s_xy = torch.zeros((2, cap), dtype=torch.float32, device=dev)
+    s_metric = torch.zeros(cap, dtype=torch.float32, device=dev)
+    s_count = torch.zeros(1, dtype=torch.int32, device=dev)
+    for k in range(n):
+        ctx.check(lib.vohip_detect_fast_dev(ctx.handle, d_imgs[k].data_ptr(), rows, cols, 0, 0.11, 0.1, 16, s_xy.data_ptr(),
+                                            s_metric.data_ptr(), cap, s_count.data_ptr()))
+        ctx.synchronize()
+        c = int(s_count.item())
+        assert c == counts[k]
+        assert torch.equal(s_xy[:, :c], d_xy[k][:, :c]) and torch.equal(s_metric[:c], d_metric[k][:c])
+    for bad_method in (2, 3, 4):
+        assert lib.vohip_detect_corners_batch_dev(ctx.handle, d_imgs.data_ptr(), n, rows, cols, 0, 2e-4, 5, 16, bad_method,
+                                                  d_xy.data_ptr(), d_metric.data_ptr(), cap, d_counts.data_ptr()) != 0
+    assert lib.vohip_detect_fast_batch_dev(ctx.handle, d_imgs.data_ptr(), n, rows, cols, 0, 0.0, 0.1, 16, d_xy.data_ptr(),
+                                           d_metric.data_ptr(), cap, d_counts.data_ptr()) != 0

@@ -1,6 +1,6 @@
 """Launch sequences of the detectors of genKeypoints.m:16-19 on one KITTI-shape frame resident on the GPU, for a
 kernel trace:  rocprofv3 --kernel-trace --stats -d <dir> -- python3 tools/detector_timing.py [--reps 200]
-Prints the wall time per call of each detector (events on the library's stream) and of the batched SURF call."""
+Prints the wall time per call of each detector (events on the library's stream) and per frame of the batched calls."""
 import argparse
 import importlib
 import json
@@ -55,17 +55,27 @@ def main():
     b_xy = torch.zeros((nb, 2 * cap), dtype=torch.float32, device=dev)
     b_metric = torch.zeros((nb, cap), dtype=torch.float32, device=dev)
     b_counts = torch.zeros(nb, dtype=torch.int32, device=dev)
-    fn = lambda: lib.vohip_detect_surf_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 200.0, 16, b_xy.data_ptr(),
-                                                 b_metric.data_ptr(), cap, b_counts.data_ptr())
-    ctx.check(fn())
-    ctx.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(5):
+    args_b = (b_xy.data_ptr(), b_metric.data_ptr(), cap, b_counts.data_ptr())
+    batch_calls = {
+        "Harris_batch": lambda: lib.vohip_detect_corners_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 2e-4, 5, 16,
+                                                                   0, *args_b),
+        "FAST_batch": lambda: lib.vohip_detect_fast_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 0.11, 0.1, 16,
+                                                              *args_b),
+        "BRISK_batch": lambda: lib.vohip_detect_brisk_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 0.2, 2e-3, 4,
+                                                                16, *args_b),
+        "SURF_batch": lambda: lib.vohip_detect_surf_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 200.0, 16,
+                                                              *args_b),
+    }
+    for name, fn in batch_calls.items():
         ctx.check(fn())
-    e1.record(stream)
-    ctx.synchronize()
-    out["SURF_batch"] = {"frames": nb, "us_per_frame": 1e3 * e0.elapsed_time(e1) / 5 / nb}
+        ctx.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(5):
+            ctx.check(fn())
+        e1.record(stream)
+        ctx.synchronize()
+        out[name] = {"frames": nb, "us_per_frame": 1e3 * e0.elapsed_time(e1) / 5 / nb}
     # the 'Des_match' bootstrap's two stages on this frame's SURF points (host arrays in and out, as the bootstrap calls them)
     import time
     feats, pts = vo.genKeypoints(frame, "SURF", ["MetricThreshold", 200], ctx=ctx, with_features=True)

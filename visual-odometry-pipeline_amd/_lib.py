@@ -186,6 +186,8 @@ SIGNATURES = {
                                      c_float_p, c_float_p, C.c_int, c_int_p]),
     "vohip_detect_fast_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                          C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "vohip_detect_fast_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                               C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "vohip_detect_surf": (C.c_int, [C.c_void_p, c_uint8_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, c_float_p,
                                      c_float_p, c_float_p, C.c_int, c_int_p]),
     "vohip_detect_surf_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,

@@ -679,6 +679,7 @@ int vohip_detect_corners_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n,
                                    float *d_metric, int cap, int *d_counts)
 {
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    VOHIP_REQUIRE(ctx, method == 0 || method == 1, "method: 0 = Harris, 1 = MinEigen");
     return vohip_detect_corners_batch_enqueue(ctx, d_imgs, n, rows, cols, colmajor, min_quality, filter_size, border, method,
                                               d_xy, d_metric, cap, d_counts);
 }
@@ -699,6 +700,15 @@ int vohip_detect_fast_dev(vohip_ctx *ctx, const uint8_t *d_img, int rows, int co
     if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
     return detect_dev(ctx, d_img, rows, cols, colmajor, min_quality, FS, border, 2, min_contrast, d_xy, d_metric, cap,
                       d_count);
+}
+
+int vohip_detect_fast_batch_dev(vohip_ctx *ctx, const uint8_t *d_imgs, int n, int rows, int cols, int colmajor,
+                                double min_contrast, double min_quality, int border, float *d_xy, float *d_metric, int cap,
+                                int *d_counts)
+{
+    if (!ctx) return VOHIP_ERR_INVALID_ARGUMENT;
+    return vohip_detect_corners_batch_enqueue(ctx, d_imgs, n, rows, cols, colmajor, min_quality, FS, border, 2, d_xy, d_metric,
+                                              cap, d_counts, min_contrast);
 }
 
 int vohip_detect_fast(vohip_ctx *ctx, const uint8_t *img, int rows, int cols, int colmajor, double min_contrast,
