@@ -544,9 +544,14 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
         ctx.check(lib.vohip_detect_surf_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 200.0, 16,
                                                   b_xy.data_ptr(), b_metric.data_ptr(), cap, b_counts.data_ptr()))
 
+    def detect_fast_batch():   # main_eval.m:172-173
+        ctx.check(lib.vohip_detect_fast_batch_dev(ctx.handle, d_batch.data_ptr(), nb, rows, cols, 0, 0.11, 0.1, 16,
+                                                  b_xy.data_ptr(), b_metric.data_ptr(), cap, b_counts.data_ptr()))
+
     batched = {}
     for name, fn in (("pyramid_build", build_batch), ("surf_detection", detect_surf_batch),
-                     ("brisk_detection", detect_brisk_batch), ("corner_detection", detect_batch)):
+                     ("brisk_detection", detect_brisk_batch), ("fast_detection", detect_fast_batch),
+                     ("corner_detection", detect_batch)):
         for _ in range(2):
             fn()
         torch.cuda.synchronize()
@@ -561,6 +566,8 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
             surf_b = float(torch.clamp(b_counts, max=cap).sum().item())
         if name == "brisk_detection":
             brisk_b = float(torch.clamp(b_counts, max=cap).sum().item())
+        if name == "fast_detection":
+            fast_b = float(torch.clamp(b_counts, max=cap).sum().item())
     corners_b = float(torch.clamp(b_counts, max=cap).sum().item())
     bytes_det_b = px * nb + 8.0 * corners_b
     # SURF per image: the image in, the integral image (4 bytes per pixel) written by the row pass, read and
@@ -597,6 +604,13 @@ def bench_image_kernels(vo, torch, ctx, d_frame, reps=50, d_frames=None):
                                    "note": "algorithmic_bytes counts every level written once and read once for the next one; "
                                            "compulsory_bytes = the image in and every level written once (levels 0 and 1 come "
                                            "out of one pass over the image, so level 0 is not read back)"},
+                 "fast_detection": {"ms": batched["fast_detection"], "corners": fast_b,
+                                    "algorithmic_bytes": px * nb + 8.0 * fast_b,
+                                    "achieved_gbs": (px * nb + 8.0 * fast_b) / (batched["fast_detection"] * 1e-3) / 1e9,
+                                    "peak_gbs": 8000.0,
+                                    "frac": (px * nb + 8.0 * fast_b) / (batched["fast_detection"] * 1e-3) / 1e9 / 8000.0,
+                                    "note": "about 180 integer operations per pixel (the segment-test score): bound by its "
+                                            "arithmetic, not by the byte per pixel it streams"},
                  "corner_detection": {"ms": batched["corner_detection"], "corners": corners_b, "algorithmic_bytes": bytes_det_b,
                                       "achieved_gbs": bytes_det_b / (batched["corner_detection"] * 1e-3) / 1e9,
                                       "peak_gbs": 8000.0,
