@@ -179,3 +179,35 @@ def test_main_eval_records_a_failed_run(vo, ctx, tmp_path):
             np.testing.assert_array_equal(recs[k][key], grouped[k][key], err_msg="%d %s" % (k, key))
     with pytest.raises((RuntimeError, vo.VohipError)):
         vo.main_eval(sequences, feats=("Harris",), repetition=2, seed=9, ctx=ctx, group=4)
+
+
+def test_run_dataset_reads_a_parking_layout_and_runs_main_demo(vo, ctx, tmp_path):
+    """main_demo.m with ds = 2 on a directory in that dataset's layout (images/img_%05d.png in colour, K.txt,
+    poses.txt; main_demo.m:100-116, :199-214, :360-362), written here from the rendered corridor: the run is the one
+    run_sequence makes from the same frames, with the scripts' SURF setting of that branch."""
+    import os
+    K = np.array([[400.0, 0, 320], [0, 400.0, 120], [0, 0, 1]])
+    scene = vo.synth.CorridorScene(K=K, width=640, height=240)
+    poses = vo.synth.corridor_trajectory(14, step=0.5)
+    frames = [scene.render(T) for T in poses]
+    root = str(tmp_path / "data")
+    os.makedirs(os.path.join(root, "parking", "images"))
+    for i, f in enumerate(frames):
+        vo.datasets.write_png(os.path.join(root, "parking", "images", "img_%05d.png" % i), np.dstack([f, f, f]))
+    np.savetxt(os.path.join(root, "parking", "K.txt"), K)
+    np.savetxt(os.path.join(root, "parking", "poses.txt"), np.array([T[:3].reshape(-1) for T in poses]))
+    out = vo.run_dataset(2, root, last_frame=13, save_dir=str(tmp_path / "res"), rng=np.random.default_rng(5), ctx=ctx)
+    assert out["frame_ct"] == 11 and out["frame_init"] == 3 and out["S"].est_trans.shape == (3, 12)
+    assert os.path.basename(out["path"]).startswith("dataset@parking_feat@SURF") and out["path"].endswith("_res.mat")
+    assert out["errs"].shape[0] == 3 and np.all(out["errs"] < 0.5)
+    hp = vo.dataset_config(2).hyper_paras
+    assert (hp.feature_extract, hp.feature_extract_options) == ("SURF", ["MetricThreshold", 100])
+    gt_xz = np.array([[T[0, 3], T[2, 3]] for T in poses])
+    ref = vo.run_sequence(frames, K, hp, ground_truth=gt_xz, bootstrap_frames=(0, 2), dataset="parking",
+                          rng=np.random.default_rng(5), ctx=ctx)
+    np.testing.assert_array_equal(out["S"].est_trans, ref["S"].est_trans)
+    np.testing.assert_array_equal(out["errs"], ref["errs"])
+    # the scripts' commented alternative (main_demo.m:27-28) as an override
+    alt = vo.run_dataset("parking", root, last_frame=13, rng=np.random.default_rng(5), ctx=ctx,
+                         hyper_paras={"feature_extract": "Harris", "feature_extract_options": ["MinQuality", 1e-4]})
+    assert alt["frame_ct"] == 11 and np.all(alt["errs"] < 0.5)
