@@ -211,3 +211,7 @@ def test_run_dataset_reads_a_parking_layout_and_runs_main_demo(vo, ctx, tmp_path
     alt = vo.run_dataset("parking", root, last_frame=13, rng=np.random.default_rng(5), ctx=ctx,
                          hyper_paras={"feature_extract": "Harris", "feature_extract_options": ["MinQuality", 1e-4]})
     assert alt["frame_ct"] == 11 and np.all(alt["errs"] < 0.5)
+    # the same directory as an entry of main_eval's sequence list (main_eval.m:16-23)
+    item = vo.eval_sequence(2, root, last_frame=13)
+    recs = vo.main_eval([item], feats=("Harris", "FAST"), repetition=1, seed=3, ctx=ctx)
+    assert len(recs) == 2 and all(not r.get("failed", False) for r in recs)

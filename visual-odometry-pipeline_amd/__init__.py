@@ -5,7 +5,7 @@ pipeline, behind the reference's own function names.  All arithmetic runs in lib
 from . import _lib
 from ._lib import Context, VohipError, default_context
 from . import batch, datasets, synth
-from .datasets import dataset_config, load_sequence, run_dataset
+from .datasets import dataset_config, eval_sequence, load_sequence, run_dataset
 from .ba import T_refinement, T_refinement_batch, baError, runBA
 from .bootstrap import (bootstrap, compProjMat, estimateEssentialMatrix, matching_init, pose_estimation_init,
                         relativeCameraPose, triangulation_init)

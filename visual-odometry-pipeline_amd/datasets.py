@@ -279,3 +279,12 @@ def run_dataset(ds, root="data", last_frame=None, hyper_paras=None, is_BA=False,
         run_options.setdefault("keyframe_d", 1)
     return run_sequence(seq.images, seq.K, hp, ground_truth=seq.ground_truth, bootstrap_frames=seq.bootstrap_frames,
                         dataset=seq.name, save_dir=save_dir, rng=rng, ctx=ctx, **run_options)
+
+
+def eval_sequence(ds, root="data", last_frame=None, reader=None):
+    """Dataset ds as an entry of evaluation.main_eval's `sequences` list, so that
+    main_eval([eval_sequence(0, root)], feats=MAIN_EVAL_FEATS, repetition=5) is main_eval.m:16-23 (which overrides the
+    feature options per variant, :165-174, and keeps the dataset's other settings)."""
+    seq = load_sequence(ds, root, last_frame=last_frame, reader=reader)
+    return dict(name=seq.name, images=seq.images, K=seq.K, ground_truth=seq.ground_truth,
+                bootstrap_frames=seq.bootstrap_frames, hyper_paras=seq.hyper_paras)
